@@ -1,0 +1,196 @@
+/* rnnt.h -- C-ABI of the MI355X-native RNN-T loss library (libwarprnnt.so).
+ *
+ * Source-compatible with the reference's public header
+ * (HawkAaron/warp-transducer include/rnnt.h:1-147): the same enums, the same
+ * by-value `rnntOptions`, and the same five exported symbols with the same
+ * argument meaning and status codes, so existing bindings compile and link
+ * against this library unchanged.  Each declaration cites the reference
+ * interface it replaces.  Everything under "Extensions" is new and optional.
+ *
+ * Contract kept from the reference:
+ *   - the library never allocates device or host memory: the caller asks
+ *     get_workspace_size() and passes a workspace in the same memory space as
+ *     the activations (reference src/rnnt_entrypoint.cpp:96-128, README.md:36-37);
+ *   - tensors are dense row-major (B, T, U, V), U = max_label_len + 1, labels
+ *     are a padded (B, U-1) int32 array (reference include/rnnt.h:69-80,
+ *     include/detail/gpu_rnnt_kernel.h:19);
+ *   - RNNT_GPU: activations are raw LOGITS (log-softmax is done inside),
+ *     gradients are dense d(loss)/d(logits); activations, gradients, workspace,
+ *     flat_labels, label_lengths and input_lengths are DEVICE pointers; costs is
+ *     a HOST pointer; the call returns after the stream has been synchronised
+ *     (reference include/detail/gpu_rnnt.h:75-80,107-110,208-213,
+ *     include/detail/gpu_rnnt_kernel.h:17-19);
+ *   - RNNT_CPU: activations are LOG-PROBS (caller applied log_softmax),
+ *     gradients are the sparse d(loss)/d(log-probs); all pointers are host
+ *     (reference include/detail/cpu_rnnt.h:253-304);
+ *   - gradients == NULL means score only (reference src/rnnt_entrypoint.cpp:65-72).
+ */
+#pragma once
+
+#ifdef __cplusplus
+#include <cstddef>
+#include <cstdint>
+extern "C" {
+#else
+#include <stddef.h>
+#include <stdint.h>
+#include <stdbool.h>
+#endif
+
+/* Opaque stream handle.  The reference forward-declares CUDA's CUstream
+ * (include/rnnt.h:13-14); the typedef name is kept so callers compile, and the
+ * value is interpreted as a hipStream_t (NULL = the default stream). */
+typedef struct CUstream_st* CUstream;
+
+/* reference include/rnnt.h:16-22 */
+typedef enum {
+    RNNT_STATUS_SUCCESS = 0,
+    RNNT_STATUS_MEMOPS_FAILED = 1,
+    RNNT_STATUS_INVALID_VALUE = 2,
+    RNNT_STATUS_EXECUTION_FAILED = 3,
+    RNNT_STATUS_UNKNOWN_ERROR = 4
+} rnntStatus_t;
+
+/* API version of the library; returns 1 (reference include/rnnt.h:25,
+ * src/rnnt_entrypoint.cpp:14-16). */
+int get_warprnnt_version();
+
+/* Text for a status code, same strings as the reference
+ * (include/rnnt.h:31, src/rnnt_entrypoint.cpp:18-35). */
+const char* rnntGetStatusString(rnntStatus_t status);
+
+/* reference include/rnnt.h:33-36 */
+typedef enum {
+    RNNT_CPU = 0,
+    RNNT_GPU = 1
+} rnntComputeLocation;
+
+/* Options, passed BY VALUE; zero-initialise before filling
+ * (reference include/rnnt.h:43-64; 32 bytes on LP64). */
+struct rnntOptions {
+    rnntComputeLocation loc;   /* where to compute: RNNT_CPU | RNNT_GPU          */
+    unsigned int num_threads;  /* RNNT_CPU: OpenMP threads (0 = runtime default)  */
+    CUstream stream;           /* RNNT_GPU: HIP stream the work is enqueued on    */
+    int blank_label;           /* index of the blank symbol                       */
+    int maxT;                  /* time dimension of the activation tensor         */
+    int maxU;                  /* label dimension of the tensor (max_label_len+1) */
+    bool batch_first;          /* RNNT_CPU layout flag; GPU is always (B,T,U,V)   */
+};
+#ifndef __cplusplus
+typedef struct rnntOptions rnntOptions;
+#endif
+
+/* RNN-T loss (negative log-likelihood per sample) and, when gradients != NULL,
+ * its gradient with respect to the activations.  fp32.
+ * Replaces reference include/rnnt.h:104-113 / src/rnnt_entrypoint.cpp:38-93.
+ * Returns RNNT_STATUS_INVALID_VALUE for NULL activations / flat_labels /
+ * label_lengths / input_lengths / costs / workspace, for alphabet_size,
+ * minibatch, options.maxT or options.maxU <= 0, and for an unknown options.loc. */
+rnntStatus_t compute_rnnt_loss(const float* const activations,
+                               float* gradients,
+                               const int* const flat_labels,
+                               const int* const label_lengths,
+                               const int* const input_lengths,
+                               int alphabet_size,
+                               int minibatch,
+                               float* costs,
+                               void* workspace,
+                               rnntOptions options);
+
+/* fp64 twin (reference include/rnnt.h:115-124, src/rnnt_entrypoint.cpp:130-185).
+ * On RNNT_GPU the lattice recursion is carried in fp64 as well. */
+rnntStatus_t compute_rnnt_loss_fp64(const double* const activations,
+                                    double* gradients,
+                                    const int* const flat_labels,
+                                    const int* const label_lengths,
+                                    const int* const input_lengths,
+                                    int alphabet_size,
+                                    int minibatch,
+                                    double* costs,
+                                    void* workspace,
+                                    rnntOptions options);
+
+/* Bytes of workspace compute_rnnt_loss* needs for these dimensions, in the
+ * memory space of the activations (gpu = true: device).  dtype_size is the
+ * element size of the activations (2, 4 or 8).  The reference's formula
+ * (src/rnnt_entrypoint.cpp:96-128) is private to it; callers always query,
+ * so only the signature and the no-internal-malloc contract are kept.
+ * Replaces reference include/rnnt.h:139-143.  INVALID_VALUE on dims <= 0. */
+rnntStatus_t get_workspace_size(int maxT, int maxU,
+                                int minibatch,
+                                bool gpu,
+                                size_t* size_bytes,
+#ifdef __cplusplus
+                                size_t dtype_size = sizeof(float));
+#else
+                                size_t dtype_size);
+#endif
+
+/* ------------------------------------------------------------------------- *
+ * Extensions (not in the reference).  GPU only.                              *
+ * ------------------------------------------------------------------------- */
+
+/* bf16 / fp16 activations and gradients (raw 16-bit storage), fp32 lattice and
+ * fp32 costs.  Same contract as compute_rnnt_loss with options.loc == RNNT_GPU;
+ * size the workspace with dtype_size = 2.  RNNT_CPU -> INVALID_VALUE. */
+rnntStatus_t compute_rnnt_loss_bf16(const uint16_t* const activations,
+                                    uint16_t* gradients,
+                                    const int* const flat_labels,
+                                    const int* const label_lengths,
+                                    const int* const input_lengths,
+                                    int alphabet_size,
+                                    int minibatch,
+                                    float* costs,
+                                    void* workspace,
+                                    rnntOptions options);
+
+rnntStatus_t compute_rnnt_loss_fp16(const uint16_t* const activations,
+                                    uint16_t* gradients,
+                                    const int* const flat_labels,
+                                    const int* const label_lengths,
+                                    const int* const input_lengths,
+                                    int alphabet_size,
+                                    int minibatch,
+                                    float* costs,
+                                    void* workspace,
+                                    rnntOptions options);
+
+/* Asynchronous form: identical work, but `costs_device` is a DEVICE array of
+ * `minibatch` elements (float for dtype_size 2/4, double for 8), nothing is
+ * copied to the host and the stream is NOT synchronised -- the call only
+ * enqueues (hipGraph-capturable).  `grad_scale_device`, when not NULL, points
+ * at `minibatch` device floats (doubles for fp64) that multiply each sample's
+ * gradient inside the gradient kernel (folds the autograd `grads.mul_(grad_out)`
+ * of reference pytorch_binding/warprnnt_pytorch/__init__.py:47-50 into the
+ * write-back).  dtype_code: 0 = fp32, 1 = fp64, 2 = bf16, 3 = fp16. */
+rnntStatus_t compute_rnnt_loss_async(const void* activations,
+                                     void* gradients,
+                                     const int* const flat_labels,
+                                     const int* const label_lengths,
+                                     const int* const input_lengths,
+                                     int alphabet_size,
+                                     int minibatch,
+                                     void* costs_device,
+                                     const void* grad_scale_device,
+                                     void* workspace,
+                                     rnntOptions options,
+                                     int dtype_code);
+
+/* Stage timing for benchmarks.  rnnt_profile_enable(1) makes every following
+ * GPU call record HIP events around its kernels on options.stream (no extra
+ * synchronisation); rnnt_profile_read() fills `ms` with the accumulated
+ * milliseconds per stage since the last rnnt_profile_reset() and returns the
+ * number of calls accumulated:
+ *   ms[0] row-stats kernel (log-softmax denominators + blank/label gather)
+ *   ms[1] lattice kernel   (alpha/beta recursion)
+ *   ms[2] coefficient kernel (per-cell gradient coefficients)
+ *   ms[3] gradient kernel  (dense gradient write-back)
+ *   ms[4] whole enqueue, first kernel start -> last kernel end
+ * Process-global, not thread-safe; meant for bench.py only. */
+void rnnt_profile_enable(int on);
+void rnnt_profile_reset(void);
+int rnnt_profile_read(double* ms, int n);
+
+#ifdef __cplusplus
+}
+#endif

@@ -1,0 +1,187 @@
+"""oracle/oracle.py -- TEST INFRASTRUCTURE ONLY.
+
+ctypes front-end to the CPU checkers:
+
+* ``liboracle.so``            -- our plain-C restatement (``rnnt_oracle.c``) and the
+                                 reference-stream generators (``gen.cpp``)
+* ``_ref/libwarprnnt_ref.so`` -- the reference's own CPU path compiled from the
+                                 reference sources (``oracle/Makefile``), when present
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg
+may import this module; the product package never does.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+_REF = None
+
+
+def build(quiet=True):
+    """(Re)build liboracle.so and, when /root/reference exists, _ref/."""
+    subprocess.run(["make", "-C", _HERE], check=True,
+                   stdout=subprocess.DEVNULL if quiet else None)
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        path = os.path.join(_HERE, "liboracle.so")
+        if not os.path.exists(path):
+            build()
+        _LIB = C.CDLL(path)
+        _LIB.oracle_gen_acts.argtypes = [C.c_void_p, C.c_size_t]
+        _LIB.oracle_gen_acts_f64.argtypes = [C.c_void_p, C.c_size_t]
+        _LIB.oracle_gen_labels.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        for suf in ("f32", "f64"):
+            getattr(_LIB, "oracle_log_softmax_" + suf).argtypes = [
+                C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
+            getattr(_LIB, "oracle_rnnt_logprobs_" + suf).argtypes = [
+                C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+            getattr(_LIB, "oracle_rnnt_logits_" + suf).argtypes = [
+                C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        _LIB.oracle_set_num_threads.argtypes = [C.c_int]
+        _LIB.oracle_num_threads.restype = C.c_int
+    return _LIB
+
+
+# --------------------------------------------------------------------------- generators
+def gen_acts(n, dtype=np.float32):
+    """tests/random.cpp:4-21 stream (mt19937(0), uniform(0,1))."""
+    out = np.empty(int(n), dtype=dtype)
+    if dtype == np.float32:
+        lib().oracle_gen_acts(out.ctypes.data, out.size)
+    else:
+        lib().oracle_gen_acts_f64(out.ctypes.data, out.size)
+    return out
+
+
+def gen_labels(alphabet_size, L):
+    """tests/random.cpp:22-38 stream (mt19937(1), uniform_int(1,A-1), forced repeats)."""
+    out = np.empty(int(L), dtype=np.int32)
+    lib().oracle_gen_labels(out.ctypes.data, int(alphabet_size), int(L))
+    return out
+
+
+# --------------------------------------------------------------------------- restatement
+def _suf(a):
+    if a.dtype == np.float32:
+        return "f32"
+    if a.dtype == np.float64:
+        return "f64"
+    raise TypeError("oracle works in float32 / float64")
+
+
+def _i32(x):
+    return np.ascontiguousarray(x, dtype=np.int32)
+
+
+def log_softmax(acts):
+    acts = np.ascontiguousarray(acts)
+    out = np.empty_like(acts)
+    A = acts.shape[-1]
+    getattr(lib(), "oracle_log_softmax_" + _suf(acts))(
+        acts.ctypes.data, acts.size // A, A, out.ctypes.data)
+    return out
+
+
+def rnnt_logprobs(log_probs, labels, act_lens, label_lens, blank=0, want_grad=True):
+    """Reference CPU contract: log-probs in, (costs, sparse grads wrt log-probs) out."""
+    lp = np.ascontiguousarray(log_probs)
+    N, T, U, A = lp.shape
+    labels, act_lens, label_lens = _i32(labels), _i32(act_lens), _i32(label_lens)
+    assert labels.shape == (N, U - 1) or U == 1
+    costs = np.empty(N, dtype=lp.dtype)
+    grads = np.empty_like(lp) if want_grad else None
+    getattr(lib(), "oracle_rnnt_logprobs_" + _suf(lp))(
+        lp.ctypes.data, grads.ctypes.data if want_grad else None, labels.ctypes.data,
+        label_lens.ctypes.data, act_lens.ctypes.data, A, N, T, U, blank, costs.ctypes.data)
+    return costs, grads
+
+
+def rnnt_logits(acts, labels, act_lens, label_lens, blank=0, want_grad=True):
+    """Reference GPU contract: logits in, (costs, dense grads wrt logits) out."""
+    x = np.ascontiguousarray(acts)
+    N, T, U, A = x.shape
+    labels, act_lens, label_lens = _i32(labels), _i32(act_lens), _i32(label_lens)
+    costs = np.empty(N, dtype=x.dtype)
+    grads = np.empty_like(x) if want_grad else None
+    scratch = np.empty_like(x)
+    getattr(lib(), "oracle_rnnt_logits_" + _suf(x))(
+        x.ctypes.data, grads.ctypes.data if want_grad else None, labels.ctypes.data,
+        label_lens.ctypes.data, act_lens.ctypes.data, A, N, T, U, blank, costs.ctypes.data,
+        scratch.ctypes.data)
+    return costs, grads
+
+
+# --------------------------------------------------------------------------- the real reference
+class rnntOptions(C.Structure):
+    # /root/reference/include/rnnt.h:43-64
+    _fields_ = [("loc", C.c_int), ("num_threads", C.c_uint), ("stream", C.c_void_p),
+                ("blank_label", C.c_int), ("maxT", C.c_int), ("maxU", C.c_int),
+                ("batch_first", C.c_bool)]
+
+
+def ref_path():
+    return os.path.join(_HERE, "_ref", "libwarprnnt_ref.so")
+
+
+def have_ref():
+    return os.path.exists(ref_path())
+
+
+def ref():
+    """The reference's own libwarprnnt (CPU build), if oracle/_ref holds it."""
+    global _REF
+    if _REF is None:
+        _REF = C.CDLL(ref_path())
+        for name in ("compute_rnnt_loss", "compute_rnnt_loss_fp64"):
+            f = getattr(_REF, name)
+            f.restype = C.c_int
+            f.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                          C.c_int, C.c_int, C.c_void_p, C.c_void_p, rnntOptions]
+        _REF.get_workspace_size.restype = C.c_int
+        _REF.get_workspace_size.argtypes = [C.c_int, C.c_int, C.c_int, C.c_bool,
+                                            C.POINTER(C.c_size_t), C.c_size_t]
+    return _REF
+
+
+def ref_rnnt_logprobs(log_probs, labels, act_lens, label_lens, blank=0, want_grad=True,
+                      num_threads=0):
+    """Call the REFERENCE's compute_rnnt_loss[_fp64] (RNNT_CPU, batch_first)."""
+    lp = np.ascontiguousarray(log_probs)
+    N, T, U, A = lp.shape
+    labels, act_lens, label_lens = _i32(labels), _i32(act_lens), _i32(label_lens)
+    costs = np.empty(N, dtype=lp.dtype)
+    grads = np.empty_like(lp) if want_grad else None
+    nbytes = C.c_size_t(0)
+    st = ref().get_workspace_size(T, U, N, False, C.byref(nbytes), lp.dtype.itemsize)
+    assert st == 0
+    ws = np.empty(nbytes.value + 16, dtype=np.uint8)
+    opt = rnntOptions(loc=0, num_threads=num_threads, stream=None, blank_label=blank,
+                      maxT=T, maxU=U, batch_first=True)
+    fn = ref().compute_rnnt_loss if lp.dtype == np.float32 else ref().compute_rnnt_loss_fp64
+    st = fn(lp.ctypes.data, grads.ctypes.data if want_grad else None, labels.ctypes.data,
+            label_lens.ctypes.data, act_lens.ctypes.data, A, N, costs.ctypes.data,
+            ws.ctypes.data, opt)
+    assert st == 0, st
+    return costs, grads
+
+
+def chain_rule_to_logits(log_probs, g_lp):
+    """g_logit = g_lp - softmax * sum_v g_lp  (SURVEY.md 8c)."""
+    s = g_lp.sum(axis=-1, keepdims=True)
+    return g_lp - np.exp(log_probs) * s
+
+
+def ref_rnnt_logits(acts, labels, act_lens, label_lens, blank=0, num_threads=0):
+    """Reference CPU path wrapped to the GPU contract (logits -> dense logit grads)."""
+    lp = log_softmax(np.ascontiguousarray(acts))
+    costs, g = ref_rnnt_logprobs(lp, labels, act_lens, label_lens, blank, True, num_threads)
+    return costs, chain_rule_to_logits(lp, g)

@@ -1,0 +1,179 @@
+// rnnt_device.h -- device-side building blocks for the gfx950 RNN-T kernels.
+//
+// Wave64 everywhere: one wavefront = 64 lanes, cross-lane traffic through DPP
+// (v_mov_b32_dpp wave_shr/wave_shl) and ds_bpermute shuffles, no 32-lane
+// assumptions (the reference's include/detail/reduce.h:5,22,32 hard-codes 32).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace rnnt {
+
+constexpr int kWave = 64;
+
+// ----------------------------------------------------------------------------- dtypes
+// Storage tags.  `store` is what sits in HBM, `comp` is the arithmetic type of the
+// row passes and of the lattice (fp32 for 16/32-bit storage, fp64 for fp64 storage).
+struct F32 { using store = float;    using comp = float;  };
+struct F64 { using store = double;   using comp = double; };
+struct BF16 { using store = uint16_t; using comp = float;  };
+struct F16 { using store = uint16_t; using comp = float;  };
+
+template <typename Tag> struct Vec {
+    static constexpr int N = 16 / sizeof(typename Tag::store);   // elements per 16-byte access
+};
+
+__device__ __forceinline__ float bf16_to_f32(uint16_t h) {
+    return __uint_as_float(static_cast<uint32_t>(h) << 16);
+}
+__device__ __forceinline__ uint16_t f32_to_bf16(float f) {   // round-to-nearest-even
+    uint32_t x = __float_as_uint(f);
+    if ((x & 0x7fffffffu) > 0x7f800000u) return static_cast<uint16_t>((x >> 16) | 0x40u);  // NaN
+    x += 0x7fffu + ((x >> 16) & 1u);
+    return static_cast<uint16_t>(x >> 16);
+}
+__device__ __forceinline__ float f16_to_f32(uint16_t h) {
+    _Float16 v;
+    __builtin_memcpy(&v, &h, 2);
+    return static_cast<float>(v);
+}
+__device__ __forceinline__ uint16_t f32_to_f16(float f) {
+    _Float16 v = static_cast<_Float16>(f);
+    uint16_t h;
+    __builtin_memcpy(&h, &v, 2);
+    return h;
+}
+
+template <typename Tag> __device__ __forceinline__ typename Tag::comp load1(const typename Tag::store* p);
+template <> __device__ __forceinline__ float load1<F32>(const float* p) { return *p; }
+template <> __device__ __forceinline__ double load1<F64>(const double* p) { return *p; }
+template <> __device__ __forceinline__ float load1<BF16>(const uint16_t* p) { return bf16_to_f32(*p); }
+template <> __device__ __forceinline__ float load1<F16>(const uint16_t* p) { return f16_to_f32(*p); }
+
+template <typename Tag> __device__ __forceinline__ void store1(typename Tag::store* p, typename Tag::comp v);
+template <> __device__ __forceinline__ void store1<F32>(float* p, float v) { *p = v; }
+template <> __device__ __forceinline__ void store1<F64>(double* p, double v) { *p = v; }
+template <> __device__ __forceinline__ void store1<BF16>(uint16_t* p, float v) { *p = f32_to_bf16(v); }
+template <> __device__ __forceinline__ void store1<F16>(uint16_t* p, float v) { *p = f32_to_f16(v); }
+
+// 16-byte packet <-> Vec<Tag>::N compute values.
+template <typename Tag> __device__ __forceinline__ void unpack(const uint4& raw, typename Tag::comp* v);
+template <> __device__ __forceinline__ void unpack<F32>(const uint4& r, float* v) {
+    v[0] = __uint_as_float(r.x); v[1] = __uint_as_float(r.y);
+    v[2] = __uint_as_float(r.z); v[3] = __uint_as_float(r.w);
+}
+template <> __device__ __forceinline__ void unpack<F64>(const uint4& r, double* v) {
+    v[0] = __hiloint2double(static_cast<int>(r.y), static_cast<int>(r.x));
+    v[1] = __hiloint2double(static_cast<int>(r.w), static_cast<int>(r.z));
+}
+template <> __device__ __forceinline__ void unpack<BF16>(const uint4& r, float* v) {
+    v[0] = __uint_as_float(r.x << 16); v[1] = __uint_as_float(r.x & 0xffff0000u);
+    v[2] = __uint_as_float(r.y << 16); v[3] = __uint_as_float(r.y & 0xffff0000u);
+    v[4] = __uint_as_float(r.z << 16); v[5] = __uint_as_float(r.z & 0xffff0000u);
+    v[6] = __uint_as_float(r.w << 16); v[7] = __uint_as_float(r.w & 0xffff0000u);
+}
+template <> __device__ __forceinline__ void unpack<F16>(const uint4& r, float* v) {
+    const uint32_t w[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        v[2 * i] = f16_to_f32(static_cast<uint16_t>(w[i] & 0xffffu));
+        v[2 * i + 1] = f16_to_f32(static_cast<uint16_t>(w[i] >> 16));
+    }
+}
+
+template <typename Tag> __device__ __forceinline__ uint4 pack(const typename Tag::comp* v);
+template <> __device__ __forceinline__ uint4 pack<F32>(const float* v) {
+    return make_uint4(__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]),
+                      __float_as_uint(v[3]));
+}
+template <> __device__ __forceinline__ uint4 pack<F64>(const double* v) {
+    return make_uint4(static_cast<uint32_t>(__double2loint(v[0])), static_cast<uint32_t>(__double2hiint(v[0])),
+                      static_cast<uint32_t>(__double2loint(v[1])), static_cast<uint32_t>(__double2hiint(v[1])));
+}
+template <> __device__ __forceinline__ uint4 pack<BF16>(const float* v) {
+    uint32_t w[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        w[i] = static_cast<uint32_t>(f32_to_bf16(v[2 * i])) | (static_cast<uint32_t>(f32_to_bf16(v[2 * i + 1])) << 16);
+    return make_uint4(w[0], w[1], w[2], w[3]);
+}
+template <> __device__ __forceinline__ uint4 pack<F16>(const float* v) {
+    uint32_t w[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        w[i] = static_cast<uint32_t>(f32_to_f16(v[2 * i])) | (static_cast<uint32_t>(f32_to_f16(v[2 * i + 1])) << 16);
+    return make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+// ----------------------------------------------------------------------------- math
+template <typename T> __device__ __forceinline__ T neg_inf();
+template <> __device__ __forceinline__ float neg_inf<float>() { return -__builtin_huge_valf(); }
+template <> __device__ __forceinline__ double neg_inf<double>() { return -__builtin_huge_val(); }
+
+// exp / log for the streaming passes and the lattice chain.  fp32 uses the hardware
+// v_exp_f32 / v_log_f32 paths; fp64 uses the full-precision library routines.
+__device__ __forceinline__ float fast_exp(float x) { return __expf(x); }
+__device__ __forceinline__ double fast_exp(double x) { return exp(x); }
+__device__ __forceinline__ float fast_log(float x) { return __logf(x); }
+__device__ __forceinline__ double fast_log(double x) { return log(x); }
+__device__ __forceinline__ float acc_log(float x) { return logf(x); }
+__device__ __forceinline__ double acc_log(double x) { return log(x); }
+__device__ __forceinline__ float vmax(float a, float b) { return fmaxf(a, b); }
+__device__ __forceinline__ double vmax(double a, double b) { return fmax(a, b); }
+__device__ __forceinline__ float vmin(float a, float b) { return fminf(a, b); }
+__device__ __forceinline__ double vmin(double a, double b) { return fmin(a, b); }
+
+// log(e^a + e^b); -inf is the additive zero (reference include/detail/rnnt_helper.h:16-24).
+__device__ __forceinline__ float log_add(float a, float b) {
+    float hi = fmaxf(a, b), lo = fminf(a, b);
+    float r = hi + __logf(1.0f + __expf(lo - hi));
+    return (hi == neg_inf<float>()) ? hi : r;
+}
+__device__ __forceinline__ double log_add(double a, double b) {
+    double hi = fmax(a, b), lo = fmin(a, b);
+    double r = hi + log1p(exp(lo - hi));
+    return (hi == neg_inf<double>()) ? hi : r;
+}
+
+// ----------------------------------------------------------------------------- cross-lane
+// Whole-wave shift by one lane through DPP.  shr: lane i receives lane i-1 (lane 0 gets
+// `fill`); shl: lane i receives lane i+1 (lane 63 gets `fill`).
+__device__ __forceinline__ int dpp_shr1(int v, int fill) {
+    return __builtin_amdgcn_update_dpp(fill, v, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+}
+__device__ __forceinline__ int dpp_shl1(int v, int fill) {
+    return __builtin_amdgcn_update_dpp(fill, v, 0x130 /* wave_shl:1 */, 0xf, 0xf, false);
+}
+__device__ __forceinline__ float wave_shr1(float v, float fill) {
+    return __int_as_float(dpp_shr1(__float_as_int(v), __float_as_int(fill)));
+}
+__device__ __forceinline__ float wave_shl1(float v, float fill) {
+    return __int_as_float(dpp_shl1(__float_as_int(v), __float_as_int(fill)));
+}
+__device__ __forceinline__ double wave_shr1(double v, double fill) {
+    int lo = dpp_shr1(__double2loint(v), __double2loint(fill));
+    int hi = dpp_shr1(__double2hiint(v), __double2hiint(fill));
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_shl1(double v, double fill) {
+    int lo = dpp_shl1(__double2loint(v), __double2loint(fill));
+    int hi = dpp_shl1(__double2hiint(v), __double2hiint(fill));
+    return __hiloint2double(hi, lo);
+}
+
+template <typename T> __device__ __forceinline__ T wave_max(T v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = vmax(v, __shfl_xor(v, off, kWave));
+    return v;
+}
+template <typename T> __device__ __forceinline__ T wave_sum(T v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, kWave);
+    return v;
+}
+
+// Force a wave-uniform value into an SGPR so that address arithmetic built on it is scalar.
+__device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+}  // namespace rnnt

@@ -1,0 +1,304 @@
+// rnnt_gpu.hip -- host driver of the gfx950 path and the exported C-ABI.
+//
+// Replaces, behaviour for behaviour, the reference's
+//   src/rnnt_entrypoint.cpp:14-185      (exports, validation, dispatch, workspace size)
+//   include/detail/gpu_rnnt.h:82-253    (GpuRNNT::compute_cost_and_score / cost_and_grad /
+//                                        score_forward: workspace carve, launches, D2H of costs)
+// The library never allocates memory: everything lives in the caller's workspace
+// (reference README.md:36-37).  The only host<->device traffic is the N-element copy of the
+// costs to the caller's HOST array followed by one stream synchronisation, which the
+// reference contract requires (gpu_rnnt.h:208-213).
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+
+#include "../../include/rnnt.h"
+#include "rnnt_cpu.h"
+#include "rnnt_kernels.h"
+
+namespace rnnt {
+
+// ----------------------------------------------------------------------------- workspace
+constexpr size_t kAlign = 256;
+static inline size_t align_up(size_t x) { return (x + kAlign - 1) / kAlign * kAlign; }
+
+struct Layout {
+    size_t cells, beta, offa, offb, llf, llb, costs, total;
+};
+
+// lat = bytes of one lattice value (4: fp32 lattice for 16/32-bit activations, 8: fp64).
+static Layout make_layout(int maxT, int maxU, int N, size_t lat) {
+    const size_t D = static_cast<size_t>(maxT) + maxU - 1;
+    const size_t sk = D * maxU * N;             // skewed lattice cells
+    Layout l{};
+    size_t o = 0;
+    l.cells = o; o = align_up(o + sk * 4 * lat);
+    l.beta = o;  o = align_up(o + (sk + maxU + 1) * lat);
+    l.offa = o;  o = align_up(o + D * N * sizeof(double));
+    l.offb = o;  o = align_up(o + D * N * sizeof(double));
+    l.llf = o;   o = align_up(o + N * sizeof(double));
+    l.llb = o;   o = align_up(o + N * sizeof(double));
+    l.costs = o; o = align_up(o + N * sizeof(double));
+    l.total = o + kAlign;                       // slack to align the caller's base pointer
+    return l;
+}
+
+// ----------------------------------------------------------------------------- profiling
+struct Profile {
+    bool on = false;
+    bool ready = false;
+    hipEvent_t ev[5];
+    double ms[5] = {0, 0, 0, 0, 0};
+    int calls = 0;
+};
+static Profile g_prof;
+
+static bool prof_prepare() {
+    if (!g_prof.on) return false;
+    if (!g_prof.ready) {
+        for (auto& e : g_prof.ev)
+            if (hipEventCreate(&e) != hipSuccess) return false;
+        g_prof.ready = true;
+    }
+    return true;
+}
+
+// ----------------------------------------------------------------------------- launch
+#define RNNT_LAUNCH_CHECK()                                        \
+    do {                                                           \
+        if (hipGetLastError() != hipSuccess) return RNNT_STATUS_EXECUTION_FAILED; \
+    } while (0)
+
+template <typename Tag>
+static rnntStatus_t run_gpu(const typename Tag::store* acts, typename Tag::store* grads,
+                            const int* labels, const int* label_lengths, const int* input_lengths,
+                            int A, int N, typename Tag::comp* costs_host,
+                            typename Tag::comp* costs_device_out, const typename Tag::comp* grad_scale,
+                            void* workspace, const rnntOptions& opt) {
+    using S = typename Tag::store;
+    using C = typename Tag::comp;
+    const int maxT = opt.maxT, maxU = opt.maxU, blank = opt.blank_label;
+    if (blank < 0 || blank >= A) return RNNT_STATUS_INVALID_VALUE;
+    if (maxU > 1024) return RNNT_STATUS_INVALID_VALUE;   // one lane per label position (as the reference)
+    if (static_cast<long long>(maxT) * maxU > 0x7fffffffLL / 4) return RNNT_STATUS_INVALID_VALUE;
+    if (N > 65535) return RNNT_STATUS_INVALID_VALUE;
+    hipStream_t stream = reinterpret_cast<hipStream_t>(opt.stream);
+    const bool training = grads != nullptr;
+
+    const Layout lay = make_layout(maxT, maxU, N, sizeof(C));
+    char* ws = reinterpret_cast<char*>(align_up(reinterpret_cast<size_t>(workspace)));
+    auto* cells = reinterpret_cast<Cell<C>*>(ws + lay.cells);
+    auto* beta = reinterpret_cast<C*>(ws + lay.beta);
+    auto* offa = reinterpret_cast<double*>(ws + lay.offa);
+    auto* offb = reinterpret_cast<double*>(ws + lay.offb);
+    auto* llf = reinterpret_cast<double*>(ws + lay.llf);
+    auto* llb = reinterpret_cast<double*>(ws + lay.llb);
+    C* costs_dev = costs_device_out ? costs_device_out : reinterpret_cast<C*>(ws + lay.costs);
+
+    // 16-byte packets need acts and grads rows to share their alignment phase.
+    const uintptr_t pa = reinterpret_cast<uintptr_t>(acts);
+    const uintptr_t pg = reinterpret_cast<uintptr_t>(grads);
+    int vec_ok = (pa % sizeof(S) == 0) ? 1 : 0;
+    if (training && ((pa ^ pg) & 15u)) vec_ok = 0;
+
+    const bool prof = costs_host != nullptr && prof_prepare();
+    auto mark = [&](int i) { if (prof) (void)hipEventRecord(g_prof.ev[i], stream); };
+
+    constexpr int WAVES = 4;
+    const int cells_per_sample = maxT * maxU;
+    const dim3 row_grid((cells_per_sample + WAVES - 1) / WAVES, N);
+    const int lat_threads = ((maxU + 63) / 64) * 64;
+    const int D = maxT + maxU - 1;
+
+    mark(0);
+    hipLaunchKernelGGL((row_stats_kernel<Tag, WAVES>), row_grid, dim3(WAVES * 64), 0, stream, acts,
+                       labels, input_lengths, label_lengths, cells, maxT, maxU, A, blank, vec_ok);
+    RNNT_LAUNCH_CHECK();
+    mark(1);
+    const int dirs = training ? 2 : 1;
+    if (lat_threads == 64)
+        hipLaunchKernelGGL((lattice_kernel<C, false>), dim3(N * dirs), dim3(64), 0, stream, cells, beta,
+                           offa, offb, llf, llb, costs_dev, input_lengths, label_lengths, maxT, maxU, dirs);
+    else
+        hipLaunchKernelGGL((lattice_kernel<C, true>), dim3(N * dirs), dim3(lat_threads), 0, stream, cells,
+                           beta, offa, offb, llf, llb, costs_dev, input_lengths, label_lengths, maxT, maxU,
+                           dirs);
+    RNNT_LAUNCH_CHECK();
+    mark(2);
+    if (training) {
+        const dim3 cgrid((D * maxU + 255) / 256, N);
+        hipLaunchKernelGGL((coef_kernel<C>), cgrid, dim3(256), 0, stream, cells, beta, offa, offb, llf,
+                           labels, input_lengths, label_lengths, maxT, maxU);
+        RNNT_LAUNCH_CHECK();
+        mark(3);
+        if (grad_scale)
+            hipLaunchKernelGGL((grad_kernel<Tag, WAVES, true>), row_grid, dim3(WAVES * 64), 0, stream, acts,
+                               grads, cells, input_lengths, label_lengths, grad_scale, maxT, maxU, A, blank,
+                               vec_ok);
+        else
+            hipLaunchKernelGGL((grad_kernel<Tag, WAVES, false>), row_grid, dim3(WAVES * 64), 0, stream, acts,
+                               grads, cells, input_lengths, label_lengths, grad_scale, maxT, maxU, A, blank,
+                               vec_ok);
+        RNNT_LAUNCH_CHECK();
+    } else {
+        mark(3);
+    }
+    mark(4);
+
+    if (costs_host) {
+        if (hipMemcpyAsync(costs_host, costs_dev, sizeof(C) * N, hipMemcpyDeviceToHost, stream) != hipSuccess)
+            return RNNT_STATUS_MEMOPS_FAILED;
+        if (hipStreamSynchronize(stream) != hipSuccess) return RNNT_STATUS_EXECUTION_FAILED;
+        if (prof) {
+            for (int i = 0; i < 4; ++i) {
+                float ms = 0.f;
+                if (hipEventElapsedTime(&ms, g_prof.ev[i], g_prof.ev[i + 1]) == hipSuccess) g_prof.ms[i] += ms;
+            }
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, g_prof.ev[0], g_prof.ev[4]) == hipSuccess) g_prof.ms[4] += ms;
+            g_prof.calls++;
+        }
+    }
+    return RNNT_STATUS_SUCCESS;
+}
+
+static bool bad_args(const void* acts, const int* labels, const int* label_lengths,
+                     const int* input_lengths, const void* costs, const void* workspace, int A, int N,
+                     const rnntOptions& o) {
+    // reference src/rnnt_entrypoint.cpp:49-59
+    return acts == nullptr || labels == nullptr || label_lengths == nullptr || input_lengths == nullptr ||
+           costs == nullptr || workspace == nullptr || A <= 0 || N <= 0 || o.maxT <= 0 || o.maxU <= 0;
+}
+
+}  // namespace rnnt
+
+using namespace rnnt;
+
+extern "C" {
+
+int get_warprnnt_version() { return 1; }
+
+const char* rnntGetStatusString(rnntStatus_t status) {
+    // Same strings as the reference (src/rnnt_entrypoint.cpp:18-35) so log scrapers keep working.
+    switch (status) {
+        case RNNT_STATUS_SUCCESS: return "no error";
+        case RNNT_STATUS_MEMOPS_FAILED: return "cuda memcpy or memset failed";
+        case RNNT_STATUS_INVALID_VALUE: return "invalid value";
+        case RNNT_STATUS_EXECUTION_FAILED: return "execution failed";
+        case RNNT_STATUS_UNKNOWN_ERROR:
+        default: return "unknown error";
+    }
+}
+
+rnntStatus_t get_workspace_size(int maxT, int maxU, int minibatch, bool gpu, size_t* size_bytes,
+                                size_t dtype_size) {
+    if (minibatch <= 0 || maxT <= 0 || maxU <= 0 || size_bytes == nullptr) return RNNT_STATUS_INVALID_VALUE;
+    const size_t lat = dtype_size >= 8 ? 8 : 4;
+    if (gpu)
+        *size_bytes = make_layout(maxT, maxU, minibatch, lat).total;
+    else
+        *size_bytes = cpu_workspace_bytes(maxT, maxU, minibatch, lat);
+    return RNNT_STATUS_SUCCESS;
+}
+
+rnntStatus_t compute_rnnt_loss(const float* const activations, float* gradients, const int* const flat_labels,
+                               const int* const label_lengths, const int* const input_lengths,
+                               int alphabet_size, int minibatch, float* costs, void* workspace,
+                               rnntOptions options) {
+    if (bad_args(activations, flat_labels, label_lengths, input_lengths, costs, workspace, alphabet_size,
+                 minibatch, options))
+        return RNNT_STATUS_INVALID_VALUE;
+    if (options.loc == RNNT_CPU)
+        return cpu_rnnt_f32(activations, gradients, flat_labels, label_lengths, input_lengths, alphabet_size,
+                            minibatch, costs, workspace, options);
+    if (options.loc == RNNT_GPU)
+        return run_gpu<F32>(activations, gradients, flat_labels, label_lengths, input_lengths, alphabet_size,
+                            minibatch, costs, nullptr, nullptr, workspace, options);
+    return RNNT_STATUS_INVALID_VALUE;
+}
+
+rnntStatus_t compute_rnnt_loss_fp64(const double* const activations, double* gradients,
+                                    const int* const flat_labels, const int* const label_lengths,
+                                    const int* const input_lengths, int alphabet_size, int minibatch,
+                                    double* costs, void* workspace, rnntOptions options) {
+    if (bad_args(activations, flat_labels, label_lengths, input_lengths, costs, workspace, alphabet_size,
+                 minibatch, options))
+        return RNNT_STATUS_INVALID_VALUE;
+    if (options.loc == RNNT_CPU)
+        return cpu_rnnt_f64(activations, gradients, flat_labels, label_lengths, input_lengths, alphabet_size,
+                            minibatch, costs, workspace, options);
+    if (options.loc == RNNT_GPU)
+        return run_gpu<F64>(activations, gradients, flat_labels, label_lengths, input_lengths, alphabet_size,
+                            minibatch, costs, nullptr, nullptr, workspace, options);
+    return RNNT_STATUS_INVALID_VALUE;
+}
+
+rnntStatus_t compute_rnnt_loss_bf16(const uint16_t* const activations, uint16_t* gradients,
+                                    const int* const flat_labels, const int* const label_lengths,
+                                    const int* const input_lengths, int alphabet_size, int minibatch,
+                                    float* costs, void* workspace, rnntOptions options) {
+    if (bad_args(activations, flat_labels, label_lengths, input_lengths, costs, workspace, alphabet_size,
+                 minibatch, options) || options.loc != RNNT_GPU)
+        return RNNT_STATUS_INVALID_VALUE;
+    return run_gpu<BF16>(activations, gradients, flat_labels, label_lengths, input_lengths, alphabet_size,
+                         minibatch, costs, nullptr, nullptr, workspace, options);
+}
+
+rnntStatus_t compute_rnnt_loss_fp16(const uint16_t* const activations, uint16_t* gradients,
+                                    const int* const flat_labels, const int* const label_lengths,
+                                    const int* const input_lengths, int alphabet_size, int minibatch,
+                                    float* costs, void* workspace, rnntOptions options) {
+    if (bad_args(activations, flat_labels, label_lengths, input_lengths, costs, workspace, alphabet_size,
+                 minibatch, options) || options.loc != RNNT_GPU)
+        return RNNT_STATUS_INVALID_VALUE;
+    return run_gpu<F16>(activations, gradients, flat_labels, label_lengths, input_lengths, alphabet_size,
+                        minibatch, costs, nullptr, nullptr, workspace, options);
+}
+
+rnntStatus_t compute_rnnt_loss_async(const void* activations, void* gradients, const int* const flat_labels,
+                                     const int* const label_lengths, const int* const input_lengths,
+                                     int alphabet_size, int minibatch, void* costs_device,
+                                     const void* grad_scale_device, void* workspace, rnntOptions options,
+                                     int dtype_code) {
+    if (bad_args(activations, flat_labels, label_lengths, input_lengths, costs_device, workspace,
+                 alphabet_size, minibatch, options) || options.loc != RNNT_GPU)
+        return RNNT_STATUS_INVALID_VALUE;
+    switch (dtype_code) {
+        case 0:
+            return run_gpu<F32>(static_cast<const float*>(activations), static_cast<float*>(gradients),
+                                flat_labels, label_lengths, input_lengths, alphabet_size, minibatch, nullptr,
+                                static_cast<float*>(costs_device), static_cast<const float*>(grad_scale_device),
+                                workspace, options);
+        case 1:
+            return run_gpu<F64>(static_cast<const double*>(activations), static_cast<double*>(gradients),
+                                flat_labels, label_lengths, input_lengths, alphabet_size, minibatch, nullptr,
+                                static_cast<double*>(costs_device),
+                                static_cast<const double*>(grad_scale_device), workspace, options);
+        case 2:
+            return run_gpu<BF16>(static_cast<const uint16_t*>(activations), static_cast<uint16_t*>(gradients),
+                                 flat_labels, label_lengths, input_lengths, alphabet_size, minibatch, nullptr,
+                                 static_cast<float*>(costs_device), static_cast<const float*>(grad_scale_device),
+                                 workspace, options);
+        case 3:
+            return run_gpu<F16>(static_cast<const uint16_t*>(activations), static_cast<uint16_t*>(gradients),
+                                flat_labels, label_lengths, input_lengths, alphabet_size, minibatch, nullptr,
+                                static_cast<float*>(costs_device), static_cast<const float*>(grad_scale_device),
+                                workspace, options);
+        default: return RNNT_STATUS_INVALID_VALUE;
+    }
+}
+
+void rnnt_profile_enable(int on) { g_prof.on = on != 0; }
+
+void rnnt_profile_reset(void) {
+    for (double& m : g_prof.ms) m = 0.0;
+    g_prof.calls = 0;
+}
+
+int rnnt_profile_read(double* ms, int n) {
+    for (int i = 0; i < n && i < 5; ++i) ms[i] = g_prof.ms[i];
+    return g_prof.calls;
+}
+
+}  // extern "C"

@@ -1,0 +1,135 @@
+"""warprnnt_pytorch -- drop-in for the reference's PyTorch binding, backed by the MI355X
+library (libwarprnnt.so, hand-written HIP for gfx950).
+
+Public surface identical to pytorch_binding/warprnnt_pytorch/__init__.py:
+``rnnt_loss(acts, labels, act_lens, label_lens, blank=0, reduction='mean')`` and
+``RNNTLoss(blank=0, reduction='mean')`` (reference __init__.py:8,53-100), same input checks
+and error types (``certify_inputs``, :103-140), same reduction semantics (:36-40), gradients
+computed in forward and scaled in backward (:43-50).
+"""
+import torch
+from torch.autograd import Function
+from torch.nn import Module
+
+from . import warp_rnnt
+
+__all__ = ['rnnt_loss', 'RNNTLoss']
+
+
+class _RNNT(Function):
+    @staticmethod
+    def forward(ctx, acts, labels, act_lens, label_lens, blank, reduction):
+        """
+        acts:       (batch, T, U, vocab) joint-network output; raw logits on the GPU,
+                    log-probabilities on the CPU (the wrappers below apply log_softmax there)
+        labels:     (batch, U-1) int32 targets, zero padded
+        act_lens:   (batch,) int32 number of valid time steps per sample
+        label_lens: (batch,) int32 number of valid labels per sample
+        """
+        is_cuda = acts.is_cuda
+        certify_inputs(acts, labels, act_lens, label_lens)
+
+        loss_func = warp_rnnt.gpu_rnnt if is_cuda else warp_rnnt.cpu_rnnt
+        # The library overwrites every element of grads (zeros in the padded region), so no
+        # zero-fill is needed (the reference allocates zeros_like: __init__.py:24).
+        grads = torch.empty_like(acts) if acts.requires_grad else torch.zeros(0).to(acts)
+        minibatch_size = acts.size(0)
+        cost_dtype = acts.dtype if acts.dtype in (torch.float32, torch.float64) else torch.float32
+        costs = torch.zeros(minibatch_size, dtype=cost_dtype)   # host, as the C-ABI requires
+        loss_func(acts, labels, act_lens, label_lens, costs, grads, blank, 0)
+
+        if reduction in ['sum', 'mean']:
+            costs = costs.sum().unsqueeze_(-1)
+            if reduction == 'mean':
+                costs /= minibatch_size
+                grads /= minibatch_size
+
+        costs = costs.to(acts.device)
+        ctx.grads = grads
+        return costs
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        grad_output = grad_output.view(-1, 1, 1, 1).to(ctx.grads)
+        return ctx.grads.mul_(grad_output), None, None, None, None, None
+
+
+def rnnt_loss(acts, labels, act_lens, label_lens, blank=0, reduction='mean'):
+    """RNN Transducer loss.
+
+    Args:
+        acts: (batch, T, U, vocab) tensor, output of the joint network
+        labels: (batch, U-1) int32 tensor of targets, zero padded
+        act_lens: (batch,) int32 tensor, valid time steps of each sample
+        label_lens: (batch,) int32 tensor, valid labels of each sample
+        blank (int, optional): blank label. Default: 0.
+        reduction (string, optional): 'none' | 'mean' | 'sum'. 'none': per-sample losses;
+            'sum': summed over the batch (shape (1,)); 'mean': the sum divided by the batch
+            size. Default: 'mean'
+    """
+    if not acts.is_cuda:
+        acts = torch.nn.functional.log_softmax(acts, -1)
+    return _RNNT.apply(acts, labels, act_lens, label_lens, blank, reduction)
+
+
+class RNNTLoss(Module):
+    """
+    Parameters:
+        blank (int, optional): blank label. Default: 0.
+        reduction (string, optional): 'none' | 'mean' | 'sum' (see `rnnt_loss`). Default: 'mean'
+    """
+
+    def __init__(self, blank=0, reduction='mean'):
+        super(RNNTLoss, self).__init__()
+        self.blank = blank
+        self.reduction = reduction
+        self.loss = _RNNT.apply
+
+    def forward(self, acts, labels, act_lens, label_lens):
+        if not acts.is_cuda:
+            # The CPU location of the library takes log-probabilities; log_softmax runs inside
+            # the kernels only on the GPU (reference __init__.py:95-98).
+            acts = torch.nn.functional.log_softmax(acts, -1)
+        return self.loss(acts, labels, act_lens, label_lens, self.blank, self.reduction)
+
+
+def check_type(var, t, name):
+    if var.dtype is not t:
+        raise TypeError("{} must be {}".format(name, t))
+
+
+def check_contiguous(var, name):
+    if not var.is_contiguous():
+        raise ValueError("{} must be contiguous".format(name))
+
+
+def check_dim(var, dim, name):
+    if len(var.shape) != dim:
+        raise ValueError("{} must be {}D".format(name, dim))
+
+
+def certify_inputs(log_probs, labels, lengths, label_lengths):
+    check_type(labels, torch.int32, "labels")
+    check_type(label_lengths, torch.int32, "label_lengths")
+    check_type(lengths, torch.int32, "lengths")
+    check_contiguous(log_probs, "log_probs")
+    check_contiguous(labels, "labels")
+    check_contiguous(label_lengths, "label_lengths")
+    check_contiguous(lengths, "lengths")
+
+    if lengths.shape[0] != log_probs.shape[0]:
+        raise ValueError("must have a length per example.")
+    if label_lengths.shape[0] != log_probs.shape[0]:
+        raise ValueError("must have a label length per example.")
+
+    check_dim(log_probs, 4, "log_probs")
+    check_dim(labels, 2, "labels")
+    check_dim(lengths, 1, "lenghts")
+    check_dim(label_lengths, 1, "label_lenghts")
+    max_T = torch.max(lengths)
+    max_U = torch.max(label_lengths)
+    T, U = log_probs.shape[1:3]
+    if T != max_T:
+        raise ValueError("Input length mismatch")
+    if U != max_U + 1:
+        raise ValueError("Output length mismatch")

@@ -1,0 +1,94 @@
+"""`warprnnt_pytorch.warp_rnnt` -- the extension-module surface of the reference binding.
+
+Same two entry points and the same 8-argument signature as the pybind11 module of
+pytorch_binding/src/binding.cpp:12-19,84-91,157-162:
+
+    cpu_rnnt(acts, labels, input_lengths, label_lengths, costs, grads, blank_label, num_threads)
+    gpu_rnnt(acts, labels, input_lengths, label_lengths, costs, grads, blank_label, num_threads)
+
+They read (N,T,U,A) off ``acts`` (binding.cpp:26-30,93-96), size and allocate a temporary
+workspace from the framework allocator (binding.cpp:115-120), use the current stream
+(binding.cpp:104) and dispatch on dtype (binding.cpp:46-81,111-153) -- float32 and float64
+as the reference, plus bfloat16/float16 on the GPU.  An empty ``grads`` tensor means
+"score only" (reference __init__.py:24 passes torch.zeros(0)).
+"""
+import torch
+
+from . import _lib
+
+
+def _options(loc, acts, blank_label, num_threads, stream):
+    return _lib.rnntOptions(loc=loc, num_threads=max(int(num_threads), 0), stream=stream,
+                            blank_label=int(blank_label), maxT=acts.size(1), maxU=acts.size(2),
+                            batch_first=True)
+
+
+def _ptr(t):
+    return t.data_ptr() if t is not None and t.numel() > 0 else None
+
+
+def cpu_rnnt(acts, labels, input_lengths, label_lengths, costs, grads, blank_label, num_threads):
+    """RNNT_CPU: acts are LOG-PROBS, grads the sparse d/d(log-probs).  Returns 0 / -1."""
+    lib = _lib.lib()
+    N, T, U, A = acts.shape
+    if acts.dtype == torch.float32:
+        fn, esz = lib.compute_rnnt_loss, 4
+    elif acts.dtype == torch.float64:
+        fn, esz = lib.compute_rnnt_loss_fp64, 8
+    else:
+        import sys
+        print("warp_rnnt.cpu_rnnt: unsupported data type %s" % acts.dtype, file=sys.stderr)
+        return -1
+    ws = torch.empty(_lib.workspace_bytes(T, U, N, False, esz), dtype=torch.uint8)
+    opt = _options(_lib.RNNT_CPU, acts, blank_label, num_threads, None)
+    st = fn(acts.data_ptr(), _ptr(grads), labels.data_ptr(), label_lengths.data_ptr(),
+            input_lengths.data_ptr(), A, N, costs.data_ptr(), ws.data_ptr(), opt)
+    _lib.check(st, "compute_rnnt_loss (RNNT_CPU)")
+    return 0
+
+
+def gpu_rnnt(acts, labels, input_lengths, label_lengths, costs, grads, blank_label, num_threads):
+    """RNNT_GPU: acts are raw LOGITS on an MI355X, grads the dense d/d(logits);
+    labels/lengths are device tensors, ``costs`` is a HOST tensor.  Returns 0 / -1."""
+    lib = _lib.lib()
+    if not acts.is_cuda:
+        raise ValueError("gpu_rnnt needs device tensors")
+    N, T, U, A = acts.shape
+    table = {torch.float32: (lib.compute_rnnt_loss, 4), torch.float64: (lib.compute_rnnt_loss_fp64, 8),
+             torch.bfloat16: (lib.compute_rnnt_loss_bf16, 2), torch.float16: (lib.compute_rnnt_loss_fp16, 2)}
+    if acts.dtype not in table:
+        import sys
+        print("warp_rnnt.gpu_rnnt: unsupported data type %s" % acts.dtype, file=sys.stderr)
+        return -1
+    fn, esz = table[acts.dtype]
+    with torch.cuda.device(acts.device):
+        ws = torch.empty(_lib.workspace_bytes(T, U, N, True, esz), dtype=torch.uint8, device=acts.device)
+        stream = torch.cuda.current_stream(acts.device).cuda_stream
+        opt = _options(_lib.RNNT_GPU, acts, blank_label, num_threads, stream)
+        st = fn(acts.data_ptr(), _ptr(grads), labels.data_ptr(), label_lengths.data_ptr(),
+                input_lengths.data_ptr(), A, N, costs.data_ptr(), ws.data_ptr(), opt)
+    _lib.check(st, "compute_rnnt_loss (RNNT_GPU)")
+    return 0
+
+
+def gpu_rnnt_async(acts, labels, input_lengths, label_lengths, costs_device, grads, blank_label,
+                   grad_scale=None, workspace=None):
+    """Extension: enqueue only (no host copy, no synchronisation).  ``costs_device`` is a device
+    tensor (float32, or float64 for float64 acts).  Returns the workspace tensor, which the caller
+    must keep alive until the stream has passed this work."""
+    lib = _lib.lib()
+    N, T, U, A = acts.shape
+    code = {torch.float32: (_lib.DT_F32, 4), torch.float64: (_lib.DT_F64, 8),
+            torch.bfloat16: (_lib.DT_BF16, 2), torch.float16: (_lib.DT_F16, 2)}[acts.dtype]
+    with torch.cuda.device(acts.device):
+        if workspace is None:
+            workspace = torch.empty(_lib.workspace_bytes(T, U, N, True, code[1]), dtype=torch.uint8,
+                                    device=acts.device)
+        stream = torch.cuda.current_stream(acts.device).cuda_stream
+        opt = _options(_lib.RNNT_GPU, acts, blank_label, 0, stream)
+        st = lib.compute_rnnt_loss_async(acts.data_ptr(), _ptr(grads), labels.data_ptr(),
+                                         label_lengths.data_ptr(), input_lengths.data_ptr(), A, N,
+                                         costs_device.data_ptr(), _ptr(grad_scale), workspace.data_ptr(),
+                                         opt, code[0])
+    _lib.check(st, "compute_rnnt_loss_async")
+    return workspace

@@ -1,0 +1,248 @@
+#!/usr/bin/env python
+"""bench.py -- RNN-T loss+grad hot path on MI355X: ms/batch and fraction of the HBM roofline.
+
+Contract (driver):  python bench.py --gpus N --steps K --warmup W   (N>1: launched by
+torch.distributed.run, one rank per GPU, RCCL).  Rank 0 prints ONE JSON line.
+
+A "step" = one pass of the hot path over one synthetic batch already resident in HBM:
+`compute_rnnt_loss` of include/rnnt.h with gradients (row statistics -> lattice -> coefficients
+-> gradient write-back), i.e. exactly what the reference's tests/test_time.cu times
+(compute_rnnt_loss incl. the costs D2H copy and stream sync).  With N>1 the batch is sharded
+(weak scaling: every rank gets the full per-GPU batch) and each step adds the single RCCL
+all-reduce of the summed loss.
+
+Workloads (BASELINE.json configs; lattice U = L+1 as tests/test_time.cu:56):
+  c2: N=16  T=150  L=40  A=28   fp32      c3: N=128 T=150 L=20 A=5000 fp32  (default, headline)
+  c4: N=64  T=1500 L=300 A=50   fp32      c5: N=128/GPU T=200 L=40 A=1024 bf16
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "warp-transducer_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+WORKLOADS = {
+    "c2": dict(N=16, T=150, L=40, A=28, dtype="fp32", published_ms=11.43),
+    "c3": dict(N=128, T=150, L=20, A=5000, dtype="fp32", published_ms=51.46),
+    "c4": dict(N=64, T=1500, L=300, A=50, dtype="fp32", published_ms=None),
+    "c5": dict(N=128, T=200, L=40, A=1024, dtype="bf16", published_ms=None),
+}
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec (MI355X_MICROARCH.md)
+TORCH_DT = {"fp32": torch.float32, "bf16": torch.bfloat16, "fp64": torch.float64, "fp16": torch.float16}
+ESIZE = {"fp32": 4, "bf16": 2, "fp64": 8, "fp16": 2}
+
+
+def make_inputs(w, dev, seed):
+    """Synthetic batch of the reference timing harness's shape (tests/test_time.cu:27-62): logits
+    uniform(0,1), every sample full length, labels in [1, A-1] with forced repeats, blank 0.
+    Generated on the device (the host mt19937 stream takes ~1 min at c3 size: BASELINE.md 3)."""
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    N, T, L, A = w["N"], w["T"], w["L"], w["A"]
+    U = L + 1
+    acts = torch.rand((N, T, U, A), generator=g, device=dev, dtype=torch.float32).to(TORCH_DT[w["dtype"]])
+    lab = torch.randint(1, A, (L,), generator=g, device=dev, dtype=torch.int32)
+    if L >= 3:
+        lab[L // 2] = lab[L // 2 + 1]
+        lab[L // 2 - 1] = lab[L // 2]
+    labels = lab.unsqueeze(0).repeat(N, 1).contiguous()
+    act_lens = torch.full((N,), T, dtype=torch.int32, device=dev)
+    label_lens = torch.full((N,), L, dtype=torch.int32, device=dev)
+    return acts, labels, act_lens, label_lens
+
+
+def algorithmic_bytes(w):
+    """acts read twice, grads written once, plus the fp32 lattice side arrays."""
+    N, T, U, A, s = w["N"], w["T"], w["L"] + 1, w["A"], ESIZE[w["dtype"]]
+    R = N * T * U
+    E = R * A
+    return dict(E=E, R=R, path=3 * E * s + 48 * R, grad_kernel=2 * E * s + 16 * R,
+                stats_kernel=E * s + 16 * R)
+
+
+def cpu_baseline(w, acts, labels, act_lens, label_lens, budget_samples):
+    """The REFERENCE's own CPU path (oracle/_ref, compiled from /root/reference) on the host
+    cores of this box, on a bounded sample of the same workload.  Input = log-probs (the
+    reference CPU contract), so log_softmax is not in its time."""
+    from oracle import oracle as O
+    n = min(w["N"], budget_samples)
+    lp = torch.log_softmax(acts[:n].float(), -1).cpu().numpy()
+    lab, tl, ll = labels[:n].cpu().numpy(), act_lens[:n].cpu().numpy(), label_lens[:n].cpu().numpy()
+    cores = os.cpu_count() or 1
+    threads = min(cores, n)
+    if O.have_ref():
+        kind, fn = "reference", lambda: O.ref_rnnt_logprobs(lp, lab, tl, ll, 0, True, threads)
+    else:
+        O.lib().oracle_set_num_threads(threads)
+        kind, fn = "port", lambda: O.rnnt_logprobs(lp, lab, tl, ll, 0, True)
+    fn()   # page-fault warm-up (the reference harness pays it inside its timing: BASELINE.md 3)
+    times = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        fn()
+        times.append((time.perf_counter() - t0) * 1e3)
+    ms = float(np.median(times)) * (w["N"] / n)
+    return dict(value=round(ms, 3), unit="ms/batch", cores=threads, kind=kind,
+                sample="%d of %d samples (T=%d,U=%d,A=%d, fp32 log-probs in, sparse log-prob grads out), "
+                       "median of 3 warmed calls, scaled x%.2f to the full batch; host has %d cores"
+                       % (n, w["N"], w["T"], w["L"] + 1, w["A"], w["N"] / n, cores))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-samples", type=int, default=32)
+    ap.add_argument("--extra", action="store_true", help="also time the other single-GPU workloads")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)   # "nccl" is RCCL on ROCm
+
+    from warprnnt_pytorch import _lib, warp_rnnt
+    lib = _lib.lib()
+
+    def run_workload(name, steps, warmup, with_cpu):
+        w = WORKLOADS[name]
+        acts, labels, act_lens, label_lens = make_inputs(w, dev, 1234 + rank)
+        N, T, U, A = acts.shape
+        grads = torch.empty_like(acts)
+        esz = ESIZE[w["dtype"]]
+        ws = torch.empty(_lib.workspace_bytes(T, U, N, True, esz), dtype=torch.uint8, device=dev)
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        opt = _lib.rnntOptions(loc=_lib.RNNT_GPU, num_threads=0, stream=stream, blank_label=0, maxT=T,
+                               maxU=U, batch_first=True)
+        if world == 1:
+            # the drop-in C-ABI call: host costs, one stream sync per call
+            fn = {"fp32": lib.compute_rnnt_loss, "bf16": lib.compute_rnnt_loss_bf16}[w["dtype"]]
+            costs = torch.zeros(N, dtype=torch.float32)
+            argv = (acts.data_ptr(), grads.data_ptr(), labels.data_ptr(), label_lens.data_ptr(),
+                    act_lens.data_ptr(), A, N, costs.data_ptr(), ws.data_ptr(), opt)
+
+            def step():
+                st = fn(*argv)
+                assert st == 0, _lib.status_string(st)
+                return costs
+        else:
+            # sharded: device costs, one RCCL all-reduce of [sum, count], one sync per step
+            costs = torch.zeros(N, dtype=torch.float32, device=dev)
+            code = {"fp32": _lib.DT_F32, "bf16": _lib.DT_BF16}[w["dtype"]]
+            argv = (acts.data_ptr(), grads.data_ptr(), labels.data_ptr(), label_lens.data_ptr(),
+                    act_lens.data_ptr(), A, N, costs.data_ptr(), None, ws.data_ptr(), opt, code)
+
+            def step():
+                st = lib.compute_rnnt_loss_async(*argv)
+                assert st == 0, _lib.status_string(st)
+                packed = torch.stack([costs.sum(dtype=torch.float64),
+                                      torch.tensor(float(N), dtype=torch.float64, device=dev)])
+                dist.all_reduce(packed)
+                torch.cuda.synchronize(dev)
+                return packed
+
+        for _ in range(warmup):
+            step()
+        lib.rnnt_profile_reset()
+        lib.rnnt_profile_enable(1 if world == 1 else 0)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            out = step()
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        elapsed = time.perf_counter() - t0
+        lib.rnnt_profile_enable(0)
+        if world > 1:
+            tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            elapsed = float(tmax.item())
+        ms_step = elapsed * 1e3 / steps
+        stage = (C.c_double * 5)()
+        calls = lib.rnnt_profile_read(stage, 5)
+        stage_ms = [stage[i] / calls for i in range(5)] if calls else None
+        ab = algorithmic_bytes(w)
+        res = dict(workload=name, ms_per_step=ms_step, stage_ms=stage_ms, bytes=ab, w=w,
+                   loss_sum=float(out.sum()) if world == 1 else float(out[0]))
+        if with_cpu and rank == 0:
+            res["cpu"] = cpu_baseline(w, acts, labels, act_lens, label_lens, args.cpu_samples)
+        del acts, grads, ws
+        torch.cuda.empty_cache()
+        return res
+
+    r = run_workload(args.workload, args.steps, args.warmup, with_cpu=(world == 1 and not args.no_cpu_baseline))
+    w, ab = r["w"], r["bytes"]
+    ms = r["ms_per_step"]
+    U = w["L"] + 1
+    out = {
+        "metric": "ms/batch RNN-T loss+grad (N,T,U,A); achieved HBM GB/s vs peak",
+        "value": round(ms, 4), "unit": "ms/batch", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(ms, 4), "higher_is_better": False,
+        "scaling": "weak", "vs_baseline": (round(ms / w["published_ms"], 5) if w["published_ms"] else None),
+        "dtype": {"fp32": "f32", "bf16": "bf16"}[w["dtype"]], "data": "synthetic",
+        "config": {"workload": "%s: N=%d/GPU T=%d U=%d(L=%d) A=%d %s, loss+grad via compute_rnnt_loss"
+                               % (args.workload, w["N"], w["T"], U, w["L"], w["A"], w["dtype"]),
+                   "global_batch": w["N"] * world, "per_gpu_batch": w["N"],
+                   "parallelism": "batch-sharded x%d, one RCCL all-reduce of the summed loss" % world
+                   if world > 1 else "single GPU"},
+        "samples_per_s": round(w["N"] * world / (ms * 1e-3), 1),
+        "path_roofline": {"bound": "hbm", "achieved": round(ab["path"] / (ms * 1e-3) / 1e9, 1),
+                          "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                          "frac": round(ab["path"] / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                          "bytes_algo": ab["path"], "note": "3*E*s + 48*R over the whole step (wall clock, "
+                          "incl. launches, costs D2H and sync); aggregate over %d GPU(s) = x%d" % (world, world)},
+    }
+    if r["stage_ms"]:
+        sm = r["stage_ms"]
+        gk = sm[3]
+        out["roofline"] = {"bound": "hbm", "kernel": "grad_kernel (dense gradient write-back)",
+                           "achieved": round(ab["grad_kernel"] / (gk * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS,
+                           "unit": "GB/s", "frac": round(ab["grad_kernel"] / (gk * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                           "traffic": None, "bytes_algo": ab["grad_kernel"], "avg_ms": round(gk, 4)}
+        out["stage_ms"] = {"row_stats": round(sm[0], 4), "lattice": round(sm[1], 4), "coef": round(sm[2], 4),
+                           "grad": round(sm[3], 4), "enqueue_span": round(sm[4], 4)}
+        out["stats_roofline"] = {"achieved": round(ab["stats_kernel"] / (sm[0] * 1e-3) / 1e9, 1),
+                                 "frac": round(ab["stats_kernel"] / (sm[0] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                 "unit": "GB/s"}
+    if "cpu" in r:
+        out["cpu_baseline"] = r["cpu"]
+    if args.extra and world == 1:
+        extra = {}
+        for name in sorted(WORKLOADS):
+            if name == args.workload:
+                continue
+            e = run_workload(name, max(5, args.steps // 2), 3, with_cpu=False)
+            eb = e["bytes"]
+            extra[name] = {"ms_per_step": round(e["ms_per_step"], 4),
+                           "stage_ms": [round(x, 4) for x in e["stage_ms"]],
+                           "path_frac": round(eb["path"] / (e["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+        out["other_workloads"] = extra
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,90 @@
+"""Batch-sharded RNN-T loss over the GPUs of one node (one process per GPU, RCCL over xGMI).
+
+Not in the reference (it has no multi-device layer: SURVEY.md 2.1/8e).  Samples are independent,
+so every rank runs the single-GPU hot path on its own contiguous slab of the batch with its own
+workspace and stream; gradients stay local (data parallel).  The data path needs exactly ONE
+collective: an all-reduce(sum) of the 2-element vector [local summed loss, local sample count]
+('sum'/'mean'), or one all-gather of the per-sample costs ('none').  The payload is 8 bytes, so
+the collective is latency-bound and is enqueued on the compute stream -- nothing is staged
+through the host.  On CPU tensors (tests: gloo, world_size 2) the same code runs the library's
+RNNT_CPU location.
+"""
+import torch
+import torch.distributed as dist
+from torch.autograd import Function
+from torch.nn import Module
+
+from . import certify_inputs, warp_rnnt
+
+__all__ = ["sharded_rnnt_loss", "ShardedRNNTLoss"]
+
+
+def _local_costs_and_grads(acts, labels, act_lens, label_lens, blank, need_grad):
+    """Per-sample costs ON THE DEVICE of acts (no host round trip on the GPU) and local grads."""
+    n = acts.size(0)
+    cost_dtype = acts.dtype if acts.dtype in (torch.float32, torch.float64) else torch.float32
+    grads = torch.empty_like(acts) if need_grad else torch.zeros(0).to(acts)
+    if acts.is_cuda:
+        costs = torch.empty(n, dtype=cost_dtype, device=acts.device)
+        ws = warp_rnnt.gpu_rnnt_async(acts, labels, act_lens, label_lens, costs, grads, blank)
+        ws.record_stream(torch.cuda.current_stream(acts.device))
+    else:
+        costs = torch.zeros(n, dtype=cost_dtype)
+        warp_rnnt.cpu_rnnt(acts, labels, act_lens, label_lens, costs, grads, blank, 0)
+    return costs, grads
+
+
+class _ShardedRNNT(Function):
+    @staticmethod
+    def forward(ctx, acts, labels, act_lens, label_lens, blank, reduction, group):
+        certify_inputs(acts, labels, act_lens, label_lens)
+        costs, grads = _local_costs_and_grads(acts, labels, act_lens, label_lens, blank, acts.requires_grad)
+        distributed = dist.is_available() and dist.is_initialized()
+        if reduction == "none":
+            if distributed:
+                world = dist.get_world_size(group)
+                parts = [torch.empty_like(costs) for _ in range(world)]
+                dist.all_gather(parts, costs, group=group)      # equal shards
+                out = torch.cat(parts)
+            else:
+                out = costs
+            ctx.rank_offset = (dist.get_rank(group) if distributed else 0) * costs.numel()
+            ctx.local_n = costs.numel()
+        else:
+            packed = torch.stack([costs.sum(dtype=torch.float64),
+                                  torch.tensor(float(costs.numel()), dtype=torch.float64, device=costs.device)])
+            if distributed:
+                dist.all_reduce(packed, op=dist.ReduceOp.SUM, group=group)   # the single collective
+            out = packed[0:1].to(costs.dtype)
+            if reduction == "mean":
+                out = out / packed[1].to(costs.dtype)
+                if grads.numel():
+                    grads.mul_((1.0 / packed[1]).to(grads.dtype))
+        ctx.grads = grads
+        ctx.reduction = reduction
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        g = grad_output
+        if ctx.reduction == "none":
+            g = g[ctx.rank_offset:ctx.rank_offset + ctx.local_n]
+        g = g.reshape(-1, 1, 1, 1).to(ctx.grads)
+        return ctx.grads.mul_(g), None, None, None, None, None, None
+
+
+def sharded_rnnt_loss(acts, labels, act_lens, label_lens, blank=0, reduction="mean", group=None):
+    """`rnnt_loss` over a batch sharded across the ranks of `group`; every rank passes its own
+    shard and receives the loss of the GLOBAL batch ('mean' divides by the global batch size)."""
+    if not acts.is_cuda:
+        acts = torch.nn.functional.log_softmax(acts, -1)
+    return _ShardedRNNT.apply(acts, labels, act_lens, label_lens, blank, reduction, group)
+
+
+class ShardedRNNTLoss(Module):
+    def __init__(self, blank=0, reduction="mean", group=None):
+        super().__init__()
+        self.blank, self.reduction, self.group = blank, reduction, group
+
+    def forward(self, acts, labels, act_lens, label_lens):
+        return sharded_rnnt_loss(acts, labels, act_lens, label_lens, self.blank, self.reduction, self.group)

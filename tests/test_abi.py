@@ -1,0 +1,95 @@
+"""The C-ABI shared library: loads, exports every symbol include/rnnt.h declares, and keeps the
+reference's validation / status behaviour (src/rnnt_entrypoint.cpp:14-35,49-59,96-128).
+No GPU compute is called here."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from warprnnt_pytorch import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_functions():
+    src = open(os.path.join(ROOT, "include", "rnnt.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b([A-Za-z_][A-Za-z0-9_]*)\s*\(", re.sub(r"#.*", "", src)))
+                  - {"defined", "sizeof"})
+
+
+def test_library_exports_every_declared_symbol():
+    lib = _lib.lib()
+    names = declared_functions()
+    assert {"compute_rnnt_loss", "compute_rnnt_loss_fp64", "get_workspace_size", "get_warprnnt_version",
+            "rnntGetStatusString"} <= set(names)
+    for n in names:
+        assert hasattr(lib, n), "libwarprnnt.so does not export %s" % n
+    assert set(names) == set(_lib.EXPORTS), (names, sorted(_lib.EXPORTS))
+
+
+def test_version_and_status_strings():
+    lib = _lib.lib()
+    assert lib.get_warprnnt_version() == 1                       # tests/test_cpu.cpp:382
+    assert [_lib.status_string(i) for i in range(5)] == [
+        "no error", "cuda memcpy or memset failed", "invalid value", "execution failed", "unknown error"]
+    assert _lib.status_string(99) == "unknown error"
+
+
+def test_options_struct_layout():
+    # by-value struct of the reference: 32 bytes on LP64
+    assert C.sizeof(_lib.rnntOptions) == 32
+    assert _lib.rnntOptions.stream.offset == 8 and _lib.rnntOptions.batch_first.offset == 28
+
+
+def test_workspace_size_contract():
+    lib = _lib.lib()
+    n = C.c_size_t(0)
+    for bad in ((0, 3, 1), (4, 0, 1), (4, 3, 0), (-1, 3, 1)):
+        assert lib.get_workspace_size(*bad, True, C.byref(n), 4) == 2        # INVALID_VALUE
+    assert lib.get_workspace_size(4, 3, 2, False, C.byref(n), 4) == 0
+    assert n.value == 4 * 2 * 4 * 3 * 4                                      # 4*N*T*U*s (CPU location)
+    assert lib.get_workspace_size(150, 21, 128, True, C.byref(n), 4) == 0
+    gpu32 = n.value
+    assert lib.get_workspace_size(150, 21, 128, True, C.byref(n), 2) == 0
+    assert n.value == gpu32                                                  # 16-bit acts keep an fp32 lattice
+    assert lib.get_workspace_size(150, 21, 128, True, C.byref(n), 8) == 0
+    assert n.value > gpu32
+    # must hold the skewed lattice: 5 fp32 words per cell of N*(T+U-1)*U
+    assert gpu32 >= 5 * 4 * 128 * (150 + 21 - 1) * 21
+
+
+@pytest.mark.parametrize("fn", ["compute_rnnt_loss", "compute_rnnt_loss_fp64"])
+def test_invalid_value_paths(fn):
+    lib = _lib.lib()
+    f = getattr(lib, fn)
+    x = np.zeros(64, dtype=np.float64)
+    i = np.ones(8, dtype=np.int32)
+    ok = dict(acts=x.ctypes.data, grads=None, lab=i.ctypes.data, ll=i.ctypes.data, tl=i.ctypes.data,
+              A=3, N=1, costs=x.ctypes.data, ws=x.ctypes.data)
+
+    def call(opt, **over):
+        a = dict(ok, **over)
+        return f(a["acts"], a["grads"], a["lab"], a["ll"], a["tl"], a["A"], a["N"], a["costs"], a["ws"], opt)
+
+    good = _lib.rnntOptions(loc=0, num_threads=1, stream=None, blank_label=0, maxT=1, maxU=2, batch_first=True)
+    for key in ("acts", "lab", "ll", "tl", "costs", "ws"):
+        assert call(good, **{key: None}) == 2
+    assert call(good, A=0) == 2 and call(good, N=0) == 2
+    for bad in (dict(maxT=0), dict(maxU=0), dict(loc=7)):
+        kw = dict(loc=0, num_threads=1, stream=None, blank_label=0, maxT=1, maxU=2, batch_first=True)
+        kw.update(bad)
+        assert call(_lib.rnntOptions(**kw)) == 2
+    # extensions refuse the CPU location
+    if fn == "compute_rnnt_loss":
+        assert lib.compute_rnnt_loss_bf16(ok["acts"], None, ok["lab"], ok["ll"], ok["tl"], 3, 1, ok["costs"],
+                                          ok["ws"], good) == 2
+
+
+def test_loader_fails_loudly_without_library(monkeypatch, tmp_path):
+    monkeypatch.setenv("WARP_RNNT_PATH", str(tmp_path))
+    monkeypatch.setattr(_lib, "_lib", None)
+    with pytest.raises(ImportError):
+        _lib.lib()

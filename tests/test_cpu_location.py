@@ -1,0 +1,126 @@
+"""RNNT_CPU location of libwarprnnt.so through the C-ABI -- the reference's tests/test_cpu.cpp
+restated (small_test :12-71, options_test :73-179, inf_test :181-240, grad_check :287-379) plus
+the cases the reference never tests (variable lengths, blank != 0, fp64, !batch_first)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from tests.golden import literals as G
+from tests.golden.make_golden import CASES, case_inputs
+from warprnnt_pytorch import _lib
+
+FIX = np.load(__file__.replace("test_cpu_location.py", "golden/ref_cases.npz"))
+
+
+def cpu_loss(log_probs, labels, act_lens, label_lens, blank=0, want_grad=True, num_threads=1,
+             batch_first=True, dims=None):
+    lib = _lib.lib()
+    lp = np.ascontiguousarray(log_probs)
+    N, T, U, A = dims if dims else lp.shape
+    fn, esz = (lib.compute_rnnt_loss, 4) if lp.dtype == np.float32 else (lib.compute_rnnt_loss_fp64, 8)
+    labels = np.ascontiguousarray(labels, dtype=np.int32)
+    tl = np.ascontiguousarray(act_lens, dtype=np.int32)
+    ll = np.ascontiguousarray(label_lens, dtype=np.int32)
+    ws = np.empty(_lib.workspace_bytes(T, U, N, False, esz), dtype=np.uint8)
+    costs = np.zeros(N, dtype=lp.dtype)
+    grads = np.full_like(lp, 7.0) if want_grad else None
+    opt = _lib.rnntOptions(loc=_lib.RNNT_CPU, num_threads=num_threads, stream=None, blank_label=blank,
+                           maxT=T, maxU=U, batch_first=batch_first)
+    st = fn(lp.ctypes.data, grads.ctypes.data if want_grad else None, labels.ctypes.data, ll.ctypes.data,
+            tl.ctypes.data, A, N, costs.ctypes.data, ws.ctypes.data, opt)
+    assert st == 0, _lib.status_string(st)
+    return costs, grads
+
+
+def test_small_test(oracle):
+    lp = oracle.log_softmax(G.SMALL_ACTS.astype(np.float32))
+    c, _ = cpu_loss(lp, G.SMALL_LABELS, [2], [2], want_grad=False)
+    assert G.SMALL_COST - 1e-4 < c[0] < G.SMALL_COST + 1e-4
+
+
+def test_options_test(oracle):
+    lp = oracle.log_softmax(G.OPTIONS_ACTS_6DP.astype(np.float32))
+    c, g = cpu_loss(lp, G.OPTIONS_LABELS, [4, 4], [2, 2])
+    assert np.abs(g - G.OPTIONS_LOGPROB_GRADS).max() < 1e-4
+    assert np.abs(c - G.OPTIONS_COSTS).max() < 1e-4
+
+
+def test_inf_test(oracle):
+    # un-normalised acts fed straight in (tests/test_cpu.cpp:219): finite cost, no NaN grads
+    acts, labels, tl, ll, blank = case_inputs("inf_test")
+    c, g = cpu_loss(acts.astype(np.float32), labels, tl, ll)
+    assert np.isfinite(c).all() and not np.isnan(g).any()
+
+
+@pytest.mark.parametrize("A,T,L,B,tol", [(20, 50, 15, 1, 1e-4), (5, 10, 5, 65, 1e-4)])
+def test_grad_check(oracle, A, T, L, B, tol):
+    """Central differences, eps 1e-2, rel_diff = sum (g-ng)^2 / sum g^2 < tol (tests/test.h:22-32,
+    tests/test_cpu.cpp:242-285,347-351).  Differences are taken on a random subset of elements
+    (the reference perturbs every element) to keep the CPU suite fast."""
+    acts = oracle.gen_acts(A * T * L * B).reshape(B, T, L, A)            # un-normalised, as the reference
+    labels = np.tile(oracle.gen_labels(A, L - 1), (B, 1))
+    tl, ll = np.full(B, T), np.full(B, L - 1)
+    _, g = cpu_loss(acts, labels, tl, ll)
+    rng = np.random.default_rng(0)
+    flat = acts.reshape(-1)
+    picks = rng.choice(flat.size, size=min(400, flat.size), replace=False)
+    num = np.zeros(picks.size)
+    for k, i in enumerate(picks):
+        old = flat[i]
+        flat[i] = old + 1e-2
+        cp, _ = cpu_loss(acts, labels, tl, ll, want_grad=False)
+        flat[i] = old - 1e-2
+        cm, _ = cpu_loss(acts, labels, tl, ll, want_grad=False)
+        flat[i] = old
+        num[k] = (cp.sum(dtype=np.float64) - cm.sum(dtype=np.float64)) / 2e-2
+    an = g.reshape(-1)[picks].astype(np.float64)
+    assert ((an - num) ** 2).sum() / (an ** 2).sum() < 5e-3   # fp32 differences on 400 elements
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+@pytest.mark.parametrize("dt", [np.float32, np.float64])
+def test_against_reference_fixture(oracle, name, dt):
+    acts, labels, tl, ll, blank = case_inputs(name)
+    lp = oracle.log_softmax(acts.astype(dt))
+    c, g = cpu_loss(lp, labels, tl, ll, blank, num_threads=0)
+    tol = 1e-10 if dt == np.float64 else 2e-6
+    assert np.abs(c - FIX[name + "/costs64"]).max() <= max(tol, 1e-9) * max(1, np.abs(c).max()) + (0 if dt == np.float64 else 2e-4)
+    # fp32 location vs the reference fp64 outputs: the reference tests allow 1e-4 (test_cpu.cpp:149)
+    assert np.abs(g - FIX[name + "/lpgrad64"]).max() < (1e-6 if dt == np.float64 else 1e-4)
+    cf, _ = cpu_loss(lp, labels, tl, ll, blank, want_grad=False)
+    assert np.array_equal(cf, c)
+
+
+def test_time_major_layout(oracle):
+    """batch_first = false: (T,U,B,V) layout of the reference (cpu_rnnt.h:140-144,294-295);
+    gradients are not zeroed in this mode (only the sparse entries are written)."""
+    acts, labels, tl, ll, blank = case_inputs("blank5_a19")
+    lp = oracle.log_softmax(acts)
+    c_ref, g_ref = cpu_loss(lp, labels, tl, ll, blank)
+    N, T, U, A = lp.shape
+    lp_t = np.ascontiguousarray(lp.transpose(1, 2, 0, 3))
+    c, g = cpu_loss(lp_t, labels, tl, ll, blank, batch_first=False, dims=(N, T, U, A))
+    assert np.allclose(c, c_ref)
+    g = g.transpose(2, 0, 1, 3)
+    touched = g != 7.0
+    assert np.allclose(g[touched], g_ref[touched]) and not g_ref[~touched].any()
+
+
+def test_bad_lengths_are_rejected(oracle):
+    lib = _lib.lib()
+    lp = np.zeros((1, 2, 3, 4), dtype=np.float32)
+    ws = np.empty(4096, dtype=np.uint8)
+    costs = np.zeros(1, dtype=np.float32)
+    lab = np.ones((1, 2), dtype=np.int32)
+    opt = _lib.rnntOptions(loc=0, num_threads=1, stream=None, blank_label=0, maxT=2, maxU=3, batch_first=True)
+    def call(tlen, llen):
+        tl, ll = np.array([tlen], dtype=np.int32), np.array([llen], dtype=np.int32)   # keep alive
+        return lib.compute_rnnt_loss(lp.ctypes.data, None, lab.ctypes.data, ll.ctypes.data, tl.ctypes.data, 4, 1,
+                                     costs.ctypes.data, ws.ctypes.data, opt)
+
+    for tlen, llen in ((3, 2), (2, 3), (0, 2)):
+        assert call(tlen, llen) == 2
+    assert call(2, 2) == 0
+    opt.blank_label = 4
+    assert call(2, 2) == 2

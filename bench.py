@@ -107,6 +107,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-samples", type=int, default=32)
     ap.add_argument("--extra", action="store_true", help="also time the other single-GPU workloads")
+    ap.add_argument("--override", default="", help="dev: override workload fields, e.g. A=4992,N=64")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -123,7 +124,11 @@ def main():
     lib = _lib.lib()
 
     def run_workload(name, steps, warmup, with_cpu):
-        w = WORKLOADS[name]
+        w = dict(WORKLOADS[name])
+        for kv in filter(None, args.override.split(",")):
+            k, v = kv.split("=")
+            w[k] = v if k == "dtype" else int(v)
+            w["published_ms"] = None
         acts, labels, act_lens, label_lens = make_inputs(w, dev, 1234 + rank)
         N, T, U, A = acts.shape
         grads = torch.empty_like(acts)

@@ -20,6 +20,19 @@ struct F64 { using store = double;   using comp = double; };
 struct BF16 { using store = uint16_t; using comp = float;  };
 struct F16 { using store = uint16_t; using comp = float;  };
 
+// 16-byte packet as a native vector (lowers to global_load/store_dwordx4).
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+template <bool NT> __device__ __forceinline__ uint4 load_packet(const u32x4* p) {
+    u32x4 v;
+    if constexpr (NT) v = __builtin_nontemporal_load(p); else v = *p;
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+template <bool NT> __device__ __forceinline__ void store_packet(u32x4* p, const uint4& r) {
+    u32x4 v = {r.x, r.y, r.z, r.w};
+    if constexpr (NT) __builtin_nontemporal_store(v, p); else *p = v;
+}
+
 template <typename Tag> struct Vec {
     static constexpr int N = 16 / sizeof(typename Tag::store);   // elements per 16-byte access
 };
@@ -91,12 +104,19 @@ template <> __device__ __forceinline__ uint4 pack<F64>(const double* v) {
     return make_uint4(static_cast<uint32_t>(__double2loint(v[0])), static_cast<uint32_t>(__double2hiint(v[0])),
                       static_cast<uint32_t>(__double2loint(v[1])), static_cast<uint32_t>(__double2hiint(v[1])));
 }
+// gfx950 converts two fp32 to packed bf16 (round-to-nearest-even) in one v_cvt_pk_bf16_f32.
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t cvt_pk_bf16(float lo, float hi) {
+    const f32x2_t f = {lo, hi};
+    const bf16x2_t h = __builtin_convertvector(f, bf16x2_t);
+    uint32_t u;
+    __builtin_memcpy(&u, &h, 4);
+    return u;
+}
 template <> __device__ __forceinline__ uint4 pack<BF16>(const float* v) {
-    uint32_t w[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-        w[i] = static_cast<uint32_t>(f32_to_bf16(v[2 * i])) | (static_cast<uint32_t>(f32_to_bf16(v[2 * i + 1])) << 16);
-    return make_uint4(w[0], w[1], w[2], w[3]);
+    return make_uint4(cvt_pk_bf16(v[0], v[1]), cvt_pk_bf16(v[2], v[3]), cvt_pk_bf16(v[4], v[5]),
+                      cvt_pk_bf16(v[6], v[7]));
 }
 template <> __device__ __forceinline__ uint4 pack<F16>(const float* v) {
     uint32_t w[4];

@@ -11,6 +11,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 #include "../../include/rnnt.h"
@@ -24,7 +25,7 @@ constexpr size_t kAlign = 256;
 static inline size_t align_up(size_t x) { return (x + kAlign - 1) / kAlign * kAlign; }
 
 struct Layout {
-    size_t cells, beta, offa, offb, llf, llb, costs, total;
+    size_t cells, rowtab, beta, offa, offb, llf, llb, costs, total;
 };
 
 // lat = bytes of one lattice value (4: fp32 lattice for 16/32-bit activations, 8: fp64).
@@ -34,6 +35,7 @@ static Layout make_layout(int maxT, int maxU, int N, size_t lat) {
     Layout l{};
     size_t o = 0;
     l.cells = o; o = align_up(o + sk * 4 * lat);
+    l.rowtab = o; o = align_up(o + static_cast<size_t>(maxT) * maxU * N * 4 * lat);
     l.beta = o;  o = align_up(o + (sk + maxU + 1) * lat);
     l.offa = o;  o = align_up(o + D * N * sizeof(double));
     l.offb = o;  o = align_up(o + D * N * sizeof(double));
@@ -64,6 +66,30 @@ static bool prof_prepare() {
     return true;
 }
 
+// ----------------------------------------------------------------------------- tuning knobs
+// Development A/B switches, read once from RNNT_TUNE="key=value,key=value" (defaults are the
+// measured best; see profiles/).  sw = waves per block of the row-stats kernel (2|4|8),
+// nta = non-temporal stats loads, gmax = grid cap of the flat gradient kernel, rows = 1 forces
+// the row-form gradient kernel.
+struct Tune { int gw = 4, sw = 4, nta = 1, gmax = 262144, rows = 0, tile = 1, tilekb = 48; };
+static Tune g_tune;
+static bool g_tune_read = false;
+static const Tune& tune() {
+    if (!g_tune_read) {
+        g_tune_read = true;
+        if (const char* e = getenv("RNNT_TUNE")) {
+            auto get = [&](const char* key, int& dst) {
+                const char* p = strstr(e, key);
+                if (p && p[strlen(key)] == '=') dst = atoi(p + strlen(key) + 1);
+            };
+            get("gw", g_tune.gw); get("sw", g_tune.sw); get("nta", g_tune.nta);
+            get("gmax", g_tune.gmax); get("rows", g_tune.rows); get("tile", g_tune.tile);
+            get("tilekb", g_tune.tilekb);
+        }
+    }
+    return g_tune;
+}
+
 // ----------------------------------------------------------------------------- launch
 #define RNNT_LAUNCH_CHECK()                                        \
     do {                                                           \
@@ -89,6 +115,7 @@ static rnntStatus_t run_gpu(const typename Tag::store* acts, typename Tag::store
     const Layout lay = make_layout(maxT, maxU, N, sizeof(C));
     char* ws = reinterpret_cast<char*>(align_up(reinterpret_cast<size_t>(workspace)));
     auto* cells = reinterpret_cast<Cell<C>*>(ws + lay.cells);
+    auto* rowtab = reinterpret_cast<Cell<C>*>(ws + lay.rowtab);
     auto* beta = reinterpret_cast<C*>(ws + lay.beta);
     auto* offa = reinterpret_cast<double*>(ws + lay.offa);
     auto* offb = reinterpret_cast<double*>(ws + lay.offb);
@@ -105,15 +132,48 @@ static rnntStatus_t run_gpu(const typename Tag::store* acts, typename Tag::store
     const bool prof = costs_host != nullptr && prof_prepare();
     auto mark = [&](int i) { if (prof) (void)hipEventRecord(g_prof.ev[i], stream); };
 
-    constexpr int WAVES = 4;
+    const Tune& tn = tune();
     const int cells_per_sample = maxT * maxU;
-    const dim3 row_grid((cells_per_sample + WAVES - 1) / WAVES, N);
+    auto row_grid = [&](int waves) { return dim3((cells_per_sample + waves - 1) / waves, N); };
     const int lat_threads = ((maxU + 63) / 64) * 64;
-    const int D = maxT + maxU - 1;
 
     mark(0);
-    hipLaunchKernelGGL((row_stats_kernel<Tag, WAVES>), row_grid, dim3(WAVES * 64), 0, stream, acts,
-                       labels, input_lengths, label_lengths, cells, maxT, maxU, A, blank, vec_ok);
+    const size_t row_bytes = static_cast<size_t>(A) * sizeof(S);
+    bool tiled = false;
+    if (tn.tile && vec_ok && row_bytes <= static_cast<size_t>(kTileMaxRowBytes)) {
+        // smallest lane group G whose tile of 256/G rows fits the LDS budget
+        const size_t budget = static_cast<size_t>(tn.tilekb) * 1024;
+        int G = 1;
+        while (G < 64 && (256 / G) * row_bytes + 32 > budget) G *= 2;
+        const int RT = 256 / G;
+        const size_t lds = RT * row_bytes + 32;
+        const unsigned long long Rall = static_cast<unsigned long long>(N) * cells_per_sample;
+        const unsigned tgrid = static_cast<unsigned>((Rall + RT - 1) / RT);
+        if (lds <= 64 * 1024) {
+            tiled = true;
+#define RNNT_TILE(GG)                                                                                   \
+    hipLaunchKernelGGL((row_stats_tile_kernel<Tag, GG>), dim3(tgrid), dim3(256), lds, stream, acts, labels, \
+                       input_lengths, label_lengths, cells, Rall, maxT, maxU, A, blank)
+            switch (G) {
+                case 1: RNNT_TILE(1); break;
+                case 2: RNNT_TILE(2); break;
+                case 4: RNNT_TILE(4); break;
+                case 8: RNNT_TILE(8); break;
+                case 16: RNNT_TILE(16); break;
+                case 32: RNNT_TILE(32); break;
+                default: RNNT_TILE(64); break;
+            }
+#undef RNNT_TILE
+        }
+    }
+    if (!tiled) {
+#define RNNT_STATS(W, NT)                                                                             \
+    hipLaunchKernelGGL((row_stats_kernel<Tag, W, NT>), row_grid(W), dim3(W * 64), 0, stream, acts, labels, \
+                       input_lengths, label_lengths, cells, maxT, maxU, A, blank, vec_ok)
+        if (tn.nta) { if (tn.sw == 8) RNNT_STATS(8, true); else if (tn.sw == 2) RNNT_STATS(2, true); else RNNT_STATS(4, true); }
+        else { if (tn.sw == 8) RNNT_STATS(8, false); else if (tn.sw == 2) RNNT_STATS(2, false); else RNNT_STATS(4, false); }
+#undef RNNT_STATS
+    }
     RNNT_LAUNCH_CHECK();
     mark(1);
     const int dirs = training ? 2 : 1;
@@ -127,19 +187,38 @@ static rnntStatus_t run_gpu(const typename Tag::store* acts, typename Tag::store
     RNNT_LAUNCH_CHECK();
     mark(2);
     if (training) {
-        const dim3 cgrid((D * maxU + 255) / 256, N);
+        const dim3 cgrid((cells_per_sample + 255) / 256, N);
         hipLaunchKernelGGL((coef_kernel<C>), cgrid, dim3(256), 0, stream, cells, beta, offa, offb, llf,
-                           labels, input_lengths, label_lengths, maxT, maxU);
+                           labels, input_lengths, label_lengths, rowtab, maxT, maxU);
         RNNT_LAUNCH_CHECK();
         mark(3);
-        if (grad_scale)
-            hipLaunchKernelGGL((grad_kernel<Tag, WAVES, true>), row_grid, dim3(WAVES * 64), 0, stream, acts,
-                               grads, cells, input_lengths, label_lengths, grad_scale, maxT, maxU, A, blank,
-                               vec_ok);
-        else
-            hipLaunchKernelGGL((grad_kernel<Tag, WAVES, false>), row_grid, dim3(WAVES * 64), 0, stream, acts,
-                               grads, cells, input_lengths, label_lengths, grad_scale, maxT, maxU, A, blank,
-                               vec_ok);
+        const unsigned long long R = static_cast<unsigned long long>(N) * cells_per_sample;
+        const unsigned long long E = R * A;
+        constexpr int V = Vec<Tag>::N;
+        const bool flat_ok = vec_ok && (pa & 15u) == 0 && (pg & 15u) == 0 && A <= (1 << 23) && !tn.rows;
+        if (flat_ok) {
+            const unsigned long long npk = E / V;
+            const unsigned long long nchunks = (npk + kChunkPackets - 1) / kChunkPackets;
+            const unsigned grid = static_cast<unsigned>(nchunks < static_cast<unsigned long long>(tn.gmax)
+                                                            ? (nchunks ? nchunks : 1) : tn.gmax);
+            const unsigned long long stride = static_cast<unsigned long long>(grid) * kChunkPackets * V;
+            const unsigned long long dq = stride / A;
+            const int drem = static_cast<int>(stride % A);
+            const float invA = 1.0f / static_cast<float>(A);
+            if (grad_scale)
+                hipLaunchKernelGGL((grad_flat_kernel<Tag, true>), dim3(grid), dim3(256), 0, stream, acts, grads,
+                                   rowtab, grad_scale, E, R, A, blank, cells_per_sample, invA, dq, drem);
+            else
+                hipLaunchKernelGGL((grad_flat_kernel<Tag, false>), dim3(grid), dim3(256), 0, stream, acts, grads,
+                                   rowtab, grad_scale, E, R, A, blank, cells_per_sample, invA, dq, drem);
+        } else {
+            if (grad_scale)
+                hipLaunchKernelGGL((grad_rows_kernel<Tag, 4, true>), row_grid(4), dim3(256), 0, stream, acts, grads,
+                                   rowtab, grad_scale, maxT, maxU, A, blank, vec_ok);
+            else
+                hipLaunchKernelGGL((grad_rows_kernel<Tag, 4, false>), row_grid(4), dim3(256), 0, stream, acts, grads,
+                                   rowtab, grad_scale, maxT, maxU, A, blank, vec_ok);
+        }
         RNNT_LAUNCH_CHECK();
     } else {
         mark(3);

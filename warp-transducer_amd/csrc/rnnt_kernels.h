@@ -29,7 +29,8 @@ namespace rnnt {
 // One lattice cell record.  Written in three stages:
 //   row_stats : x = log p(blank|t,u)   y = log p(y_u|t,u)   z = logZ(t,u)   w = (unused)
 //   lattice   : w = scaled alpha(t,u)
-//   coef      : x = c   y = cb   z = cl   w = label index (as number), overwriting in place
+// The gradient coefficients {c, cb, cl, label} use the same 4-word record type in a separate
+// natural-order row table (coef_kernel).
 template <typename L> struct alignas(4 * sizeof(L)) Cell { L x, y, z, w; };
 
 constexpr int kLatticeBlock = 8;   // diagonals per prefetch/renormalisation block
@@ -63,7 +64,7 @@ __device__ __forceinline__ void row_split(uintptr_t addr, int A, bool vec_ok, in
 
 // ------------------------------------------------------------------------------------------
 // Pass A.  grid = (ceil(maxT*maxU / WAVES), N), block = WAVES*64; one wavefront per row.
-template <typename Tag, int WAVES>
+template <typename Tag, int WAVES, bool NT>
 __global__ __launch_bounds__(WAVES * 64) void row_stats_kernel(
         const typename Tag::store* __restrict__ acts, const int* __restrict__ labels,
         const int* __restrict__ xlen, const int* __restrict__ ylen,
@@ -97,10 +98,11 @@ __global__ __launch_bounds__(WAVES * 64) void row_stats_kernel(
         C v[1] = {load1<Tag>(row + e)};
         absorb<C, 1>(v, m, s);
     }
-    const uint4* vp = reinterpret_cast<const uint4*>(row + head);
+    const u32x4* vp = reinterpret_cast<const u32x4*>(row + head);
     int i = lane;
     for (; i + 192 < nvec; i += 256) {
-        const uint4 r0 = vp[i], r1 = vp[i + 64], r2 = vp[i + 128], r3 = vp[i + 192];
+        const uint4 r0 = load_packet<NT>(vp + i), r1 = load_packet<NT>(vp + i + 64),
+                    r2 = load_packet<NT>(vp + i + 128), r3 = load_packet<NT>(vp + i + 192);
         C v[4 * V];
         unpack<Tag>(r0, v);
         unpack<Tag>(r1, v + V);
@@ -109,7 +111,7 @@ __global__ __launch_bounds__(WAVES * 64) void row_stats_kernel(
         absorb<C, 4 * V>(v, m, s);
     }
     for (; i < nvec; i += 64) {
-        const uint4 r = vp[i];
+        const uint4 r = load_packet<NT>(vp + i);
         C v[V];
         unpack<Tag>(r, v);
         absorb<C, V>(v, m, s);
@@ -132,6 +134,124 @@ __global__ __launch_bounds__(WAVES * 64) void row_stats_kernel(
         rec.z = logZ;
         rec.w = 0;
         cells[(static_cast<size_t>(b) * D + (t + u)) * maxU + u] = rec;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Pass A, TILE form for short rows (row bytes <= kTileMaxRowBytes).  A wavefront per row wastes
+// lanes and pays a 12-shuffle reduction per row when a row is only tens to hundreds of bytes,
+// so here a 256-thread block streams a contiguous tile of RT = 256/G rows (a flat, fully
+// coalesced range of the tensor) into LDS with non-temporal 16-byte loads, then G lanes per row
+// reduce it out of LDS: pass 1 max, pass 2 sum-exp.  Lane-to-element order is rotated by the
+// row number when A is even so that the RT rows fall into different LDS banks.
+// grid = ceil(R / RT), dynamic LDS = RT*A*s + 32 bytes.
+constexpr int kTileMaxRowBytes = 2048;
+
+template <typename Tag, int G>
+__global__ __launch_bounds__(256) void row_stats_tile_kernel(
+        const typename Tag::store* __restrict__ acts, const int* __restrict__ labels,
+        const int* __restrict__ xlen, const int* __restrict__ ylen,
+        Cell<typename Tag::comp>* __restrict__ cells, unsigned long long R, int maxT, int maxU, int A,
+        int blank) {
+    using S = typename Tag::store;
+    using C = typename Tag::comp;
+    constexpr int V = Vec<Tag>::N;
+    constexpr int RT = 256 / G;
+    extern __shared__ uint4 tile_raw[];
+    S* tile = reinterpret_cast<S*>(tile_raw);
+
+    const unsigned long long r0 = static_cast<unsigned long long>(blockIdx.x) * RT;
+    const int nrows = static_cast<int>(R - r0 < static_cast<unsigned long long>(RT) ? R - r0 : RT);
+    const S* base = acts + r0 * static_cast<unsigned>(A);
+    const int n_el = nrows * A;
+    const int phase = static_cast<int>((reinterpret_cast<uintptr_t>(base) & 15u) / sizeof(S));
+    int head = (V - phase) % V;
+    if (head > n_el) head = n_el;
+    const int nbody = (n_el - head) / V;
+    const int tail0 = head + nbody * V;
+
+    // ---- global -> LDS, the tile keeps the 16-byte phase of its global address
+    for (int e = threadIdx.x; e < head; e += 256) tile[phase + e] = base[e];
+    {
+        const u32x4* src = reinterpret_cast<const u32x4*>(base + head);
+        uint4* dst = tile_raw + (phase + head) / V;
+        int p = threadIdx.x;
+        for (; p + 768 < nbody; p += 1024) {
+            const uint4 a0 = load_packet<true>(src + p), a1 = load_packet<true>(src + p + 256),
+                        a2 = load_packet<true>(src + p + 512), a3 = load_packet<true>(src + p + 768);
+            dst[p] = a0; dst[p + 256] = a1; dst[p + 512] = a2; dst[p + 768] = a3;
+        }
+        for (; p < nbody; p += 256) dst[p] = load_packet<true>(src + p);
+    }
+    for (int e = tail0 + threadIdx.x; e < n_el; e += 256) tile[phase + e] = base[e];
+    __syncthreads();
+
+    // ---- G lanes per row
+    const int rl = threadIdx.x / G, j = threadIdx.x % G;
+    if (rl >= nrows) return;                                   // whole lane groups leave together
+    const S* rowp = tile + phase + rl * A;
+    C m = neg_inf<C>(), sum = 0, shift = 0;
+    if (phase == 0 && A % V == 0) {
+        // rows are whole 16-byte packets: read LDS 16 bytes at a time (ds_read_b128)
+        const uint4* rowpk = tile_raw + rl * (A / V);
+        const int npk = A / V;
+        for (int p = j; p < npk; p += G) {
+            C v[V];
+            unpack<Tag>(rowpk[p], v);
+#pragma unroll
+            for (int i = 0; i < V; ++i) m = vmax(m, v[i]);
+        }
+#pragma unroll
+        for (int off = G / 2; off > 0; off >>= 1) m = vmax(m, __shfl_xor(m, off, kWave));
+        shift = (m == neg_inf<C>()) ? C(0) : m;
+        for (int p = j; p < npk; p += G) {
+            C v[V];
+            unpack<Tag>(rowpk[p], v);
+#pragma unroll
+            for (int i = 0; i < V; ++i) sum += fast_exp(v[i] - shift);
+        }
+    } else {
+        const int rot = (A & 1) ? 0 : (rl % A);
+        for (int e = j; e < A; e += G) {
+            int pos = e + rot;
+            if (pos >= A) pos -= A;
+            m = vmax(m, load1<Tag>(rowp + pos));
+        }
+#pragma unroll
+        for (int off = G / 2; off > 0; off >>= 1) m = vmax(m, __shfl_xor(m, off, kWave));
+        shift = (m == neg_inf<C>()) ? C(0) : m;
+        for (int e = j; e < A; e += G) {
+            int pos = e + rot;
+            if (pos >= A) pos -= A;
+            sum += fast_exp(load1<Tag>(rowp + pos) - shift);
+        }
+    }
+#pragma unroll
+    for (int off = G / 2; off > 0; off >>= 1) sum += __shfl_xor(sum, off, kWave);
+
+    if (j == 0) {
+        const unsigned TU = static_cast<unsigned>(maxT) * maxU;
+        const unsigned long long r = r0 + rl;
+        const int b = static_cast<int>(r / TU);
+        const int q = static_cast<int>(r - static_cast<unsigned long long>(b) * TU);
+        const int t = q / maxU, u = q - t * maxU;
+        const int Tb = xlen[b], Ub = ylen[b] + 1;
+        if (t < Tb && u < Ub) {
+            const C logZ = shift + acc_log(sum);
+            const bool has_lab = u < Ub - 1;
+            int lab = blank;
+            if (has_lab) {
+                lab = labels[static_cast<size_t>(b) * (maxU - 1) + u];
+                lab = lab < 0 ? 0 : (lab >= A ? A - 1 : lab);
+            }
+            const int D = maxT + maxU - 1;
+            Cell<C> rec;
+            rec.x = load1<Tag>(rowp + blank) - logZ;
+            rec.y = has_lab ? load1<Tag>(rowp + lab) - logZ : C(0);
+            rec.z = logZ;
+            rec.w = 0;
+            cells[(static_cast<size_t>(b) * D + (t + u)) * maxU + u] = rec;
+        }
     }
 }
 
@@ -296,65 +416,196 @@ __global__ __launch_bounds__(1024) void lattice_kernel(
 }
 
 // ------------------------------------------------------------------------------------------
-// Gradient coefficients per lattice cell (skewed index space, fully coalesced).
-// grid = (ceil(D*maxU/256), N), block = 256.  Overwrites the cell record in place.
-//   c  = alpha + beta - ll - logZ                       (g_v = exp(x_v + c) for every v)
-//   cb = exp(alpha + lp_blank + beta(t+1,u) - ll)        (t < T-1)
-//      = exp(alpha + lp_blank - ll)                      (t = T-1, u = U-1)
-//   cl = exp(alpha + lp_label + beta(t,u+1) - ll)        (u < U-1)
-// Formulas: reference gpu_rnnt_kernel.h:161-174, docs/rnnt_notes.tex:138-145.
+// Gradient coefficients, one record per (b,t,u) ROW in natural row order r = (b*maxT + t)*maxU + u
+// (the order the gradient pass streams the big tensor in).  grid = (ceil(maxT*maxU/256), N).
+//   x = c  = alpha + beta - ll - logZ                   (g_v = exp(x_v + c) for every v)
+//   y = cb = exp(alpha + lp_blank + beta(t+1,u) - ll)    (t < T-1)
+//          = exp(alpha + lp_blank - ll)                  (t = T-1, u = U-1)
+//   z = cl = exp(alpha + lp_label + beta(t,u+1) - ll)    (u < U-1)
+//   w = label index of the row (-1: no label transition, kPadded: padded row -> zero gradient)
+// Formulas: reference gpu_rnnt_kernel.h:161-174, docs/rnnt_notes.tex:138-145.  The sums are
+// formed in fp64 from the scaled fp32 lattice values and their fp64 offsets.
+constexpr int kPadded = -2;
+
 template <typename L>
 __global__ __launch_bounds__(256) void coef_kernel(
-        Cell<L>* __restrict__ cells, const L* __restrict__ beta, const double* __restrict__ offa,
+        const Cell<L>* __restrict__ cells, const L* __restrict__ beta, const double* __restrict__ offa,
         const double* __restrict__ offb, const double* __restrict__ ll_fwd,
         const int* __restrict__ labels, const int* __restrict__ xlen, const int* __restrict__ ylen,
-        int maxT, int maxU) {
+        Cell<L>* __restrict__ rowtab, int maxT, int maxU) {
     const int b = blockIdx.y;
-    const int D = maxT + maxU - 1;
-    const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= D * maxU) return;
-    const int n = idx / maxU, u = idx - n * maxU;
-    const int t = n - u;
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    if (q >= maxT * maxU) return;
+    const int t = q / maxU, u = q - t * maxU;
     const int Tb = xlen[b], Ub = ylen[b] + 1;
-    if (u >= Ub || t < 0 || t >= Tb) return;
-    const size_t base = static_cast<size_t>(b) * D * maxU;
-    Cell<L>* cp = cells + base + idx;
-    const L* bp = beta + base + idx;
-    const Cell<L> r = *cp;
-    const double* oa = offa + static_cast<size_t>(b) * D;
-    const double* ob = offb + static_cast<size_t>(b) * D;
-    const double ll = ll_fwd[b];
-    const double alpha = static_cast<double>(r.w) + oa[n] - ll;     // alpha(t,u) - ll
-    const bool last_t = (t == Tb - 1), last_u = (u == Ub - 1);
-    const double ob1 = (last_t && last_u) ? 0.0 : ob[n + 1];
-
     Cell<L> o;
-    o.x = static_cast<L>(alpha + static_cast<double>(bp[0]) + ob[n] - static_cast<double>(r.z));
-    L cb = 0, cl = 0;
-    if (!last_t)
-        cb = fast_exp(static_cast<L>(alpha + static_cast<double>(r.x) + static_cast<double>(bp[maxU]) + ob1));
-    else if (last_u)
-        cb = fast_exp(static_cast<L>(alpha + static_cast<double>(r.x)));
-    int lab = -1;
-    if (!last_u) {
-        cl = fast_exp(static_cast<L>(alpha + static_cast<double>(r.y) + static_cast<double>(bp[maxU + 1]) + ob1));
-        lab = labels[static_cast<size_t>(b) * (maxU - 1) + u];
+    o.x = 0; o.y = 0; o.z = 0; o.w = static_cast<L>(kPadded);
+    if (t < Tb && u < Ub) {
+        const int D = maxT + maxU - 1;
+        const int n = t + u;
+        const size_t idx = static_cast<size_t>(b) * D * maxU + static_cast<size_t>(n) * maxU + u;
+        const Cell<L> r = cells[idx];
+        const L* bp = beta + idx;
+        const double* oa = offa + static_cast<size_t>(b) * D;
+        const double* ob = offb + static_cast<size_t>(b) * D;
+        const double alpha = static_cast<double>(r.w) + oa[n] - ll_fwd[b];     // alpha(t,u) - ll
+        const bool last_t = (t == Tb - 1), last_u = (u == Ub - 1);
+        const double ob1 = (last_t && last_u) ? 0.0 : ob[n + 1];
+        o.x = static_cast<L>(alpha + static_cast<double>(bp[0]) + ob[n] - static_cast<double>(r.z));
+        if (!last_t)
+            o.y = fast_exp(static_cast<L>(alpha + static_cast<double>(r.x) + static_cast<double>(bp[maxU]) + ob1));
+        else if (last_u)
+            o.y = fast_exp(static_cast<L>(alpha + static_cast<double>(r.x)));
+        int lab = -1;
+        if (!last_u) {
+            o.z = fast_exp(static_cast<L>(alpha + static_cast<double>(r.y) + static_cast<double>(bp[maxU + 1]) + ob1));
+            lab = labels[static_cast<size_t>(b) * (maxU - 1) + u];
+        }
+        o.w = static_cast<L>(lab);
     }
-    o.y = cb;
-    o.z = cl;
-    o.w = static_cast<L>(lab);
-    *cp = o;
+    rowtab[static_cast<size_t>(b) * maxT * maxU + q] = o;
 }
 
 // ------------------------------------------------------------------------------------------
-// Pass B.  grid = (ceil(maxT*maxU / WAVES), N), block = WAVES*64; one wavefront per row.
-// Padded rows (t >= T_b or u >= U_b) are zero-filled here, so no memset of the gradient
-// tensor is needed (the reference does one: gpu_rnnt.h:107-110).
-template <typename Tag, int WAVES, bool SCALED>
-__global__ __launch_bounds__(WAVES * 64) void grad_kernel(
+// Pass B, FLAT form (the production path).  The (N,T,U,A) tensor is streamed as one flat array
+// of 16-byte packets: a block owns a contiguous, 16 KB-aligned chunk of kChunkPackets packets
+// per iteration (each of its 4 wavefronts moves whole 1 KB lines) and grid-strides over the
+// chunks; loads and stores carry the non-temporal hint.  The row of a packet is recovered
+// arithmetically (row of the chunk start is carried incrementally in 64-bit; inside the chunk
+// a 32-bit reciprocal division) and its {c, cb, cl, label} record comes from the natural-order
+// row table (L1/L2 hits: consecutive packets share rows).  Padded rows are written as zeros
+// here, so no memset of the gradient tensor exists (the reference does one: gpu_rnnt.h:107-110).
+// Measured on MI355X (tools/microbench/stream_variants.hip): this structure sustains
+// 6.4-6.5 TB/s read+write with the exp included, the wavefront-per-row form 5.1 TB/s.
+constexpr int kChunkPackets = 1024;   // 4 packets per thread, 256 threads
+
+template <typename Tag, bool SCALED>
+__global__ __launch_bounds__(256) void grad_flat_kernel(
         const typename Tag::store* __restrict__ acts, typename Tag::store* __restrict__ grads,
-        const Cell<typename Tag::comp>* __restrict__ cells, const int* __restrict__ xlen,
-        const int* __restrict__ ylen, const typename Tag::comp* __restrict__ grad_scale,
+        const Cell<typename Tag::comp>* __restrict__ rowtab, const typename Tag::comp* __restrict__ grad_scale,
+        unsigned long long E, unsigned long long R, int A, int blank, int TU, float invA,
+        unsigned long long dq, int drem) {
+    using C = typename Tag::comp;
+    constexpr int V = Vec<Tag>::N;
+    constexpr int CH = kChunkPackets * V;                 // elements per chunk
+    const unsigned long long npk = E / V;
+    const unsigned long long nchunks = (npk + kChunkPackets - 1) / kChunkPackets;
+    const u32x4* in = reinterpret_cast<const u32x4*>(acts);
+    u32x4* out = reinterpret_cast<u32x4*>(grads);
+
+    unsigned long long c = blockIdx.x;
+    unsigned long long r = (c * CH) / static_cast<unsigned>(A);                   // row of the chunk start
+    int rem = static_cast<int>((c * CH) - r * static_cast<unsigned>(A));          // offset inside it
+
+    auto scale_of = [&](unsigned long long row) -> C {
+        if constexpr (SCALED) return grad_scale[row / static_cast<unsigned>(TU)]; else return C(1);
+    };
+    // One element at position `pos` of a row with record `rec`.
+    auto elem = [&](const Cell<C>& rec, int pos, C x, C gs) -> C {
+        const int lab = static_cast<int>(rec.w);
+        if (lab == kPadded) return C(0);
+        C g = fast_exp(x + rec.x);
+        if (pos == blank) g -= rec.y;
+        if (pos == lab) g -= rec.z;
+        if constexpr (SCALED) g *= gs;
+        return g;
+    };
+
+    for (; c < nchunks; c += gridDim.x) {
+        const unsigned long long pk0 = c * kChunkPackets;
+        uint4 raw[4];
+        Cell<C> rec[4];
+        int v0[4];
+        unsigned long long row[4];
+        bool live[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int p = k * 256 + threadIdx.x;
+            live[k] = pk0 + p < npk;
+            const unsigned idx = static_cast<unsigned>(rem) + static_cast<unsigned>(p) * V;
+            unsigned q = static_cast<unsigned>(static_cast<float>(idx) * invA);
+            int rr = static_cast<int>(idx - q * static_cast<unsigned>(A));
+            if (rr < 0) { rr += A; --q; } else if (rr >= A) { rr -= A; ++q; }
+            v0[k] = rr;
+            row[k] = r + q;
+            if (live[k]) {
+                raw[k] = load_packet<true>(in + pk0 + p);
+                rec[k] = rowtab[row[k]];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (!live[k]) continue;
+            const int p = k * 256 + threadIdx.x;
+            C v[V];
+            unpack<Tag>(raw[k], v);
+            if (v0[k] + V <= A) {
+                // whole packet inside one row (the common case)
+                const int lab = static_cast<int>(rec[k].w);
+                if (lab == kPadded) {
+#pragma unroll
+                    for (int j = 0; j < V; ++j) v[j] = 0;
+                } else {
+                    const C cc = rec[k].x;
+#pragma unroll
+                    for (int j = 0; j < V; ++j) v[j] = fast_exp(v[j] + cc);
+                    if (static_cast<unsigned>(blank - v0[k]) < static_cast<unsigned>(V) ||
+                        static_cast<unsigned>(lab - v0[k]) < static_cast<unsigned>(V)) {
+#pragma unroll
+                        for (int j = 0; j < V; ++j) {
+                            if (v0[k] + j == blank) v[j] -= rec[k].y;
+                            if (v0[k] + j == lab) v[j] -= rec[k].z;
+                        }
+                    }
+                    if constexpr (SCALED) {
+                        const C gs = scale_of(row[k]);
+#pragma unroll
+                        for (int j = 0; j < V; ++j) v[j] *= gs;
+                    }
+                }
+            } else {
+                // packet crosses a row boundary (A not a multiple of the packet, or A < packet)
+                unsigned long long rw = row[k];
+                int pos = v0[k];
+                Cell<C> cur = rec[k];
+                C gs = scale_of(rw);
+#pragma unroll
+                for (int j = 0; j < V; ++j) {
+                    while (pos >= A) {
+                        pos -= A;
+                        ++rw;
+                        if (rw < R) cur = rowtab[rw];
+                        gs = scale_of(rw < R ? rw : R - 1);
+                    }
+                    v[j] = elem(cur, pos, v[j], gs);
+                    ++pos;
+                }
+            }
+            store_packet<true>(out + pk0 + p, pack<Tag>(v));
+        }
+        r += dq;
+        rem += drem;
+        if (rem >= A) { rem -= A; ++r; }
+    }
+
+    // the E % V elements after the last whole packet
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        for (unsigned long long e = npk * V; e < E; ++e) {
+            const unsigned long long rw = e / static_cast<unsigned>(A);
+            const int pos = static_cast<int>(e - rw * static_cast<unsigned>(A));
+            store1<Tag>(grads + e, elem(rowtab[rw], pos, load1<Tag>(acts + e), scale_of(rw)));
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Pass B, row form: one wavefront per row with a scalar head/tail, used only when the tensors
+// are not 16-byte aligned (or differ in their 16-byte phase) and packets cannot be used flat.
+// grid = (ceil(maxT*maxU / WAVES), N), block = WAVES*64.
+template <typename Tag, int WAVES, bool SCALED>
+__global__ __launch_bounds__(WAVES * 64) void grad_rows_kernel(
+        const typename Tag::store* __restrict__ acts, typename Tag::store* __restrict__ grads,
+        const Cell<typename Tag::comp>* __restrict__ rowtab, const typename Tag::comp* __restrict__ grad_scale,
         int maxT, int maxU, int A, int blank, int vec_ok) {
     using S = typename Tag::store;
     using C = typename Tag::comp;
@@ -363,28 +614,25 @@ __global__ __launch_bounds__(WAVES * 64) void grad_kernel(
     const int lane = threadIdx.x & 63;
     const int q = uniform(blockIdx.x * WAVES + (threadIdx.x >> 6));
     if (q >= maxT * maxU) return;
-    const int t = q / maxU, u = q - t * maxU;
-    const int Tb = xlen[b], Ub = ylen[b] + 1;
-    const size_t roff = (static_cast<size_t>(b) * maxT * maxU + q) * A;
+    const size_t rix = static_cast<size_t>(b) * maxT * maxU + q;
+    const size_t roff = rix * A;
     const S* row = acts + roff;
     S* grow = grads + roff;
 
     int head, nvec, tail0;
     row_split<S>(reinterpret_cast<uintptr_t>(row), A, vec_ok != 0, head, nvec, tail0);
-    uint4* gp = reinterpret_cast<uint4*>(grow + head);
+    u32x4* gp = reinterpret_cast<u32x4*>(grow + head);
+    const Cell<C> r = rowtab[rix];
+    const int lab = static_cast<int>(r.w);
 
-    if (t >= Tb || u >= Ub) {
+    if (lab == kPadded) {
         for (int e = lane; e < head; e += 64) store1<Tag>(grow + e, C(0));
         const uint4 z = make_uint4(0, 0, 0, 0);
-        for (int i = lane; i < nvec; i += 64) gp[i] = z;
+        for (int i = lane; i < nvec; i += 64) store_packet<false>(gp + i, z);
         for (int e = tail0 + lane; e < A; e += 64) store1<Tag>(grow + e, C(0));
         return;
     }
-
-    const int D = maxT + maxU - 1;
-    const Cell<C> r = cells[(static_cast<size_t>(b) * D + (t + u)) * maxU + u];
     const C c = r.x, cb = r.y, cl = r.z;
-    const int lab = static_cast<int>(r.w);
     C gs = 1;
     if constexpr (SCALED) gs = grad_scale[b];
 
@@ -395,45 +643,15 @@ __global__ __launch_bounds__(WAVES * 64) void grad_kernel(
         if constexpr (SCALED) g *= gs;
         return g;
     };
-    auto packet = [&](int e0, C* v) {
-#pragma unroll
-        for (int j = 0; j < V; ++j) v[j] = fast_exp(v[j] + c);
-        if (static_cast<unsigned>(blank - e0) < static_cast<unsigned>(V) ||
-            static_cast<unsigned>(lab - e0) < static_cast<unsigned>(V)) {
-#pragma unroll
-            for (int j = 0; j < V; ++j) {
-                if (e0 + j == blank) v[j] -= cb;
-                if (e0 + j == lab) v[j] -= cl;
-            }
-        }
-        if constexpr (SCALED) {
-#pragma unroll
-            for (int j = 0; j < V; ++j) v[j] *= gs;
-        }
-    };
-
     for (int e = lane; e < head; e += 64) store1<Tag>(grow + e, one(e, load1<Tag>(row + e)));
-    const uint4* vp = reinterpret_cast<const uint4*>(row + head);
-    int i = lane;
-    for (; i + 192 < nvec; i += 256) {
-        const uint4 r0 = vp[i], r1 = vp[i + 64], r2 = vp[i + 128], r3 = vp[i + 192];
-        C v0[V], v1[V], v2[V], v3[V];
-        unpack<Tag>(r0, v0); unpack<Tag>(r1, v1); unpack<Tag>(r2, v2); unpack<Tag>(r3, v3);
-        packet(head + i * V, v0);
-        packet(head + (i + 64) * V, v1);
-        packet(head + (i + 128) * V, v2);
-        packet(head + (i + 192) * V, v3);
-        gp[i] = pack<Tag>(v0);
-        gp[i + 64] = pack<Tag>(v1);
-        gp[i + 128] = pack<Tag>(v2);
-        gp[i + 192] = pack<Tag>(v3);
-    }
-    for (; i < nvec; i += 64) {
-        const uint4 r0 = vp[i];
-        C v0[V];
-        unpack<Tag>(r0, v0);
-        packet(head + i * V, v0);
-        gp[i] = pack<Tag>(v0);
+    const u32x4* vp = reinterpret_cast<const u32x4*>(row + head);
+    for (int i = lane; i < nvec; i += 64) {
+        const uint4 r0 = load_packet<false>(vp + i);
+        C v[V];
+        unpack<Tag>(r0, v);
+#pragma unroll
+        for (int j = 0; j < V; ++j) v[j] = one(head + i * V + j, v[j]);
+        store_packet<false>(gp + i, pack<Tag>(v));
     }
     for (int e = tail0 + lane; e < A; e += 64) store1<Tag>(grow + e, one(e, load1<Tag>(row + e)));
 }

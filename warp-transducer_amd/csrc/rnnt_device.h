@@ -145,16 +145,27 @@ __device__ __forceinline__ float vmin(float a, float b) { return fminf(a, b); }
 __device__ __forceinline__ double vmin(double a, double b) { return fmin(a, b); }
 
 // log(e^a + e^b); -inf is the additive zero (reference include/detail/rnnt_helper.h:16-24).
-__device__ __forceinline__ float log_add(float a, float b) {
-    float hi = fmaxf(a, b), lo = fminf(a, b);
-    float r = hi + __logf(1.0f + __expf(lo - hi));
-    return (hi == neg_inf<float>()) ? hi : r;
+// The lattice works in BASE-2 logs with a finite "log zero" sentinel:
+//   log2_add(a, b) = log2(2^a + 2^b) = hi + log2(1 + 2^(lo - hi))
+// is then add / max / min / sub / v_exp_f32 / add / v_log_f32 / add with no multiplies, and the
+// sentinel (about -1e30; it absorbs every finite addend) needs no -inf / NaN special cases: the
+// reference's `if (a == -inf) return b` short-circuits (include/detail/rnnt_helper.h:16-24)
+// fall out of the arithmetic.  The argument of the log is in [1,2]: none of the denormal
+// handling of the library wrappers is needed; absolute error ~1e-7 per call.
+template <typename T> __device__ __forceinline__ T log_zero();
+template <> __device__ __forceinline__ float log_zero<float>() { return -1.0e30f; }
+template <> __device__ __forceinline__ double log_zero<double>() { return -1.0e300; }
+
+__device__ __forceinline__ float log2_add(float a, float b) {
+    const float hi = fmaxf(a, b), lo = fminf(a, b);
+    return hi + __builtin_amdgcn_logf(1.0f + __builtin_amdgcn_exp2f(lo - hi));
 }
-__device__ __forceinline__ double log_add(double a, double b) {
-    double hi = fmax(a, b), lo = fmin(a, b);
-    double r = hi + log1p(exp(lo - hi));
-    return (hi == neg_inf<double>()) ? hi : r;
+__device__ __forceinline__ double log2_add(double a, double b) {
+    const double hi = fmax(a, b), lo = fmin(a, b);
+    return hi + log2(1.0 + exp2(lo - hi));
 }
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+__device__ __forceinline__ double fast_exp2(double x) { return exp2(x); }
 
 // ----------------------------------------------------------------------------- cross-lane
 // Whole-wave shift by one lane through DPP.  shr: lane i receives lane i-1 (lane 0 gets
@@ -180,6 +191,38 @@ __device__ __forceinline__ double wave_shl1(double v, double fill) {
     int lo = dpp_shl1(__double2loint(v), __double2loint(fill));
     int hi = dpp_shl1(__double2hiint(v), __double2hiint(fill));
     return __hiloint2double(hi, lo);
+}
+
+// Generic DPP move (lanes without a source keep their own value).
+template <int CTRL, int ROWMASK> __device__ __forceinline__ float dpp_mov(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), CTRL, ROWMASK, 0xf, false));
+}
+template <int CTRL, int ROWMASK> __device__ __forceinline__ double dpp_mov(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(__double2loint(v), __double2loint(v), CTRL, ROWMASK, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(__double2hiint(v), __double2hiint(v), CTRL, ROWMASK, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+// Value of lane `k` (compile-time) as a wave-uniform scalar; write a scalar into lane `k`.
+__device__ __forceinline__ float lane_get(float v, int k) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), k));
+}
+__device__ __forceinline__ double lane_get(double v, int k) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), k),
+                            __builtin_amdgcn_readlane(__double2loint(v), k));
+}
+template <typename T> __device__ __forceinline__ T lane_set(T dst, T s, int k) {
+    return (static_cast<int>(threadIdx.x & 63) == k) ? s : dst;       // lowers to one v_cndmask with a constant mask
+}
+// Wave-wide maximum through DPP only (no LDS round trips): quad swaps, row mirrors, then the
+// row broadcasts; the result is read from lane 63 and is wave-uniform.
+template <typename T> __device__ __forceinline__ T wave_max_dpp(T v) {
+    v = vmax(v, dpp_mov<0xB1, 0xf>(v));    // quad_perm [1,0,3,2]
+    v = vmax(v, dpp_mov<0x4E, 0xf>(v));    // quad_perm [2,3,0,1]
+    v = vmax(v, dpp_mov<0x141, 0xf>(v));   // row_half_mirror
+    v = vmax(v, dpp_mov<0x140, 0xf>(v));   // row_mirror
+    v = vmax(v, dpp_mov<0x142, 0xa>(v));   // row_bcast:15 -> rows 1,3
+    v = vmax(v, dpp_mov<0x143, 0xc>(v));   // row_bcast:31 -> rows 2,3
+    return lane_get(v, 63);
 }
 
 template <typename T> __device__ __forceinline__ T wave_max(T v) {

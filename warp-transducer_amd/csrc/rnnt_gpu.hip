@@ -30,15 +30,17 @@ struct Layout {
 
 // lat = bytes of one lattice value (4: fp32 lattice for 16/32-bit activations, 8: fp64).
 static Layout make_layout(int maxT, int maxU, int N, size_t lat) {
-    const size_t D = static_cast<size_t>(maxT) + maxU - 1;
-    const size_t sk = D * maxU * N;             // skewed lattice cells
+    const size_t D = lat_rows(maxT, maxU);      // diagonals + padding rows
+    const size_t Up = (static_cast<size_t>(maxU) + 63) / 64 * 64;   // one 64-lane row per wavefront
+    const size_t W = Up / 64;
+    const size_t sk = D * Up * N;               // skewed lattice cells
     Layout l{};
     size_t o = 0;
     l.cells = o; o = align_up(o + sk * 4 * lat);
     l.rowtab = o; o = align_up(o + static_cast<size_t>(maxT) * maxU * N * 4 * lat);
-    l.beta = o;  o = align_up(o + (sk + maxU + 1) * lat);
-    l.offa = o;  o = align_up(o + D * N * sizeof(double));
-    l.offb = o;  o = align_up(o + D * N * sizeof(double));
+    l.beta = o;  o = align_up(o + (sk + Up + 64) * lat);
+    l.offa = o;  o = align_up(o + D * W * N * sizeof(double));
+    l.offb = o;  o = align_up(o + (D * W * N + D) * sizeof(double));
     l.llf = o;   o = align_up(o + N * sizeof(double));
     l.llb = o;   o = align_up(o + N * sizeof(double));
     l.costs = o; o = align_up(o + N * sizeof(double));
@@ -135,7 +137,8 @@ static rnntStatus_t run_gpu(const typename Tag::store* acts, typename Tag::store
     const Tune& tn = tune();
     const int cells_per_sample = maxT * maxU;
     auto row_grid = [&](int waves) { return dim3((cells_per_sample + waves - 1) / waves, N); };
-    const int lat_threads = ((maxU + 63) / 64) * 64;
+    const int Up = ((maxU + 63) / 64) * 64;
+    const int lat_threads = Up;
 
     mark(0);
     const size_t row_bytes = static_cast<size_t>(A) * sizeof(S);
@@ -153,7 +156,7 @@ static rnntStatus_t run_gpu(const typename Tag::store* acts, typename Tag::store
             tiled = true;
 #define RNNT_TILE(GG)                                                                                   \
     hipLaunchKernelGGL((row_stats_tile_kernel<Tag, GG>), dim3(tgrid), dim3(256), lds, stream, acts, labels, \
-                       input_lengths, label_lengths, cells, Rall, maxT, maxU, A, blank)
+                       input_lengths, label_lengths, cells, Rall, maxT, maxU, Up, A, blank)
             switch (G) {
                 case 1: RNNT_TILE(1); break;
                 case 2: RNNT_TILE(2); break;
@@ -169,7 +172,7 @@ static rnntStatus_t run_gpu(const typename Tag::store* acts, typename Tag::store
     if (!tiled) {
 #define RNNT_STATS(W, NT)                                                                             \
     hipLaunchKernelGGL((row_stats_kernel<Tag, W, NT>), row_grid(W), dim3(W * 64), 0, stream, acts, labels, \
-                       input_lengths, label_lengths, cells, maxT, maxU, A, blank, vec_ok)
+                       input_lengths, label_lengths, cells, maxT, maxU, Up, A, blank, vec_ok)
         if (tn.nta) { if (tn.sw == 8) RNNT_STATS(8, true); else if (tn.sw == 2) RNNT_STATS(2, true); else RNNT_STATS(4, true); }
         else { if (tn.sw == 8) RNNT_STATS(8, false); else if (tn.sw == 2) RNNT_STATS(2, false); else RNNT_STATS(4, false); }
 #undef RNNT_STATS
@@ -177,19 +180,19 @@ static rnntStatus_t run_gpu(const typename Tag::store* acts, typename Tag::store
     RNNT_LAUNCH_CHECK();
     mark(1);
     const int dirs = training ? 2 : 1;
-    if (lat_threads == 64)
-        hipLaunchKernelGGL((lattice_kernel<C, false>), dim3(N * dirs), dim3(64), 0, stream, cells, beta,
-                           offa, offb, llf, llb, costs_dev, input_lengths, label_lengths, maxT, maxU, dirs);
-    else
-        hipLaunchKernelGGL((lattice_kernel<C, true>), dim3(N * dirs), dim3(lat_threads), 0, stream, cells,
-                           beta, offa, offb, llf, llb, costs_dev, input_lengths, label_lengths, maxT, maxU,
-                           dirs);
+#define RNNT_LATTICE(MW)                                                                                  \
+    hipLaunchKernelGGL((lattice_kernel<C, MW>), dim3(N * dirs), dim3(lat_threads), 0, stream, cells, beta, \
+                       offa, offb, llf, llb, costs_dev, input_lengths, label_lengths, maxT, maxU, Up, dirs)
+    if (lat_threads == 64) RNNT_LATTICE(1);
+    else if (lat_threads <= 512) RNNT_LATTICE(8);
+    else RNNT_LATTICE(16);
+#undef RNNT_LATTICE
     RNNT_LAUNCH_CHECK();
     mark(2);
     if (training) {
         const dim3 cgrid((cells_per_sample + 255) / 256, N);
         hipLaunchKernelGGL((coef_kernel<C>), cgrid, dim3(256), 0, stream, cells, beta, offa, offb, llf,
-                           labels, input_lengths, label_lengths, rowtab, maxT, maxU);
+                           labels, input_lengths, label_lengths, rowtab, maxT, maxU, Up);
         RNNT_LAUNCH_CHECK();
         mark(3);
         const unsigned long long R = static_cast<unsigned long long>(N) * cells_per_sample;

@@ -16,7 +16,8 @@
 //   include/detail/gpu_rnnt_kernel.h:143-179 + gpu_rnnt.h:107-110 (gradient kernel + memset)
 //
 // Lattice side data lives in the caller's workspace in a DIAGONAL-SKEWED layout:
-//   cell(b, t, u) -> ((b * D + (t + u)) * maxU + u),  D = maxT + maxU - 1
+//   cell(b, t, u) -> ((b * Dp + kLatPad + (t + u)) * Up + u),  Dp = maxT + maxU - 1 + 2*kLatPad,
+//   Up = 64*ceil(maxU/64)                                         (lat_index below)
 // so that the lanes of the lattice wavefront (consecutive u on one anti-diagonal t+u = n)
 // touch consecutive addresses.  All indices are 64-bit (the reference's are 32-bit int:
 // gpu_rnnt_kernel.h:7-8,161,174).
@@ -26,14 +27,25 @@
 
 namespace rnnt {
 
-// One lattice cell record.  Written in three stages:
-//   row_stats : x = log p(blank|t,u)   y = log p(y_u|t,u)   z = logZ(t,u)   w = (unused)
-//   lattice   : w = scaled alpha(t,u)
+// One lattice cell record.  Written in two stages:
+//   row_stats : x = log2 p(blank|t,u)   y = log2 p(y_u|t,u)   z = logZ(t,u) (natural)   w = 0
+//   lattice   : w = scaled alpha(t,u) (base 2)
 // The gradient coefficients {c, cb, cl, label} use the same 4-word record type in a separate
 // natural-order row table (coef_kernel).
 template <typename L> struct alignas(4 * sizeof(L)) Cell { L x, y, z, w; };
 
-constexpr int kLatticeBlock = 8;   // diagonals per prefetch/renormalisation block
+constexpr double kLog2e = 1.4426950408889634;
+constexpr double kLn2 = 0.6931471805599453;
+
+// The skewed arrays carry kLatPad spare rows before diagonal 0 and after diagonal D-1 of every
+// sample, so the last (partial) chunk of a sweep can run its full C steps without bounds checks.
+constexpr int kLatPad = 16;
+__host__ __device__ inline size_t lat_rows(int maxT, int maxU) { return static_cast<size_t>(maxT) + maxU - 1 + 2 * kLatPad; }
+// element index of (b, n, u) in a skewed array with row stride Up
+__host__ __device__ inline size_t lat_index(int b, int n, int u, int maxT, int maxU, int Up) {
+    return (static_cast<size_t>(b) * lat_rows(maxT, maxU) + kLatPad + n) * Up + u;
+}
+
 
 // ------------------------------------------------------------------------------------------
 // Online (max, sum-exp) accumulation of N values into a lane's running pair.
@@ -68,7 +80,7 @@ template <typename Tag, int WAVES, bool NT>
 __global__ __launch_bounds__(WAVES * 64) void row_stats_kernel(
         const typename Tag::store* __restrict__ acts, const int* __restrict__ labels,
         const int* __restrict__ xlen, const int* __restrict__ ylen,
-        Cell<typename Tag::comp>* __restrict__ cells, int maxT, int maxU, int A, int blank, int vec_ok) {
+        Cell<typename Tag::comp>* __restrict__ cells, int maxT, int maxU, int Up, int A, int blank, int vec_ok) {
     using S = typename Tag::store;
     using C = typename Tag::comp;
     constexpr int V = Vec<Tag>::N;
@@ -127,13 +139,12 @@ __global__ __launch_bounds__(WAVES * 64) void row_stats_kernel(
     const C logZ = shift + acc_log(S_);
 
     if (lane == 0) {
-        const int D = maxT + maxU - 1;
-        Cell<C> rec;
-        rec.x = xb - logZ;
-        rec.y = has_lab ? xl - logZ : C(0);
+        Cell<C> rec;                                   // lattice log-probs are kept in base 2
+        rec.x = vmax((xb - logZ) * C(kLog2e), log_zero<C>());
+        rec.y = has_lab ? vmax((xl - logZ) * C(kLog2e), log_zero<C>()) : log_zero<C>();
         rec.z = logZ;
         rec.w = 0;
-        cells[(static_cast<size_t>(b) * D + (t + u)) * maxU + u] = rec;
+        cells[lat_index(b, t + u, u, maxT, maxU, Up)] = rec;
     }
 }
 
@@ -151,8 +162,8 @@ template <typename Tag, int G>
 __global__ __launch_bounds__(256) void row_stats_tile_kernel(
         const typename Tag::store* __restrict__ acts, const int* __restrict__ labels,
         const int* __restrict__ xlen, const int* __restrict__ ylen,
-        Cell<typename Tag::comp>* __restrict__ cells, unsigned long long R, int maxT, int maxU, int A,
-        int blank) {
+        Cell<typename Tag::comp>* __restrict__ cells, unsigned long long R, int maxT, int maxU, int Up,
+        int A, int blank) {
     using S = typename Tag::store;
     using C = typename Tag::comp;
     constexpr int V = Vec<Tag>::N;
@@ -244,174 +255,293 @@ __global__ __launch_bounds__(256) void row_stats_tile_kernel(
                 lab = labels[static_cast<size_t>(b) * (maxU - 1) + u];
                 lab = lab < 0 ? 0 : (lab >= A ? A - 1 : lab);
             }
-            const int D = maxT + maxU - 1;
-            Cell<C> rec;
-            rec.x = load1<Tag>(rowp + blank) - logZ;
-            rec.y = has_lab ? load1<Tag>(rowp + lab) - logZ : C(0);
+            Cell<C> rec;                               // lattice log-probs are kept in base 2
+            rec.x = vmax((load1<Tag>(rowp + blank) - logZ) * C(kLog2e), log_zero<C>());
+            rec.y = has_lab ? vmax((load1<Tag>(rowp + lab) - logZ) * C(kLog2e), log_zero<C>()) : log_zero<C>();
             rec.z = logZ;
             rec.w = 0;
-            cells[(static_cast<size_t>(b) * D + (t + u)) * maxU + u] = rec;
+            cells[lat_index(b, t + u, u, maxT, maxU, Up)] = rec;
         }
     }
 }
 
 // ------------------------------------------------------------------------------------------
-// Lattice recursion.  grid = N * dirs (dirs = 2: alpha block and beta block per sample run
-// concurrently; dirs = 1: alpha only, forward scoring), block = ceil(maxU/64) wavefronts,
-// thread u owns lattice column u and walks the anti-diagonals.
+// Lattice recursion.  grid = N * dirs (dirs = 2: the alpha block and the beta block of a sample
+// run concurrently; dirs = 1: alpha only, forward scoring), block = Up = 64*ceil(maxU/64)
+// threads; thread u owns lattice column u, a wavefront owns 64 columns.
 //
-// Numerics: every kLatticeBlock diagonals the running values are re-centred on the block
-// maximum and the shift is accumulated in an fp64 offset per sample and diagonal
-// (offa / offb), so fp32 lattice values stay O(10) however long the utterance is; the
-// fp32 round-off of the reference's un-scaled recursion (1 ulp of |alpha| ~ 6e3 is 5e-4 at
-// T=1500,U=300: BASELINE.md section 3) does not build up.
-template <typename L, bool MULTI>
-__global__ __launch_bounds__(1024) void lattice_kernel(
+// A wavefront walks the anti-diagonals with its values in registers (base-2 logs):
+//   alpha: a(n,u) = log2add(a(n-1,u) + lp_blank(n-1,u), a(n-1,u-1) + lp_label(n-1,u-1))
+//   beta : b(n,u) = log2add(b(n+1,u) + lp_blank(n,u),   b(n+1,u+1) + lp_label(n,u))
+// (n = t+u; the skewed layout makes every per-diagonal access one coalesced row, addressed as
+// buffer base + scalar row offset + per-lane column offset).  The neighbour value moves one lane
+// through a DPP wave shift.  A lone wavefront is ISSUE-bound, not latency-bound (measured: a
+// dependent VALU op 3.5 ns, but ~2 ns per issued instruction of any kind), so the step is
+// stripped to its ten arithmetic instructions plus one load and one store:
+//   * NO validity tests.  All state starts at the finite "log zero" sentinel and every loaded
+//     log-prob is clamped to [sentinel, 0] (one v_med3_f32), so columns that have not started
+//     yet stay at "zero", and whatever is computed for cells outside the T_b x U_b lattice can
+//     only flow further outside it (alpha moves to larger t,u; beta to smaller): probability
+//     mass that leaves the lattice never comes back, and none exists outside it to begin with.
+//   * Diagonals are processed in chunks of C with two register buffers: the log-probs of chunk
+//     j+1 are fetched while chunk j computes; the C results of a chunk are stored at the start
+//     of the next chunk, BEFORE its prefetch is issued, so the in-order vmcnt never drains.
+//   * At the end of a chunk the wavefront re-centres its values on their maximum (DPP reduction)
+//     and adds the shift to its fp64 offset (off[b][wave][n]); fp32 values stay O(10) however
+//     long T+U is, so the round-off of an un-scaled fp32 recursion (5e-3 on grads at T=1500,
+//     U=301 in the reference's own fp32 CPU path) does not build up.
+//   * U > 64: the wavefronts of a block form a skewed pipeline -- in time slot s wavefront w
+//     works on chunk s-w (alpha; mirrored for beta) and reads the C boundary values its
+//     neighbour produced in slot s-1 from a 2-deep LDS ring (converted between the two
+//     wavefronts' offsets), so the block synchronises once per C diagonals instead of once per
+//     diagonal (the reference barriers every diagonal: gpu_rnnt_kernel.h:26-40).
+// Chunk length by lattice type and block size (MAXW = wavefronts per block the instantiation is
+// bounded to: 1024-thread blocks only get 128 VGPRs, so they use shorter chunks).
+template <typename L, int MAXW> struct LatChunk {
+    static constexpr int C = (sizeof(L) == 4 ? 16 : 8) / (MAXW > 8 ? 2 : 1);
+};
+#ifndef RNNT_LAT_ABLATE
+#define RNNT_LAT_ABLATE 0      // development only: bit0 drops the lattice stores, bit1 the loads
+#endif
+
+typedef unsigned int lat_u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int lat_u32x4 __attribute__((ext_vector_type(4)));
+
+// Row-addressed access to the skewed arrays through buffer instructions: the descriptor holds the
+// sample's base, `soff` is the scalar byte offset of a row, `voff` the lane's byte offset in it.
+template <typename L> struct LatIO;
+template <> struct LatIO<float> {
+    static __device__ __forceinline__ void load_xy(__amdgpu_buffer_rsrc_t r, int voff, int soff, float& x, float& y) {
+        const lat_u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
+        x = __builtin_amdgcn_fmed3f(__uint_as_float(v.x), log_zero<float>(), 0.0f);
+        y = __builtin_amdgcn_fmed3f(__uint_as_float(v.y), log_zero<float>(), 0.0f);
+    }
+    static __device__ __forceinline__ void store(__amdgpu_buffer_rsrc_t r, int voff, int soff, float v) {
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, voff, soff, 0);
+    }
+    static __device__ __forceinline__ float load(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+        return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+    }
+};
+template <> struct LatIO<double> {
+    static __device__ __forceinline__ void load_xy(__amdgpu_buffer_rsrc_t r, int voff, int soff, double& x, double& y) {
+        const lat_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+        x = fmin(fmax(__hiloint2double(static_cast<int>(v.y), static_cast<int>(v.x)), log_zero<double>()), 0.0);
+        y = fmin(fmax(__hiloint2double(static_cast<int>(v.w), static_cast<int>(v.z)), log_zero<double>()), 0.0);
+    }
+    static __device__ __forceinline__ void store(__amdgpu_buffer_rsrc_t r, int voff, int soff, double v) {
+        const lat_u32x2 w = {static_cast<unsigned>(__double2loint(v)), static_cast<unsigned>(__double2hiint(v))};
+        __builtin_amdgcn_raw_buffer_store_b64(w, r, voff, soff, 0);
+    }
+    static __device__ __forceinline__ double load(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+        const lat_u32x2 w = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
+        return __hiloint2double(static_cast<int>(w.y), static_cast<int>(w.x));
+    }
+};
+
+template <typename L, int MAXW>
+__global__ __launch_bounds__(MAXW * 64) void lattice_kernel(
         Cell<L>* __restrict__ cells, L* __restrict__ beta, double* __restrict__ offa,
         double* __restrict__ offb, double* __restrict__ ll_fwd, double* __restrict__ ll_bwd,
         L* __restrict__ costs_dev, const int* __restrict__ xlen, const int* __restrict__ ylen,
-        int maxT, int maxU, int dirs) {
-    constexpr int K = kLatticeBlock;
-    __shared__ L edge[2][16];
-    __shared__ L red[16];
+        int maxT, int maxU, int Up, int dirs) {
+    constexpr int C = LatChunk<L, MAXW>::C;
+    constexpr bool MULTI = MAXW > 1;
+    using IO = LatIO<L>;
+    __shared__ L ring[16][2][C];
+    __shared__ double ringoff[16][2];
     const int b = blockIdx.x / dirs;
     const int dir = blockIdx.x - b * dirs;
     const int u = threadIdx.x;
-    const int lane = u & 63, wave = u >> 6, nwaves = blockDim.x >> 6;
+    const int lane = u & 63;
+    const int wave = uniform(u >> 6);
+    const int W = blockDim.x >> 6;
     const int Tb = xlen[b], Ub = ylen[b] + 1;
     const int Db = Tb + Ub - 1;
-    const int D = maxT + maxU - 1;
-    const size_t base = static_cast<size_t>(b) * D * maxU;
-    Cell<L>* c = cells + base;
-    L* bt = beta + base;
-    double* off = (dir == 0 ? offa : offb) + static_cast<size_t>(b) * D;
-    const L NEG = neg_inf<L>();
-    (void)nwaves; (void)lane; (void)wave; (void)edge; (void)red;
-
-    auto block_max = [&](L v) -> L {
-        L m = wave_max(v);
-        if constexpr (MULTI) {
-            if (lane == 0) red[wave] = m;
-            __syncthreads();
-            m = red[0];
-            for (int w = 1; w < nwaves; ++w) m = vmax(m, red[w]);
-            __syncthreads();
-        }
-        return m;
-    };
-
-    double Coff = 0.0;   // accumulated re-centring shift (block-uniform)
+    const size_t Dp = lat_rows(maxT, maxU);
+    // descriptors start at the first PAD row of this sample: row n lives at (n + kLatPad)
+    const size_t sample0 = static_cast<size_t>(b) * Dp * Up;
+    const int cell_row = Up * static_cast<int>(sizeof(Cell<L>));      // bytes per row of `cells`
+    const int beta_row = Up * static_cast<int>(sizeof(L));            // bytes per row of `beta`
+    const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(
+        cells + sample0, 0, static_cast<int>(Dp * cell_row), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(
+        beta + sample0, 0, static_cast<int>(Dp * beta_row), 0x00020000);
+    const int vc = u * static_cast<int>(sizeof(Cell<L>));             // lane offset of cell (.,u)
+    const int vw = vc + 3 * static_cast<int>(sizeof(L));              // ... of its .w field
+    const int vb = u * static_cast<int>(sizeof(L));
+    double* off = (dir == 0 ? offa : offb) + (static_cast<size_t>(b) * W + wave) * Dp + kLatPad;
+    const L NEG = log_zero<L>();
+    const unsigned Tb_eff = (u < Ub) ? static_cast<unsigned>(Tb) : 0u;   // cell (n-u,u) in the lattice <=> (unsigned)(n-u) < Tb_eff
+    const int nsteps = Db - 1;
+    const int nchunks = (nsteps + C - 1) / C;
+    const int nslots = nchunks + (MULTI ? W - 1 : 0);
+    (void)ring; (void)ringoff;
+    double Coff = 0.0, Cused = 0.0;
+    L bufA_b[C], bufA_l[C], bufB_b[C], bufB_l[C], hist[C];
+    int jprev = -1;                      // chunk whose results are still in `hist`
 
     if (dir == 0) {
-        // ---------------- alpha: diagonal n is built from diagonal n-1 ----------------
-        // lane u holds a = alpha~(n-1-u, u); it feeds (t+1,u) [blank] on its own lane and
-        // (t,u+1) [label] on lane u+1; both use the SOURCE cell's log-probs.
+        // ------------------------------- alpha -------------------------------
         L a = (u == 0) ? L(0) : NEG;
-        if (u == 0) { c[0].w = 0; off[0] = 0.0; }
-        L pb[K], pl[K], nb[K], nl[K];
-        auto fetch = [&](int n0, L* xb, L* xl) {
+        if (u == 0) IO::store(rc, vw, kLatPad * cell_row, L(0));
+        if (lane == 0) off[0] = 0.0;
+        auto fetch = [&](int j, L* xb, L* xl) {     // chunk j: diagonals j*C+1 .. j*C+C read SOURCE rows j*C .. j*C+C-1
+            if (RNNT_LAT_ABLATE & 2) { for (int k = 0; k < C; ++k) { xb[k] = L(-1.5); xl[k] = L(-2.5); } return; }
 #pragma unroll
-            for (int k = 0; k < K; ++k) {
-                const int src = n0 + k - 1;          // source diagonal
-                const int ts = src - u;
-                const bool ok = (src < Db - 1) && (u < Ub) && (ts >= 0) && (ts < Tb);
-                L x = 0, y = 0;
-                if (ok) {
-                    const Cell<L>* p = c + static_cast<size_t>(src) * maxU + u;
-                    x = p->x; y = p->y;
+            for (int k = 0; k < C; ++k) IO::load_xy(rc, vc, (j * C + k + kLatPad) * cell_row, xb[k], xl[k]);
+        };
+        auto flush = [&]() {                        // results of chunk jprev (issued BEFORE the next prefetch)
+            if (RNNT_LAT_ABLATE & 1) return;
+#pragma unroll
+            for (int k = 0; k < C; ++k) IO::store(rc, vw, (jprev * C + 1 + k + kLatPad) * cell_row, hist[k]);
+            if (lane < C) off[jprev * C + 1 + lane] = Cused;
+        };
+        auto chunk = [&](int s, int j, const L* pb, const L* pl, L* nb, L* nl) {
+            if (jprev >= 0) flush();
+            fetch(j + 1 < nchunks ? j + 1 : j, nb, nl);       // (stay inside the back padding)
+            L inv = NEG;
+            if constexpr (MULTI) {
+                if (wave > 0) {
+                    const L raw = ring[wave - 1][(s - 1) & 1][lane & (C - 1)];
+                    const L delta = static_cast<L>(ringoff[wave - 1][(s - 1) & 1] - Coff);
+                    inv = raw + delta;
                 }
-                xb[k] = x; xl[k] = y;
+            }
+            L outv = NEG;
+#pragma unroll
+            for (int k = 0; k < C; ++k) {
+                const L stay = a + pb[k];
+                const L emit = a + pl[k];
+                L up = wave_shr1(emit, NEG);
+                if constexpr (MULTI) {
+                    up = (lane == 0) ? lane_get(inv, k) : up;
+                    outv = lane_set(outv, lane_get(emit, 63), k);
+                }
+                a = log2_add(stay, up);
+                hist[k] = a;
+            }
+            jprev = j;
+            Cused = Coff;
+            if constexpr (MULTI) {
+                if (lane < C) ring[wave][s & 1][lane] = outv;
+                if (lane == 0) ringoff[wave][s & 1] = Coff;
+            }
+            if (j + 1 < nchunks) {                       // re-centre (not after the final diagonal)
+                // maximum over the lanes that are INSIDE the lattice on this diagonal only: whatever
+                // sits in the others must not steer the offset
+                const bool inside = static_cast<unsigned>(j * C + C - u) < Tb_eff;
+                const L m = wave_max_dpp(inside ? a : NEG);
+                if (m > NEG * L(0.5)) { a -= m; Coff += static_cast<double>(m); }   // skip all-"zero" waves
             }
         };
-        fetch(1, pb, pl);
-        for (int n0 = 1; n0 < Db; n0 += K) {
-            fetch(n0 + K, nb, nl);
-#pragma unroll
-            for (int k = 0; k < K; ++k) {
-                const int n = n0 + k;
-                if (n < Db) {                          // block-uniform
-                    const L stay = a + pb[k];
-                    const L emit = a + pl[k];
-                    L up = wave_shr1(emit, NEG);
-                    if constexpr (MULTI) {
-                        if (lane == 63) edge[n & 1][wave] = emit;
-                        __syncthreads();
-                        if (lane == 0 && wave > 0) up = edge[n & 1][wave - 1];
-                    }
-                    const int t = n - u;
-                    const bool valid = (u < Ub) && (t >= 0) && (t < Tb);
-                    const L v = log_add(stay, up);
-                    a = valid ? v : NEG;
-                    if (valid) c[static_cast<size_t>(n) * maxU + u].w = a;
-                    if (u == 0) off[n] = Coff;
+        fetch(0, bufA_b, bufA_l);
+        for (int s = 0; s < nslots; s += 2) {
+            {
+                const int j = MULTI ? s - wave : s;
+                if (j >= 0 && j < nchunks) {
+                    if (j & 1) chunk(s, j, bufB_b, bufB_l, bufA_b, bufA_l); else chunk(s, j, bufA_b, bufA_l, bufB_b, bufB_l);
                 }
+                if constexpr (MULTI) __syncthreads();
             }
-            const L m = block_max(a);
-            if (m != NEG) { a -= m; Coff += static_cast<double>(m); }
-#pragma unroll
-            for (int k = 0; k < K; ++k) { pb[k] = nb[k]; pl[k] = nl[k]; }
+            if (s + 1 < nslots) {
+                const int j = MULTI ? s + 1 - wave : s + 1;
+                if (j >= 0 && j < nchunks) {
+                    if (j & 1) chunk(s + 1, j, bufB_b, bufB_l, bufA_b, bufA_l); else chunk(s + 1, j, bufA_b, bufA_l, bufB_b, bufB_l);
+                }
+                if constexpr (MULTI) __syncthreads();
+            }
         }
+        if (jprev >= 0) flush();
         if (u == Ub - 1) {
-            const double ll = static_cast<double>(a) + Coff +
-                              static_cast<double>(c[static_cast<size_t>(Db - 1) * maxU + u].x);
-            ll_fwd[b] = ll;
-            costs_dev[b] = static_cast<L>(-ll);
+            // alpha(T-1,U-1) of this column: read it back (same thread wrote it), with the offset
+            // that was current when its diagonal was stored
+            const L a_last = (nsteps == 0) ? L(0) : IO::load(rc, vw, (Db - 1 + kLatPad) * cell_row);
+            const double o_last = (nsteps == 0) ? 0.0 : Cused;   // the last chunk is never re-centred
+            L xl_, xb_;
+            IO::load_xy(rc, vc, (Db - 1 + kLatPad) * cell_row, xb_, xl_);
+            const double ll2 = static_cast<double>(a_last) + o_last + static_cast<double>(xb_);
+            ll_fwd[b] = ll2;                                  // base 2, for the coefficient kernel
+            costs_dev[b] = static_cast<L>(-ll2 * kLn2);
         }
     } else {
-        // ---------------- beta: diagonal n is built from diagonal n+1 ----------------
-        // lane u holds bv = beta~(n+1-u, u); target (n-u, u) takes its own lane's value
-        // [blank] and lane u+1's value [label], with the TARGET cell's log-probs.
+        // ------------------------------- beta -------------------------------
         L bv = NEG;
         if (u == Ub - 1) {
-            const size_t last = static_cast<size_t>(Db - 1) * maxU + u;
-            bv = c[last].x;
-            bt[last] = bv;
+            L xl_;
+            IO::load_xy(rc, vc, (Db - 1 + kLatPad) * cell_row, bv, xl_);
+            IO::store(rb, vb, (Db - 1 + kLatPad) * beta_row, bv);
         }
-        if (u == 0) off[Db - 1] = 0.0;
-        L pb[K], pl[K], nb[K], nl[K];
-        auto fetch = [&](int n0, L* xb, L* xl) {    // diagonals n0, n0-1, ... n0-K+1
+        if (lane == 0) off[Db - 1] = 0.0;
+        auto fetch = [&](int j, L* xb, L* xl) {     // chunk j: steps i = j*C .. j*C+C-1, TARGET rows n = Db-2-i
+            if (RNNT_LAT_ABLATE & 2) { for (int k = 0; k < C; ++k) { xb[k] = L(-1.5); xl[k] = L(-2.5); } return; }
 #pragma unroll
-            for (int k = 0; k < K; ++k) {
-                const int n = n0 - k;
-                const int t = n - u;
-                const bool ok = (n >= 0) && (u < Ub) && (t >= 0) && (t < Tb);
-                L x = 0, y = 0;
-                if (ok) {
-                    const Cell<L>* p = c + static_cast<size_t>(n) * maxU + u;
-                    x = p->x; y = p->y;
+            for (int k = 0; k < C; ++k) IO::load_xy(rc, vc, (Db - 2 - (j * C + k) + kLatPad) * cell_row, xb[k], xl[k]);
+        };
+        auto flush = [&]() {
+            if (RNNT_LAT_ABLATE & 1) return;
+#pragma unroll
+            for (int k = 0; k < C; ++k) IO::store(rb, vb, (Db - 2 - (jprev * C + k) + kLatPad) * beta_row, hist[k]);
+            if (lane < C) off[Db - 2 - (jprev * C + lane)] = Cused;
+        };
+        auto chunk = [&](int s, int j, const L* pb, const L* pl, L* nb, L* nl) {
+            if (jprev >= 0) flush();
+            fetch(j + 1 < nchunks ? j + 1 : j, nb, nl);      // (no rows below the front padding)
+            L inv = NEG;
+            if constexpr (MULTI) {
+                if (wave + 1 < W) {
+                    const L raw = ring[wave + 1][(s - 1) & 1][lane & (C - 1)];
+                    const L delta = static_cast<L>(ringoff[wave + 1][(s - 1) & 1] - Coff);
+                    inv = raw + delta;
                 }
-                xb[k] = x; xl[k] = y;
+            }
+            L outv = NEG;
+#pragma unroll
+            for (int k = 0; k < C; ++k) {
+                L right = wave_shl1(bv, NEG);
+                if constexpr (MULTI) {
+                    right = (lane == 63) ? lane_get(inv, k) : right;
+                    outv = lane_set(outv, lane_get(bv, 0), k);
+                }
+                const L stay = bv + pb[k];
+                const L emit = right + pl[k];
+                bv = log2_add(stay, emit);
+                hist[k] = bv;
+            }
+            jprev = j;
+            Cused = Coff;
+            if constexpr (MULTI) {
+                if (lane < C) ring[wave][s & 1][lane] = outv;
+                if (lane == 0) ringoff[wave][s & 1] = Coff;
+            }
+            if (j + 1 < nchunks) {
+                const bool inside = static_cast<unsigned>(Db - 2 - (j * C + C - 1) - u) < Tb_eff;
+                const L m = wave_max_dpp(inside ? bv : NEG);
+                if (m > NEG * L(0.5)) { bv -= m; Coff += static_cast<double>(m); }
             }
         };
-        fetch(Db - 2, pb, pl);
-        for (int n0 = Db - 2; n0 >= 0; n0 -= K) {
-            fetch(n0 - K, nb, nl);
-#pragma unroll
-            for (int k = 0; k < K; ++k) {
-                const int n = n0 - k;
-                if (n >= 0) {                          // block-uniform
-                    L right = wave_shl1(bv, NEG);
-                    if constexpr (MULTI) {
-                        if (lane == 0) edge[n & 1][wave] = bv;
-                        __syncthreads();
-                        if (lane == 63 && wave + 1 < nwaves) right = edge[n & 1][wave + 1];
-                    }
-                    const L stay = bv + pb[k];
-                    const L emit = right + pl[k];
-                    const int t = n - u;
-                    const bool valid = (u < Ub) && (t >= 0) && (t < Tb);
-                    const L v = log_add(stay, emit);
-                    bv = valid ? v : NEG;
-                    if (valid) bt[static_cast<size_t>(n) * maxU + u] = bv;
-                    if (u == 0) off[n] = Coff;
+        fetch(0, bufA_b, bufA_l);
+        for (int s = 0; s < nslots; s += 2) {
+            {
+                const int j = MULTI ? s - (W - 1 - wave) : s;
+                if (j >= 0 && j < nchunks) {
+                    if (j & 1) chunk(s, j, bufB_b, bufB_l, bufA_b, bufA_l); else chunk(s, j, bufA_b, bufA_l, bufB_b, bufB_l);
                 }
+                if constexpr (MULTI) __syncthreads();
             }
-            const L m = block_max(bv);
-            if (m != NEG) { bv -= m; Coff += static_cast<double>(m); }
-#pragma unroll
-            for (int k = 0; k < K; ++k) { pb[k] = nb[k]; pl[k] = nl[k]; }
+            if (s + 1 < nslots) {
+                const int j = MULTI ? s + 1 - (W - 1 - wave) : s + 1;
+                if (j >= 0 && j < nchunks) {
+                    if (j & 1) chunk(s + 1, j, bufB_b, bufB_l, bufA_b, bufA_l); else chunk(s + 1, j, bufA_b, bufA_l, bufB_b, bufB_l);
+                }
+                if constexpr (MULTI) __syncthreads();
+            }
         }
-        if (u == 0) ll_bwd[b] = static_cast<double>(bv) + Coff;
+        if (jprev >= 0) flush();
+        if (u == 0) {
+            const L b0 = IO::load(rb, vb, kLatPad * beta_row);
+            ll_bwd[b] = (static_cast<double>(b0) + (nsteps == 0 ? 0.0 : Cused)) * kLn2;
+        }
     }
 }
 
@@ -432,7 +562,7 @@ __global__ __launch_bounds__(256) void coef_kernel(
         const Cell<L>* __restrict__ cells, const L* __restrict__ beta, const double* __restrict__ offa,
         const double* __restrict__ offb, const double* __restrict__ ll_fwd,
         const int* __restrict__ labels, const int* __restrict__ xlen, const int* __restrict__ ylen,
-        Cell<L>* __restrict__ rowtab, int maxT, int maxU) {
+        Cell<L>* __restrict__ rowtab, int maxT, int maxU, int Up) {
     const int b = blockIdx.y;
     const int q = blockIdx.x * 256 + threadIdx.x;
     if (q >= maxT * maxU) return;
@@ -441,24 +571,27 @@ __global__ __launch_bounds__(256) void coef_kernel(
     Cell<L> o;
     o.x = 0; o.y = 0; o.z = 0; o.w = static_cast<L>(kPadded);
     if (t < Tb && u < Ub) {
-        const int D = maxT + maxU - 1;
+        const size_t Dp = lat_rows(maxT, maxU);
         const int n = t + u;
-        const size_t idx = static_cast<size_t>(b) * D * maxU + static_cast<size_t>(n) * maxU + u;
+        const int W = Up >> 6;
+        const size_t idx = lat_index(b, n, u, maxT, maxU, Up);
         const Cell<L> r = cells[idx];
         const L* bp = beta + idx;
-        const double* oa = offa + static_cast<size_t>(b) * D;
-        const double* ob = offb + static_cast<size_t>(b) * D;
-        const double alpha = static_cast<double>(r.w) + oa[n] - ll_fwd[b];     // alpha(t,u) - ll
+        // offsets are per wavefront of the lattice block: cell (.,u) belongs to wave u/64
+        const double* oa = offa + (static_cast<size_t>(b) * W + (u >> 6)) * Dp + kLatPad;
+        const double* ob = offb + (static_cast<size_t>(b) * W + (u >> 6)) * Dp + kLatPad;
+        const double* ob_r = offb + (static_cast<size_t>(b) * W + ((u + 1) >> 6)) * Dp + kLatPad;   // column u+1
+        // everything below is in base-2 logs until the final conversion
+        const double alpha = static_cast<double>(r.w) + oa[n] - ll_fwd[b];     // log2 alpha(t,u) - log2 P(y|x)
         const bool last_t = (t == Tb - 1), last_u = (u == Ub - 1);
-        const double ob1 = (last_t && last_u) ? 0.0 : ob[n + 1];
-        o.x = static_cast<L>(alpha + static_cast<double>(bp[0]) + ob[n] - static_cast<double>(r.z));
+        o.x = static_cast<L>((alpha + static_cast<double>(bp[0]) + ob[n]) * kLn2 - static_cast<double>(r.z));
         if (!last_t)
-            o.y = fast_exp(static_cast<L>(alpha + static_cast<double>(r.x) + static_cast<double>(bp[maxU]) + ob1));
+            o.y = fast_exp2(static_cast<L>(alpha + static_cast<double>(r.x) + static_cast<double>(bp[Up]) + ob[n + 1]));
         else if (last_u)
-            o.y = fast_exp(static_cast<L>(alpha + static_cast<double>(r.x)));
+            o.y = fast_exp2(static_cast<L>(alpha + static_cast<double>(r.x)));
         int lab = -1;
         if (!last_u) {
-            o.z = fast_exp(static_cast<L>(alpha + static_cast<double>(r.y) + static_cast<double>(bp[maxU + 1]) + ob1));
+            o.z = fast_exp2(static_cast<L>(alpha + static_cast<double>(r.y) + static_cast<double>(bp[Up + 1]) + ob_r[n + 1]));
             lab = labels[static_cast<size_t>(b) * (maxU - 1) + u];
         }
         o.w = static_cast<L>(lab);

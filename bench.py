@@ -108,6 +108,8 @@ def main():
     ap.add_argument("--cpu-samples", type=int, default=32)
     ap.add_argument("--extra", action="store_true", help="also time the other single-GPU workloads")
     ap.add_argument("--override", default="", help="dev: override workload fields, e.g. A=4992,N=64")
+    ap.add_argument("--force-sharded", action="store_true",
+                    help="dev: run the multi-GPU step (async entry + RCCL all-reduce) even with one rank")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -117,8 +119,14 @@ def main():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
-        dist.init_process_group("nccl", device_id=dev)   # "nccl" is RCCL on ROCm
+    sharded = world > 1 or args.force_sharded
+    if sharded:
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29533")
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+        else:
+            dist.init_process_group("nccl", device_id=dev)   # "nccl" is RCCL on ROCm
 
     from warprnnt_pytorch import _lib, warp_rnnt
     lib = _lib.lib()
@@ -137,7 +145,7 @@ def main():
         stream = torch.cuda.current_stream(dev).cuda_stream
         opt = _lib.rnntOptions(loc=_lib.RNNT_GPU, num_threads=0, stream=stream, blank_label=0, maxT=T,
                                maxU=U, batch_first=True)
-        if world == 1:
+        if not sharded:
             # the drop-in C-ABI call: host costs, one stream sync per call
             fn = {"fp32": lib.compute_rnnt_loss, "bf16": lib.compute_rnnt_loss_bf16}[w["dtype"]]
             costs = torch.zeros(N, dtype=torch.float32)
@@ -162,24 +170,25 @@ def main():
                                       torch.tensor(float(N), dtype=torch.float64, device=dev)])
                 dist.all_reduce(packed)
                 torch.cuda.synchronize(dev)
+                lib.rnnt_profile_collect()
                 return packed
 
         for _ in range(warmup):
             step()
         lib.rnnt_profile_reset()
-        lib.rnnt_profile_enable(1 if world == 1 else 0)
-        if world > 1:
+        lib.rnnt_profile_enable(1)
+        if sharded:
             dist.barrier()
         torch.cuda.synchronize(dev)
         t0 = time.perf_counter()
         for _ in range(steps):
             out = step()
         torch.cuda.synchronize(dev)
-        if world > 1:
+        if sharded:
             dist.barrier()
         elapsed = time.perf_counter() - t0
         lib.rnnt_profile_enable(0)
-        if world > 1:
+        if sharded:
             tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             elapsed = float(tmax.item())
@@ -189,14 +198,14 @@ def main():
         stage_ms = [stage[i] / calls for i in range(5)] if calls else None
         ab = algorithmic_bytes(w)
         res = dict(workload=name, ms_per_step=ms_step, stage_ms=stage_ms, bytes=ab, w=w,
-                   loss_sum=float(out.sum()) if world == 1 else float(out[0]))
+                   loss_sum=float(out.sum()) if not sharded else float(out[0]))
         if with_cpu and rank == 0:
             res["cpu"] = cpu_baseline(w, acts, labels, act_lens, label_lens, args.cpu_samples)
         del acts, grads, ws
         torch.cuda.empty_cache()
         return res
 
-    r = run_workload(args.workload, args.steps, args.warmup, with_cpu=(world == 1 and not args.no_cpu_baseline))
+    r = run_workload(args.workload, args.steps, args.warmup, with_cpu=(not sharded and not args.no_cpu_baseline))
     w, ab = r["w"], r["bytes"]
     ms = r["ms_per_step"]
     U = w["L"] + 1
@@ -221,10 +230,19 @@ def main():
     if r["stage_ms"]:
         sm = r["stage_ms"]
         gk = sm[3]
-        out["roofline"] = {"bound": "hbm", "kernel": "grad_kernel (dense gradient write-back)",
+        traffic = None
+        try:   # PMC-measured HBM bytes per launch of this kernel, from the committed rocprofv3 passes
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
+            if not args.override:
+                traffic = tj[args.workload]["grad_flat_kernel"]["traffic_bytes"]
+        except (OSError, KeyError, ValueError):
+            pass
+        out["roofline"] = {"bound": "hbm", "kernel": "grad_flat_kernel (second read of the logits + dense gradient write-back)",
                            "achieved": round(ab["grad_kernel"] / (gk * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS,
                            "unit": "GB/s", "frac": round(ab["grad_kernel"] / (gk * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                           "traffic": None, "bytes_algo": ab["grad_kernel"], "avg_ms": round(gk, 4)}
+                           "traffic": traffic, "bytes_algo": ab["grad_kernel"], "avg_ms": round(gk, 4),
+                           "traffic_source": "profiles/r01_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)"
+                           if traffic else None}
         out["stage_ms"] = {"row_stats": round(sm[0], 4), "lattice": round(sm[1], 4), "coef": round(sm[2], 4),
                            "grad": round(sm[3], 4), "enqueue_span": round(sm[4], 4)}
         out["stats_roofline"] = {"achieved": round(ab["stats_kernel"] / (sm[0] * 1e-3) / 1e9, 1),
@@ -232,7 +250,7 @@ def main():
                                  "unit": "GB/s"}
     if "cpu" in r:
         out["cpu_baseline"] = r["cpu"]
-    if args.extra and world == 1:
+    if args.extra and not sharded:
         extra = {}
         for name in sorted(WORKLOADS):
             if name == args.workload:
@@ -245,7 +263,7 @@ def main():
         out["other_workloads"] = extra
     if rank == 0:
         print(json.dumps(out))
-    if world > 1:
+    if sharded:
         dist.destroy_process_group()
 
 

@@ -186,8 +186,11 @@ rnntStatus_t compute_rnnt_loss_async(const void* activations,
  *   ms[2] coefficient kernel (per-cell gradient coefficients)
  *   ms[3] gradient kernel  (dense gradient write-back)
  *   ms[4] whole enqueue, first kernel start -> last kernel end
+ * compute_rnnt_loss_async does not synchronise, so its events are read by an explicit
+ * rnnt_profile_collect() once the caller has synchronised the stream.
  * Process-global, not thread-safe; meant for bench.py only. */
 void rnnt_profile_enable(int on);
+void rnnt_profile_collect(void);   /* after synchronising a compute_rnnt_loss_async call: add its times */
 void rnnt_profile_reset(void);
 int rnnt_profile_read(double* ms, int n);
 

@@ -55,6 +55,7 @@ struct Profile {
     hipEvent_t ev[5];
     double ms[5] = {0, 0, 0, 0, 0};
     int calls = 0;
+    bool pending = false;   // events of an asynchronous call recorded, not yet read
 };
 static Profile g_prof;
 
@@ -68,12 +69,23 @@ static bool prof_prepare() {
     return true;
 }
 
+static void prof_accumulate() {
+    for (int i = 0; i < 4; ++i) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, g_prof.ev[i], g_prof.ev[i + 1]) == hipSuccess) g_prof.ms[i] += ms;
+    }
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, g_prof.ev[0], g_prof.ev[4]) == hipSuccess) g_prof.ms[4] += ms;
+    g_prof.calls++;
+    g_prof.pending = false;
+}
+
 // ----------------------------------------------------------------------------- tuning knobs
 // Development A/B switches, read once from RNNT_TUNE="key=value,key=value" (defaults are the
 // measured best; see profiles/).  sw = waves per block of the row-stats kernel (2|4|8),
 // nta = non-temporal stats loads, gmax = grid cap of the flat gradient kernel, rows = 1 forces
 // the row-form gradient kernel.
-struct Tune { int gw = 4, sw = 4, nta = 1, gmax = 262144, rows = 0, tile = 1, tilekb = 48; };
+struct Tune { int gw = 4, sw = 4, nta = 1, gmax = 4194304, rows = 0, tile = 1, tilekb = 48, ppt = 2; };
 static Tune g_tune;
 static bool g_tune_read = false;
 static const Tune& tune() {
@@ -86,7 +98,7 @@ static const Tune& tune() {
             };
             get("gw", g_tune.gw); get("sw", g_tune.sw); get("nta", g_tune.nta);
             get("gmax", g_tune.gmax); get("rows", g_tune.rows); get("tile", g_tune.tile);
-            get("tilekb", g_tune.tilekb);
+            get("tilekb", g_tune.tilekb); get("ppt", g_tune.ppt);
         }
     }
     return g_tune;
@@ -131,7 +143,7 @@ static rnntStatus_t run_gpu(const typename Tag::store* acts, typename Tag::store
     int vec_ok = (pa % sizeof(S) == 0) ? 1 : 0;
     if (training && ((pa ^ pg) & 15u)) vec_ok = 0;
 
-    const bool prof = costs_host != nullptr && prof_prepare();
+    const bool prof = prof_prepare();
     auto mark = [&](int i) { if (prof) (void)hipEventRecord(g_prof.ev[i], stream); };
 
     const Tune& tn = tune();
@@ -201,19 +213,23 @@ static rnntStatus_t run_gpu(const typename Tag::store* acts, typename Tag::store
         const bool flat_ok = vec_ok && (pa & 15u) == 0 && (pg & 15u) == 0 && A <= (1 << 23) && !tn.rows;
         if (flat_ok) {
             const unsigned long long npk = E / V;
-            const unsigned long long nchunks = (npk + kChunkPackets - 1) / kChunkPackets;
+            const int ppt = (tn.ppt == 1 || tn.ppt == 4) ? tn.ppt : 2;
+            const unsigned long long cpk = static_cast<unsigned long long>(ppt) * 256;
+            const unsigned long long nchunks = (npk + cpk - 1) / cpk;
             const unsigned grid = static_cast<unsigned>(nchunks < static_cast<unsigned long long>(tn.gmax)
                                                             ? (nchunks ? nchunks : 1) : tn.gmax);
-            const unsigned long long stride = static_cast<unsigned long long>(grid) * kChunkPackets * V;
+            const unsigned long long stride = static_cast<unsigned long long>(grid) * cpk * V;
             const unsigned long long dq = stride / A;
             const int drem = static_cast<int>(stride % A);
             const float invA = 1.0f / static_cast<float>(A);
-            if (grad_scale)
-                hipLaunchKernelGGL((grad_flat_kernel<Tag, true>), dim3(grid), dim3(256), 0, stream, acts, grads,
-                                   rowtab, grad_scale, E, R, A, blank, cells_per_sample, invA, dq, drem);
-            else
-                hipLaunchKernelGGL((grad_flat_kernel<Tag, false>), dim3(grid), dim3(256), 0, stream, acts, grads,
-                                   rowtab, grad_scale, E, R, A, blank, cells_per_sample, invA, dq, drem);
+#define RNNT_FLAT(SC, PP)                                                                                  \
+    hipLaunchKernelGGL((grad_flat_kernel<Tag, SC, PP>), dim3(grid), dim3(256), 0, stream, acts, grads, rowtab, \
+                       grad_scale, E, R, A, blank, cells_per_sample, invA, dq, drem)
+            if (grad_scale) RNNT_FLAT(true, 2);
+            else if (ppt == 1) RNNT_FLAT(false, 1);
+            else if (ppt == 4) RNNT_FLAT(false, 4);
+            else RNNT_FLAT(false, 2);
+#undef RNNT_FLAT
         } else {
             if (grad_scale)
                 hipLaunchKernelGGL((grad_rows_kernel<Tag, 4, true>), row_grid(4), dim3(256), 0, stream, acts, grads,
@@ -232,15 +248,9 @@ static rnntStatus_t run_gpu(const typename Tag::store* acts, typename Tag::store
         if (hipMemcpyAsync(costs_host, costs_dev, sizeof(C) * N, hipMemcpyDeviceToHost, stream) != hipSuccess)
             return RNNT_STATUS_MEMOPS_FAILED;
         if (hipStreamSynchronize(stream) != hipSuccess) return RNNT_STATUS_EXECUTION_FAILED;
-        if (prof) {
-            for (int i = 0; i < 4; ++i) {
-                float ms = 0.f;
-                if (hipEventElapsedTime(&ms, g_prof.ev[i], g_prof.ev[i + 1]) == hipSuccess) g_prof.ms[i] += ms;
-            }
-            float ms = 0.f;
-            if (hipEventElapsedTime(&ms, g_prof.ev[0], g_prof.ev[4]) == hipSuccess) g_prof.ms[4] += ms;
-            g_prof.calls++;
-        }
+        if (prof) prof_accumulate();
+    } else if (prof) {
+        g_prof.pending = true;     // the caller synchronises, then calls rnnt_profile_collect()
     }
     return RNNT_STATUS_SUCCESS;
 }
@@ -372,6 +382,10 @@ rnntStatus_t compute_rnnt_loss_async(const void* activations, void* gradients, c
 }
 
 void rnnt_profile_enable(int on) { g_prof.on = on != 0; }
+
+void rnnt_profile_collect(void) {
+    if (g_prof.on && g_prof.ready && g_prof.pending) prof_accumulate();
+}
 
 void rnnt_profile_reset(void) {
     for (double& m : g_prof.ms) m = 0.0;

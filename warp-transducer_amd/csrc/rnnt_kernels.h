@@ -605,14 +605,12 @@ __global__ __launch_bounds__(256) void coef_kernel(
 // per iteration (each of its 4 wavefronts moves whole 1 KB lines) and grid-strides over the
 // chunks; loads and stores carry the non-temporal hint.  The row of a packet is recovered
 // arithmetically (row of the chunk start is carried incrementally in 64-bit; inside the chunk
-// a 32-bit reciprocal division) and its {c, cb, cl, label} record comes from the natural-order
+// a 32-bit reciprocal division; chunk = PPT*256 packets) and its {c, cb, cl, label} record comes from the natural-order
 // row table (L1/L2 hits: consecutive packets share rows).  Padded rows are written as zeros
 // here, so no memset of the gradient tensor exists (the reference does one: gpu_rnnt.h:107-110).
 // Measured on MI355X (tools/microbench/stream_variants.hip): this structure sustains
 // 6.4-6.5 TB/s read+write with the exp included, the wavefront-per-row form 5.1 TB/s.
-constexpr int kChunkPackets = 1024;   // 4 packets per thread, 256 threads
-
-template <typename Tag, bool SCALED>
+template <typename Tag, bool SCALED, int PPT>      // PPT = packets per thread and iteration
 __global__ __launch_bounds__(256) void grad_flat_kernel(
         const typename Tag::store* __restrict__ acts, typename Tag::store* __restrict__ grads,
         const Cell<typename Tag::comp>* __restrict__ rowtab, const typename Tag::comp* __restrict__ grad_scale,
@@ -620,6 +618,7 @@ __global__ __launch_bounds__(256) void grad_flat_kernel(
         unsigned long long dq, int drem) {
     using C = typename Tag::comp;
     constexpr int V = Vec<Tag>::N;
+    constexpr int kChunkPackets = PPT * 256;
     constexpr int CH = kChunkPackets * V;                 // elements per chunk
     const unsigned long long npk = E / V;
     const unsigned long long nchunks = (npk + kChunkPackets - 1) / kChunkPackets;
@@ -646,13 +645,13 @@ __global__ __launch_bounds__(256) void grad_flat_kernel(
 
     for (; c < nchunks; c += gridDim.x) {
         const unsigned long long pk0 = c * kChunkPackets;
-        uint4 raw[4];
-        Cell<C> rec[4];
-        int v0[4];
-        unsigned long long row[4];
-        bool live[4];
+        uint4 raw[PPT];
+        Cell<C> rec[PPT];
+        int v0[PPT];
+        unsigned long long row[PPT];
+        bool live[PPT];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < PPT; ++k) {
             const int p = k * 256 + threadIdx.x;
             live[k] = pk0 + p < npk;
             const unsigned idx = static_cast<unsigned>(rem) + static_cast<unsigned>(p) * V;
@@ -667,7 +666,7 @@ __global__ __launch_bounds__(256) void grad_flat_kernel(
             }
         }
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < PPT; ++k) {
             if (!live[k]) continue;
             const int p = k * 256 + threadIdx.x;
             C v[V];

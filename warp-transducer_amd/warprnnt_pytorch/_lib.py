@@ -41,6 +41,7 @@ EXPORTS = {
                                           _PTR, _PTR, rnntOptions, C.c_int]),
     "rnnt_profile_enable": (None, [C.c_int]),
     "rnnt_profile_reset": (None, []),
+    "rnnt_profile_collect": (None, []),
     "rnnt_profile_read": (C.c_int, [C.POINTER(C.c_double), C.c_int]),
 }
 

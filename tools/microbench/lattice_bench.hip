@@ -11,21 +11,21 @@ int main(int argc, char** argv) {
     const int N = argc > 1 ? atoi(argv[1]) : 16, T = argc > 2 ? atoi(argv[2]) : 1500, U = argc > 3 ? atoi(argv[3]) : 41;
     const int Up = (U + 63) / 64 * 64, W = Up / 64;
     const size_t Dp = lat_rows(T, U);
-    Cell<float>* cells; float* beta; double *offa, *offb, *llf, *llb; float* costs; int *xlen, *ylen;
-    CK(hipMalloc(&cells, N * Dp * Up * 16)); CK(hipMalloc(&beta, (N * Dp * Up + Up + 64) * 4));
+    LogPair<float>* cells; float* alpha; float* beta; double *offa, *offb, *llf, *llb; float* costs; int *xlen, *ylen;
+    CK(hipMalloc(&cells, N * Dp * Up * 8)); CK(hipMalloc(&beta, (N * Dp * Up + Up + 64) * 4)); CK(hipMalloc(&alpha, (N * Dp * Up + Up + 64) * 4));
     CK(hipMalloc(&offa, N * W * Dp * 8)); CK(hipMalloc(&offb, (N * W * Dp + Dp) * 8));
     CK(hipMalloc(&llf, N * 8)); CK(hipMalloc(&llb, N * 8)); CK(hipMalloc(&costs, N * 4));
     CK(hipMalloc(&xlen, N * 4)); CK(hipMalloc(&ylen, N * 4));
-    std::vector<Cell<float>> h(N * Dp * Up);
-    for (auto& c : h) { c.x = -1.0f - (rand() % 100) * 0.01f; c.y = -2.0f - (rand() % 100) * 0.01f; c.z = 5; c.w = 0; }
-    CK(hipMemcpy(cells, h.data(), h.size() * 16, hipMemcpyHostToDevice));
+    std::vector<LogPair<float>> h(N * Dp * Up);
+    for (auto& c : h) { c.x = -1.0f - (rand() % 100) * 0.01f; c.y = -2.0f - (rand() % 100) * 0.01f; }
+    CK(hipMemcpy(cells, h.data(), h.size() * 8, hipMemcpyHostToDevice));
     std::vector<int> hx(N, T), hy(N, U - 1);
     CK(hipMemcpy(xlen, hx.data(), N * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(ylen, hy.data(), N * 4, hipMemcpyHostToDevice));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     auto launch = [&] {
-        if (W == 1) hipLaunchKernelGGL((lattice_kernel<float, 1>), dim3(N * 2), dim3(64), 0, 0, cells, beta, offa, offb, llf, llb, costs, xlen, ylen, T, U, Up, 2);
-        else if (W <= 8) hipLaunchKernelGGL((lattice_kernel<float, 8>), dim3(N * 2), dim3(Up), 0, 0, cells, beta, offa, offb, llf, llb, costs, xlen, ylen, T, U, Up, 2);
-        else hipLaunchKernelGGL((lattice_kernel<float, 16>), dim3(N * 2), dim3(Up), 0, 0, cells, beta, offa, offb, llf, llb, costs, xlen, ylen, T, U, Up, 2);
+        if (W == 1) hipLaunchKernelGGL((lattice_kernel<float, 1>), dim3(N * 2), dim3(64), 0, 0, cells, alpha, beta, offa, offb, llf, llb, costs, xlen, ylen, T, U, Up, 2);
+        else if (W <= 8) hipLaunchKernelGGL((lattice_kernel<float, 8>), dim3(N * 2), dim3(Up), 0, 0, cells, alpha, beta, offa, offb, llf, llb, costs, xlen, ylen, T, U, Up, 2);
+        else hipLaunchKernelGGL((lattice_kernel<float, 16>), dim3(N * 2), dim3(Up), 0, 0, cells, alpha, beta, offa, offb, llf, llb, costs, xlen, ylen, T, U, Up, 2);
     };
     for (int i = 0; i < 3; ++i) launch();
     CK(hipDeviceSynchronize());

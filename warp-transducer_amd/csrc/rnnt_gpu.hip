@@ -25,7 +25,7 @@ constexpr size_t kAlign = 256;
 static inline size_t align_up(size_t x) { return (x + kAlign - 1) / kAlign * kAlign; }
 
 struct Layout {
-    size_t cells, rowtab, beta, offa, offb, llf, llb, costs, total;
+    size_t lp2, logz, alpha, rowtab, beta, offa, offb, llf, llb, costs, total;
 };
 
 // lat = bytes of one lattice value (4: fp32 lattice for 16/32-bit activations, 8: fp64).
@@ -36,7 +36,9 @@ static Layout make_layout(int maxT, int maxU, int N, size_t lat) {
     const size_t sk = D * Up * N;               // skewed lattice cells
     Layout l{};
     size_t o = 0;
-    l.cells = o; o = align_up(o + sk * 4 * lat);
+    l.lp2 = o;   o = align_up(o + sk * 2 * lat);
+    l.logz = o;  o = align_up(o + sk * lat);
+    l.alpha = o; o = align_up(o + sk * lat);
     l.rowtab = o; o = align_up(o + static_cast<size_t>(maxT) * maxU * N * 4 * lat);
     l.beta = o;  o = align_up(o + (sk + Up + 64) * lat);
     l.offa = o;  o = align_up(o + D * W * N * sizeof(double));
@@ -128,7 +130,9 @@ static rnntStatus_t run_gpu(const typename Tag::store* acts, typename Tag::store
 
     const Layout lay = make_layout(maxT, maxU, N, sizeof(C));
     char* ws = reinterpret_cast<char*>(align_up(reinterpret_cast<size_t>(workspace)));
-    auto* cells = reinterpret_cast<Cell<C>*>(ws + lay.cells);
+    auto* lp2 = reinterpret_cast<LogPair<C>*>(ws + lay.lp2);
+    auto* logz = reinterpret_cast<C*>(ws + lay.logz);
+    auto* alpha = reinterpret_cast<C*>(ws + lay.alpha);
     auto* rowtab = reinterpret_cast<Cell<C>*>(ws + lay.rowtab);
     auto* beta = reinterpret_cast<C*>(ws + lay.beta);
     auto* offa = reinterpret_cast<double*>(ws + lay.offa);
@@ -168,7 +172,7 @@ static rnntStatus_t run_gpu(const typename Tag::store* acts, typename Tag::store
             tiled = true;
 #define RNNT_TILE(GG)                                                                                   \
     hipLaunchKernelGGL((row_stats_tile_kernel<Tag, GG>), dim3(tgrid), dim3(256), lds, stream, acts, labels, \
-                       input_lengths, label_lengths, cells, Rall, maxT, maxU, Up, A, blank)
+                       input_lengths, label_lengths, lp2, logz, Rall, maxT, maxU, Up, A, blank)
             switch (G) {
                 case 1: RNNT_TILE(1); break;
                 case 2: RNNT_TILE(2); break;
@@ -184,7 +188,7 @@ static rnntStatus_t run_gpu(const typename Tag::store* acts, typename Tag::store
     if (!tiled) {
 #define RNNT_STATS(W, NT)                                                                             \
     hipLaunchKernelGGL((row_stats_kernel<Tag, W, NT>), row_grid(W), dim3(W * 64), 0, stream, acts, labels, \
-                       input_lengths, label_lengths, cells, maxT, maxU, Up, A, blank, vec_ok)
+                       input_lengths, label_lengths, lp2, logz, maxT, maxU, Up, A, blank, vec_ok)
         if (tn.nta) { if (tn.sw == 8) RNNT_STATS(8, true); else if (tn.sw == 2) RNNT_STATS(2, true); else RNNT_STATS(4, true); }
         else { if (tn.sw == 8) RNNT_STATS(8, false); else if (tn.sw == 2) RNNT_STATS(2, false); else RNNT_STATS(4, false); }
 #undef RNNT_STATS
@@ -193,7 +197,7 @@ static rnntStatus_t run_gpu(const typename Tag::store* acts, typename Tag::store
     mark(1);
     const int dirs = training ? 2 : 1;
 #define RNNT_LATTICE(MW)                                                                                  \
-    hipLaunchKernelGGL((lattice_kernel<C, MW>), dim3(N * dirs), dim3(lat_threads), 0, stream, cells, beta, \
+    hipLaunchKernelGGL((lattice_kernel<C, MW>), dim3(N * dirs), dim3(lat_threads), 0, stream, lp2, alpha, beta, \
                        offa, offb, llf, llb, costs_dev, input_lengths, label_lengths, maxT, maxU, Up, dirs)
     if (lat_threads == 64) RNNT_LATTICE(1);
     else if (lat_threads <= 512) RNNT_LATTICE(8);
@@ -202,8 +206,9 @@ static rnntStatus_t run_gpu(const typename Tag::store* acts, typename Tag::store
     RNNT_LAUNCH_CHECK();
     mark(2);
     if (training) {
-        const dim3 cgrid((cells_per_sample + 255) / 256, N);
-        hipLaunchKernelGGL((coef_kernel<C>), cgrid, dim3(256), 0, stream, cells, beta, offa, offb, llf,
+        const long long skew_cells = static_cast<long long>(maxT + maxU - 1) * Up;
+        const dim3 cgrid(static_cast<unsigned>(((skew_cells + 255) / 256 + 7) / 8 * 8), N);   // multiple of 8: XCD-aware remap
+        hipLaunchKernelGGL((coef_kernel<C>), cgrid, dim3(256), 0, stream, lp2, logz, alpha, beta, offa, offb, llf,
                            labels, input_lengths, label_lengths, rowtab, maxT, maxU, Up);
         RNNT_LAUNCH_CHECK();
         mark(3);

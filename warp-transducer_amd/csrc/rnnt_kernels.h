@@ -27,11 +27,14 @@
 
 namespace rnnt {
 
-// One lattice cell record.  Written in two stages:
-//   row_stats : x = log2 p(blank|t,u)   y = log2 p(y_u|t,u)   z = logZ(t,u) (natural)   w = 0
-//   lattice   : w = scaled alpha(t,u) (base 2)
-// The gradient coefficients {c, cb, cl, label} use the same 4-word record type in a separate
+// Skewed lattice arrays (structure of arrays, dense rows of Up values):
+//   lp2   : {x = log2 p(blank|t,u), y = log2 p(y_u|t,u)}   written by the row-stats pass
+//   logz  : natural-log partition function of the row        written by the row-stats pass
+//   alpha : scaled forward variable (base 2)                 written by the lattice kernel
+//   beta  : scaled backward variable (base 2)                written by the lattice kernel
+// The gradient coefficients {c, cb, cl, label} use the 4-word record `Cell` in a separate
 // natural-order row table (coef_kernel).
+template <typename L> struct alignas(2 * sizeof(L)) LogPair { L x, y; };
 template <typename L> struct alignas(4 * sizeof(L)) Cell { L x, y, z, w; };
 
 constexpr double kLog2e = 1.4426950408889634;
@@ -80,7 +83,8 @@ template <typename Tag, int WAVES, bool NT>
 __global__ __launch_bounds__(WAVES * 64) void row_stats_kernel(
         const typename Tag::store* __restrict__ acts, const int* __restrict__ labels,
         const int* __restrict__ xlen, const int* __restrict__ ylen,
-        Cell<typename Tag::comp>* __restrict__ cells, int maxT, int maxU, int Up, int A, int blank, int vec_ok) {
+        LogPair<typename Tag::comp>* __restrict__ lp2, typename Tag::comp* __restrict__ logz,
+        int maxT, int maxU, int Up, int A, int blank, int vec_ok) {
     using S = typename Tag::store;
     using C = typename Tag::comp;
     constexpr int V = Vec<Tag>::N;
@@ -139,12 +143,12 @@ __global__ __launch_bounds__(WAVES * 64) void row_stats_kernel(
     const C logZ = shift + acc_log(S_);
 
     if (lane == 0) {
-        Cell<C> rec;                                   // lattice log-probs are kept in base 2
+        LogPair<C> rec;                                // lattice log-probs are kept in base 2
         rec.x = vmax((xb - logZ) * C(kLog2e), log_zero<C>());
         rec.y = has_lab ? vmax((xl - logZ) * C(kLog2e), log_zero<C>()) : log_zero<C>();
-        rec.z = logZ;
-        rec.w = 0;
-        cells[lat_index(b, t + u, u, maxT, maxU, Up)] = rec;
+        const size_t idx = lat_index(b, t + u, u, maxT, maxU, Up);
+        lp2[idx] = rec;
+        logz[idx] = logZ;
     }
 }
 
@@ -162,8 +166,8 @@ template <typename Tag, int G>
 __global__ __launch_bounds__(256) void row_stats_tile_kernel(
         const typename Tag::store* __restrict__ acts, const int* __restrict__ labels,
         const int* __restrict__ xlen, const int* __restrict__ ylen,
-        Cell<typename Tag::comp>* __restrict__ cells, unsigned long long R, int maxT, int maxU, int Up,
-        int A, int blank) {
+        LogPair<typename Tag::comp>* __restrict__ lp2, typename Tag::comp* __restrict__ logz,
+        unsigned long long R, int maxT, int maxU, int Up, int A, int blank) {
     using S = typename Tag::store;
     using C = typename Tag::comp;
     constexpr int V = Vec<Tag>::N;
@@ -255,12 +259,12 @@ __global__ __launch_bounds__(256) void row_stats_tile_kernel(
                 lab = labels[static_cast<size_t>(b) * (maxU - 1) + u];
                 lab = lab < 0 ? 0 : (lab >= A ? A - 1 : lab);
             }
-            Cell<C> rec;                               // lattice log-probs are kept in base 2
+            LogPair<C> rec;                            // lattice log-probs are kept in base 2
             rec.x = vmax((load1<Tag>(rowp + blank) - logZ) * C(kLog2e), log_zero<C>());
             rec.y = has_lab ? vmax((load1<Tag>(rowp + lab) - logZ) * C(kLog2e), log_zero<C>()) : log_zero<C>();
-            rec.z = logZ;
-            rec.w = 0;
-            cells[lat_index(b, t + u, u, maxT, maxU, Up)] = rec;
+            const size_t idx = lat_index(b, t + u, u, maxT, maxU, Up);
+            lp2[idx] = rec;
+            logz[idx] = logZ;
         }
     }
 }
@@ -341,10 +345,10 @@ template <> struct LatIO<double> {
 
 template <typename L, int MAXW>
 __global__ __launch_bounds__(MAXW * 64) void lattice_kernel(
-        Cell<L>* __restrict__ cells, L* __restrict__ beta, double* __restrict__ offa,
-        double* __restrict__ offb, double* __restrict__ ll_fwd, double* __restrict__ ll_bwd,
-        L* __restrict__ costs_dev, const int* __restrict__ xlen, const int* __restrict__ ylen,
-        int maxT, int maxU, int Up, int dirs) {
+        const LogPair<L>* __restrict__ lp2, L* __restrict__ alpha, L* __restrict__ beta,
+        double* __restrict__ offa, double* __restrict__ offb, double* __restrict__ ll_fwd,
+        double* __restrict__ ll_bwd, L* __restrict__ costs_dev, const int* __restrict__ xlen,
+        const int* __restrict__ ylen, int maxT, int maxU, int Up, int dirs) {
     constexpr int C = LatChunk<L, MAXW>::C;
     constexpr bool MULTI = MAXW > 1;
     using IO = LatIO<L>;
@@ -361,15 +365,14 @@ __global__ __launch_bounds__(MAXW * 64) void lattice_kernel(
     const size_t Dp = lat_rows(maxT, maxU);
     // descriptors start at the first PAD row of this sample: row n lives at (n + kLatPad)
     const size_t sample0 = static_cast<size_t>(b) * Dp * Up;
-    const int cell_row = Up * static_cast<int>(sizeof(Cell<L>));      // bytes per row of `cells`
-    const int beta_row = Up * static_cast<int>(sizeof(L));            // bytes per row of `beta`
+    const int cell_row = Up * static_cast<int>(sizeof(LogPair<L>));   // bytes per row of `lp2`
+    const int beta_row = Up * static_cast<int>(sizeof(L));            // bytes per row of `alpha` / `beta`
     const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(
-        cells + sample0, 0, static_cast<int>(Dp * cell_row), 0x00020000);
+        const_cast<LogPair<L>*>(lp2) + sample0, 0, static_cast<int>(Dp * cell_row), 0x00020000);
     const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(
-        beta + sample0, 0, static_cast<int>(Dp * beta_row), 0x00020000);
-    const int vc = u * static_cast<int>(sizeof(Cell<L>));             // lane offset of cell (.,u)
-    const int vw = vc + 3 * static_cast<int>(sizeof(L));              // ... of its .w field
-    const int vb = u * static_cast<int>(sizeof(L));
+        (dir == 0 ? alpha : beta) + sample0, 0, static_cast<int>(Dp * beta_row), 0x00020000);
+    const int vc = u * static_cast<int>(sizeof(LogPair<L>));          // lane offset of column u in an lp2 row
+    const int vb = u * static_cast<int>(sizeof(L));                   // ... in an alpha / beta row
     double* off = (dir == 0 ? offa : offb) + (static_cast<size_t>(b) * W + wave) * Dp + kLatPad;
     const L NEG = log_zero<L>();
     const unsigned Tb_eff = (u < Ub) ? static_cast<unsigned>(Tb) : 0u;   // cell (n-u,u) in the lattice <=> (unsigned)(n-u) < Tb_eff
@@ -384,7 +387,7 @@ __global__ __launch_bounds__(MAXW * 64) void lattice_kernel(
     if (dir == 0) {
         // ------------------------------- alpha -------------------------------
         L a = (u == 0) ? L(0) : NEG;
-        if (u == 0) IO::store(rc, vw, kLatPad * cell_row, L(0));
+        if (u == 0) IO::store(rb, vb, kLatPad * beta_row, L(0));
         if (lane == 0) off[0] = 0.0;
         auto fetch = [&](int j, L* xb, L* xl) {     // chunk j: diagonals j*C+1 .. j*C+C read SOURCE rows j*C .. j*C+C-1
             if (RNNT_LAT_ABLATE & 2) { for (int k = 0; k < C; ++k) { xb[k] = L(-1.5); xl[k] = L(-2.5); } return; }
@@ -394,7 +397,7 @@ __global__ __launch_bounds__(MAXW * 64) void lattice_kernel(
         auto flush = [&]() {                        // results of chunk jprev (issued BEFORE the next prefetch)
             if (RNNT_LAT_ABLATE & 1) return;
 #pragma unroll
-            for (int k = 0; k < C; ++k) IO::store(rc, vw, (jprev * C + 1 + k + kLatPad) * cell_row, hist[k]);
+            for (int k = 0; k < C; ++k) IO::store(rb, vb, (jprev * C + 1 + k + kLatPad) * beta_row, hist[k]);
             if (lane < C) off[jprev * C + 1 + lane] = Cused;
         };
         auto chunk = [&](int s, int j, const L* pb, const L* pl, L* nb, L* nl) {
@@ -456,7 +459,7 @@ __global__ __launch_bounds__(MAXW * 64) void lattice_kernel(
         if (u == Ub - 1) {
             // alpha(T-1,U-1) of this column: read it back (same thread wrote it), with the offset
             // that was current when its diagonal was stored
-            const L a_last = (nsteps == 0) ? L(0) : IO::load(rc, vw, (Db - 1 + kLatPad) * cell_row);
+            const L a_last = (nsteps == 0) ? L(0) : IO::load(rb, vb, (Db - 1 + kLatPad) * beta_row);
             const double o_last = (nsteps == 0) ? 0.0 : Cused;   // the last chunk is never re-centred
             L xl_, xb_;
             IO::load_xy(rc, vc, (Db - 1 + kLatPad) * cell_row, xb_, xl_);
@@ -547,7 +550,7 @@ __global__ __launch_bounds__(MAXW * 64) void lattice_kernel(
 
 // ------------------------------------------------------------------------------------------
 // Gradient coefficients, one record per (b,t,u) ROW in natural row order r = (b*maxT + t)*maxU + u
-// (the order the gradient pass streams the big tensor in).  grid = (ceil(maxT*maxU/256), N).
+// (the order the gradient pass streams the big tensor in).  grid = (8*ceil(D*Up/2048), N), block 256.
 //   x = c  = alpha + beta - ll - logZ                   (g_v = exp(x_v + c) for every v)
 //   y = cb = exp(alpha + lp_blank + beta(t+1,u) - ll)    (t < T-1)
 //          = exp(alpha + lp_blank - ll)                  (t = T-1, u = U-1)
@@ -559,25 +562,42 @@ constexpr int kPadded = -2;
 
 template <typename L>
 __global__ __launch_bounds__(256) void coef_kernel(
-        const Cell<L>* __restrict__ cells, const L* __restrict__ beta, const double* __restrict__ offa,
+        const LogPair<L>* __restrict__ lp2, const L* __restrict__ logz, const L* __restrict__ alpha_arr,
+        const L* __restrict__ beta, const double* __restrict__ offa,
         const double* __restrict__ offb, const double* __restrict__ ll_fwd,
         const int* __restrict__ labels, const int* __restrict__ xlen, const int* __restrict__ ylen,
         Cell<L>* __restrict__ rowtab, int maxT, int maxU, int Up) {
+    // Threads run over the SKEWED index space (diagonal n, column u): a wavefront covers 64
+    // consecutive columns of one diagonal, so every read of the lattice arrays is one coalesced
+    // row segment and the per-diagonal offsets are wave-uniform; the only scattered access is the
+    // single 16-byte store of the record into the natural-order row table.
+    // XCD-aware block order (workgroup i runs on XCD i % 8, each XCD has its own L2): blocks are
+    // remapped so that every XCD owns one contiguous range of diagonals and the partial lines of
+    // the row table are combined in ONE L2.  gridDim.x is a multiple of 8.  Speed only.
     const int b = blockIdx.y;
-    const int q = blockIdx.x * 256 + threadIdx.x;
-    if (q >= maxT * maxU) return;
-    const int t = q / maxU, u = q - t * maxU;
+    const unsigned per = gridDim.x >> 3;
+    const unsigned blk = (blockIdx.x & 7u) * per + (blockIdx.x >> 3);
+    const int D = maxT + maxU - 1;
+    const long long i0 = (static_cast<long long>(blk) * 4 + (threadIdx.x >> 6)) * 64;   // this wavefront's first cell
+    if (i0 >= static_cast<long long>(D) * Up) return;
+    const int n = uniform(static_cast<int>(i0 / Up));
+    const int u = static_cast<int>(i0 - static_cast<long long>(n) * Up) + (threadIdx.x & 63);
+    const int t = n - u;
+    if (u >= maxU || t < 0 || t >= maxT) return;              // not a row of the tensor
     const int Tb = xlen[b], Ub = ylen[b] + 1;
     Cell<L> o;
     o.x = 0; o.y = 0; o.z = 0; o.w = static_cast<L>(kPadded);
     if (t < Tb && u < Ub) {
         const size_t Dp = lat_rows(maxT, maxU);
-        const int n = t + u;
         const int W = Up >> 6;
         const size_t idx = lat_index(b, n, u, maxT, maxU, Up);
-        const Cell<L> r = cells[idx];
+        Cell<L> r;
+        {
+            const LogPair<L> p = lp2[idx];
+            r.x = p.x; r.y = p.y; r.z = logz[idx]; r.w = alpha_arr[idx];
+        }
         const L* bp = beta + idx;
-        // offsets are per wavefront of the lattice block: cell (.,u) belongs to wave u/64
+        // offsets are per wavefront of the lattice block: column u belongs to wave u/64
         const double* oa = offa + (static_cast<size_t>(b) * W + (u >> 6)) * Dp + kLatPad;
         const double* ob = offb + (static_cast<size_t>(b) * W + (u >> 6)) * Dp + kLatPad;
         const double* ob_r = offb + (static_cast<size_t>(b) * W + ((u + 1) >> 6)) * Dp + kLatPad;   // column u+1
@@ -596,7 +616,7 @@ __global__ __launch_bounds__(256) void coef_kernel(
         }
         o.w = static_cast<L>(lab);
     }
-    rowtab[static_cast<size_t>(b) * maxT * maxU + q] = o;
+    rowtab[(static_cast<size_t>(b) * maxT + t) * maxU + u] = o;
 }
 
 // ------------------------------------------------------------------------------------------

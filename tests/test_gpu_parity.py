@@ -192,9 +192,14 @@ def test_async_entry_and_fused_grad_scale(oracle):
     assert np.abs(grads.cpu().numpy() - ref_g).max() < 3e-4
 
 
-def test_pytorch_binding_on_gpu():
-    """pytorch_binding/test/test.py on the device: CPU and GPU must give identical grads."""
+@pytest.mark.parametrize("async_entry", [True, False])
+def test_pytorch_binding_on_gpu(monkeypatch, async_entry):
+    """pytorch_binding/test/test.py on the device: CPU and GPU must give identical grads.  Both
+    routes of the wrapper: the asynchronous entry (device costs) and the reference's host-costs
+    entry compute_rnnt_loss."""
+    import warprnnt_pytorch
     from warprnnt_pytorch import RNNTLoss
+    monkeypatch.setattr(warprnnt_pytorch, "_ASYNC_GPU", async_entry)
     dev = torch.device("cuda:0")
     for acts_np, labels, cost, grads_ref in ((G.SMALL_ACTS, [[1, 2]], G.SMALL_COST, G.SMALL_GRADS),
                                              (G.BIG_ACTS, [[1, 2], [1, 1]], sum(G.OPTIONS_COSTS), G.BIG_GRADS)):

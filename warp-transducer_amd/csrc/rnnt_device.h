@@ -95,6 +95,23 @@ template <> __device__ __forceinline__ void unpack<F16>(const uint4& r, float* v
     }
 }
 
+// 8-byte half packet -> Vec<Tag>::N / 2 compute values (fp64: one value).
+template <typename Tag> __device__ __forceinline__ void unpack_half(const uint2& raw, typename Tag::comp* v);
+template <> __device__ __forceinline__ void unpack_half<F32>(const uint2& r, float* v) {
+    v[0] = __uint_as_float(r.x); v[1] = __uint_as_float(r.y);
+}
+template <> __device__ __forceinline__ void unpack_half<F64>(const uint2& r, double* v) {
+    v[0] = __hiloint2double(static_cast<int>(r.y), static_cast<int>(r.x));
+}
+template <> __device__ __forceinline__ void unpack_half<BF16>(const uint2& r, float* v) {
+    v[0] = __uint_as_float(r.x << 16); v[1] = __uint_as_float(r.x & 0xffff0000u);
+    v[2] = __uint_as_float(r.y << 16); v[3] = __uint_as_float(r.y & 0xffff0000u);
+}
+template <> __device__ __forceinline__ void unpack_half<F16>(const uint2& r, float* v) {
+    v[0] = f16_to_f32(static_cast<uint16_t>(r.x & 0xffffu)); v[1] = f16_to_f32(static_cast<uint16_t>(r.x >> 16));
+    v[2] = f16_to_f32(static_cast<uint16_t>(r.y & 0xffffu)); v[3] = f16_to_f32(static_cast<uint16_t>(r.y >> 16));
+}
+
 template <typename Tag> __device__ __forceinline__ uint4 pack(const typename Tag::comp* v);
 template <> __device__ __forceinline__ uint4 pack<F32>(const float* v) {
     return make_uint4(__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]),

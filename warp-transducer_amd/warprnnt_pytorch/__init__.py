@@ -15,6 +15,11 @@ from . import warp_rnnt
 
 __all__ = ['rnnt_loss', 'RNNTLoss']
 
+# GPU tensors go through compute_rnnt_loss_async (device costs, no sync) unless
+# WARPRNNT_SYNC_API=1 asks for the reference's host-costs entry point compute_rnnt_loss.
+import os as _os
+_ASYNC_GPU = _os.environ.get("WARPRNNT_SYNC_API", "0") != "1"
+
 
 class _RNNT(Function):
     @staticmethod
@@ -29,14 +34,22 @@ class _RNNT(Function):
         is_cuda = acts.is_cuda
         certify_inputs(acts, labels, act_lens, label_lens)
 
-        loss_func = warp_rnnt.gpu_rnnt if is_cuda else warp_rnnt.cpu_rnnt
         # The library overwrites every element of grads (zeros in the padded region), so no
         # zero-fill is needed (the reference allocates zeros_like: __init__.py:24).
         grads = torch.empty_like(acts) if acts.requires_grad else torch.zeros(0).to(acts)
         minibatch_size = acts.size(0)
         cost_dtype = acts.dtype if acts.dtype in (torch.float32, torch.float64) else torch.float32
-        costs = torch.zeros(minibatch_size, dtype=cost_dtype)   # host, as the C-ABI requires
-        loss_func(acts, labels, act_lens, label_lens, costs, grads, blank, 0)
+        if is_cuda and _ASYNC_GPU:
+            # The reference copies the costs to the host inside the library and back to the device
+            # here (__init__.py:26,42).  The asynchronous entry leaves them on the device: same
+            # result, no D2H/H2D round trip and no stream synchronisation in the training step.
+            costs = torch.empty(minibatch_size, dtype=cost_dtype, device=acts.device)
+            ws = warp_rnnt.gpu_rnnt_async(acts, labels, act_lens, label_lens, costs, grads, blank)
+            ws.record_stream(torch.cuda.current_stream(acts.device))
+        else:
+            loss_func = warp_rnnt.gpu_rnnt if is_cuda else warp_rnnt.cpu_rnnt
+            costs = torch.zeros(minibatch_size, dtype=cost_dtype)   # host, as the C-ABI requires
+            loss_func(acts, labels, act_lens, label_lens, costs, grads, blank, 0)
 
         if reduction in ['sum', 'mean']:
             costs = costs.sum().unsqueeze_(-1)

@@ -14,6 +14,8 @@ def run_gpu(acts_np, labels, act_lens, label_lens, blank=0, dtype=torch.float32,
     lab = torch.tensor(np.asarray(labels, dtype=np.int32), device=dev)
     if lab.dim() == 1:
         lab = lab.view(x.shape[0], -1)
+    if lab.numel() == 0:      # maxU == 1: no labels exist, but the C-ABI rejects a NULL pointer (as the reference)
+        lab = torch.zeros(1, dtype=torch.int32, device=dev)
     tl = torch.tensor(np.asarray(act_lens, dtype=np.int32), device=dev)
     ll = torch.tensor(np.asarray(label_lens, dtype=np.int32), device=dev)
     cost_dtype = dtype if dtype in (torch.float32, torch.float64) else torch.float32
@@ -269,3 +271,69 @@ def test_full_size_properties(oracle, name):
     got_g = grads[pick].double().cpu().numpy()
     assert np.abs(got_c - ref_c).max() <= 1e-4 * np.abs(ref_c).max()               # loss: 1e-4 relative
     assert np.abs(got_g - ref_g).max() < (1e-3 if dtype == torch.float32 else 4e-3)  # grads: 1e-3 (north_star)
+
+
+# ----------------------------------------------------------------------------------------------
+# structural boundaries of the kernels: wavefront edges (U = 63/64/65/128/129/200), chunk edges
+# of the lattice sweep (T+U around multiples of 16), one-cell lattices, tile / row kernel switch
+# (row bytes around 2 KB), packet straddling (A odd, A < packet), blank at either end
+BOUNDARY_SHAPES = [
+    (1, 1, 1, 1), (1, 1, 1, 7), (2, 1, 5, 9), (2, 6, 1, 9), (1, 2, 2, 2), (3, 16, 2, 3), (3, 17, 2, 4),
+    (2, 15, 3, 31), (2, 31, 3, 33), (2, 33, 16, 8), (2, 5, 63, 6), (2, 5, 64, 6), (2, 5, 65, 6),
+    (1, 40, 128, 5), (1, 40, 129, 5), (1, 9, 200, 4), (1, 300, 66, 3), (2, 48, 17, 511), (2, 12, 9, 512),
+    (2, 12, 9, 513), (1, 7, 5, 2049), (3, 20, 33, 1), (2, 130, 70, 2),
+]
+
+
+@pytest.mark.parametrize("shape", BOUNDARY_SHAPES)
+def test_boundary_shapes(oracle, shape):
+    N, T, U, A = shape
+    rng = np.random.default_rng(7 * N + 13 * T + 17 * U + 19 * A)
+    acts = rng.standard_normal(shape) * 1.5
+    blank = int(rng.integers(0, A))
+    labels = rng.integers(0, A, size=(N, max(U - 1, 1)))[:, :U - 1]
+    if A > 1:
+        labels[labels == blank] = (blank + 1) % A
+    tl = rng.integers(1, T + 1, size=N); tl[0] = T
+    ll = rng.integers(0, U, size=N); ll[-1] = U - 1
+    if N == 1:
+        tl[0], ll[0] = T, U - 1
+    if A == 1 and U > 1:          # only the blank exists: labels must equal it; the GPU contract
+        labels[:] = 0             # subtracts both corrections, so compare the loss only
+    labels = labels.reshape(N, U - 1) if U > 1 else np.zeros((N, 0), dtype=np.int64)
+    a32 = acts.astype(np.float32).astype(np.float64)
+    ref_c, ref_g = oracle.rnnt_logits(a32, labels if U > 1 else np.zeros((N, 1), dtype=np.int32)[:, :0],
+                                      tl, ll, blank)
+    lab_dev = labels if U > 1 else np.zeros((N, 0), dtype=np.int32)
+    costs, grads = run_gpu(a32, lab_dev, tl, ll, blank)
+    assert np.abs(costs - ref_c).max() <= 1e-4 * max(1.0, np.abs(ref_c).max())
+    if not (A == 1 and U > 1):
+        assert np.abs(grads - ref_g).max() < 1e-4
+    for b in range(N):
+        assert not grads[b, tl[b]:].any() and not grads[b, :, ll[b] + 1:].any()
+    c64, g64 = run_gpu(acts, lab_dev, tl, ll, blank, dtype=torch.float64)
+    r64c, r64g = oracle.rnnt_logits(acts, labels if U > 1 else np.zeros((N, 1), dtype=np.int32)[:, :0], tl, ll, blank)
+    assert np.abs(c64 - r64c).max() <= 1e-10 * max(1.0, np.abs(r64c).max())
+    if not (A == 1 and U > 1):
+        assert np.abs(g64 - r64g).max() < 1e-9
+
+
+def test_random_sweep_fp32_and_bf16(oracle):
+    """60 seeded random problems, variable lengths, fp32 and bf16 storage."""
+    rng = np.random.default_rng(2026)
+    for it in range(60):
+        N = int(rng.integers(1, 5)); T = int(rng.integers(1, 70)); U = int(rng.integers(1, 140))
+        A = int(rng.choice([2, 3, 5, 8, 17, 28, 50, 64, 100, 257, 1024]))
+        acts = rng.standard_normal((N, T, U, A)) * float(rng.choice([0.5, 2.0, 6.0]))
+        blank = int(rng.integers(0, A))
+        labels = rng.integers(0, A, size=(N, U - 1))
+        labels[labels == blank] = (blank + 1) % A
+        tl = rng.integers(1, T + 1, size=N); tl[int(rng.integers(0, N))] = T
+        ll = rng.integers(0, U, size=N); ll[int(rng.integers(0, N))] = U - 1
+        dtype = torch.bfloat16 if it % 3 == 2 else torch.float32
+        x = torch.tensor(acts).to(dtype)
+        ref_c, ref_g = oracle.rnnt_logits(x.double().numpy(), labels, tl, ll, blank)
+        costs, grads = run_gpu(x.double().numpy(), labels, tl, ll, blank, dtype=dtype)
+        tol_g = 1e-4 if dtype == torch.float32 else 4e-3
+        assert np.abs(costs - ref_c).max() <= 1e-4 * max(1.0, np.abs(ref_c).max()), (it, N, T, U, A)
+        assert np.abs(grads - ref_g).max() < tol_g, (it, N, T, U, A, str(dtype))

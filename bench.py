@@ -76,7 +76,7 @@ def cpu_baseline(w, acts, labels, act_lens, label_lens, budget_samples):
     reference CPU contract), so log_softmax is not in its time."""
     from oracle import oracle as O
     n = min(w["N"], budget_samples)
-    lp = torch.log_softmax(acts[:n].float(), -1).cpu().numpy()
+    lp = torch.cat([torch.log_softmax(acts[i:i + 16].float(), -1).cpu() for i in range(0, n, 16)]).numpy()
     lab, tl, ll = labels[:n].cpu().numpy(), act_lens[:n].cpu().numpy(), label_lens[:n].cpu().numpy()
     cores = os.cpu_count() or 1
     threads = min(cores, n)
@@ -105,7 +105,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-samples", type=int, default=32)
+    ap.add_argument("--cpu-samples", type=int, default=128)
     ap.add_argument("--extra", action="store_true", help="also time the other single-GPU workloads")
     ap.add_argument("--override", default="", help="dev: override workload fields, e.g. A=4992,N=64")
     ap.add_argument("--force-sharded", action="store_true",

@@ -1,14 +1,20 @@
-// rnnt_kernels.h -- the four gfx950 kernels of the RNN-T loss hot path.
+// rnnt_kernels.h -- the gfx950 kernels of the RNN-T loss hot path (four stages).
 //
-//   row_stats_kernel   one read of the (N,T,U,A) logits: online log-sum-exp per (b,t,u)
-//                      row + gather of the blank / label logits          [HBM-bound, E*s read]
-//   lattice_kernel     alpha and beta recursions over the T x U lattice, one wavefront
-//                      lane per u, sweeping anti-diagonals, values carried in registers,
-//                      neighbour exchange through DPP wave shifts         [latency-bound, O(R)]
-//   coef_kernel        per lattice cell: the three numbers the gradient needs
-//                      (row exponent offset, blank correction, label correction)  [O(R)]
-//   grad_kernel        second read of the logits + dense gradient write-back
-//                      g_v = exp(x_v + c) - [v==blank] cb - [v==label] cl   [HBM-bound, 2*E*s]
+//   1 row_stats_kernel       rows > 2 KB: one wavefront per (b,t,u) row, ONE read of the logits,
+//     row_stats_tile_kernel  rows <= 2 KB: a block stages a contiguous tile of rows in LDS;
+//                            online log-sum-exp per row + gather of the blank / label logits
+//                                                                      [HBM-bound, E*s read]
+//   2 lattice_kernel         alpha and beta recursions over the T x U lattice (concurrently),
+//                            one wavefront lane per u sweeping the anti-diagonals, values in
+//                            registers, neighbour exchange through DPP wave shifts, base-2
+//                            scaled arithmetic                          [issue/latency-bound, O(R)]
+//   3 coef_kernel            per lattice cell: the three numbers the gradient needs (row exponent
+//                            offset, blank correction, label correction) into a natural-order
+//                            row table                                                   [O(R)]
+//   4 grad_flat_kernel       second read of the logits as one flat packet stream + dense gradient
+//                            g_v = exp(x_v + c) - [v==blank] cb - [v==label] cl, zero-fill of the
+//                            padding                              [HBM-bound, 2*E*s read+write]
+//     grad_rows_kernel       the same per row, for tensors that are not 16-byte aligned
 //
 // What they replace in the reference (behaviour, not structure):
 //   include/detail/reduce.h:45-104 + gpu_rnnt.h:73-80   (two-pass max / exp-sum denominators)

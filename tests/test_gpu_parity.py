@@ -337,3 +337,35 @@ def test_random_sweep_fp32_and_bf16(oracle):
         tol_g = 1e-4 if dtype == torch.float32 else 4e-3
         assert np.abs(costs - ref_c).max() <= 1e-4 * max(1.0, np.abs(ref_c).max()), (it, N, T, U, A)
         assert np.abs(grads - ref_g).max() < tol_g, (it, N, T, U, A, str(dtype))
+
+
+@pytest.mark.parametrize("shape", [(2, 3, 1024, 4),      # maxU at the limit: 16 wavefronts, 1024-thread blocks
+                                   (1, 3000, 2, 6),      # very long utterance, 188 chunks
+                                   (2, 3, 2, 100000),    # huge vocabulary: 400 KB rows
+                                   (700, 3, 2, 5),       # many tiny samples
+                                   (3, 40, 700, 3)])     # wide lattice, 11 wavefronts, tiny vocab (packet < row)
+def test_extreme_shapes(oracle, shape):
+    N, T, U, A = shape
+    rng = np.random.default_rng(N + T + U + A)
+    acts = (rng.standard_normal(shape) * 1.5).astype(np.float32)
+    labels = rng.integers(1, A, size=(N, U - 1))
+    tl = rng.integers(max(1, T // 2), T + 1, size=N); tl[0] = T
+    ll = rng.integers((U - 1) // 2, U, size=N); ll[-1] = U - 1
+    ref_c, ref_g = oracle.rnnt_logits(acts.astype(np.float64), labels, tl, ll)
+    costs, grads = run_gpu(acts, labels, tl, ll)
+    assert np.abs(costs - ref_c).max() <= 1e-4 * max(1.0, np.abs(ref_c).max())
+    assert np.abs(grads - ref_g).max() < 2e-4
+    assert np.abs(grads.sum(-1)).max() < 2e-4          # every row of the logit gradient sums to zero
+
+
+def test_limits_are_reported_not_crashed():
+    from warprnnt_pytorch import _lib
+    lib = _lib.lib()
+    dev = torch.device("cuda:0")
+    x = torch.zeros(8, device=dev)
+    i = torch.ones(4, dtype=torch.int32, device=dev)
+    costs = torch.zeros(1)
+    opt = _lib.rnntOptions(loc=1, num_threads=0, stream=None, blank_label=0, maxT=1, maxU=1025, batch_first=True)
+    st = lib.compute_rnnt_loss(x.data_ptr(), None, i.data_ptr(), i.data_ptr(), i.data_ptr(), 2, 1, costs.data_ptr(),
+                               x.data_ptr(), opt)
+    assert st == 2            # maxU > 1024 -> RNNT_STATUS_INVALID_VALUE (documented limit, as the reference)

@@ -108,6 +108,8 @@ def main():
     ap.add_argument("--cpu-samples", type=int, default=128)
     ap.add_argument("--extra", action="store_true", help="also time the other single-GPU workloads")
     ap.add_argument("--override", default="", help="dev: override workload fields, e.g. A=4992,N=64")
+    ap.add_argument("--varlen", action="store_true",
+                    help="robustness run: T_b ~ U[T/2,T], L_b ~ U[L/2,L] (seed 2, maxima forced), SURVEY.md 8d")
     ap.add_argument("--force-sharded", action="store_true",
                     help="dev: run the multi-GPU step (async entry + RCCL all-reduce) even with one rank")
     args = ap.parse_args()
@@ -139,6 +141,11 @@ def main():
             w["published_ms"] = None
         acts, labels, act_lens, label_lens = make_inputs(w, dev, 1234 + rank)
         N, T, U, A = acts.shape
+        if args.varlen:
+            g2 = torch.Generator(device=dev); g2.manual_seed(2)
+            act_lens = torch.randint(T // 2, T + 1, (N,), generator=g2, device=dev, dtype=torch.int32)
+            label_lens = torch.randint((U - 1) // 2, U, (N,), generator=g2, device=dev, dtype=torch.int32)
+            act_lens[0], label_lens[0] = T, U - 1
         grads = torch.empty_like(acts)
         esz = ESIZE[w["dtype"]]
         ws = torch.empty(_lib.workspace_bytes(T, U, N, True, esz), dtype=torch.uint8, device=dev)
@@ -215,8 +222,9 @@ def main():
         "warmup": args.warmup, "ms_per_step": round(ms, 4), "higher_is_better": False,
         "scaling": "weak", "vs_baseline": (round(ms / w["published_ms"], 5) if w["published_ms"] else None),
         "dtype": {"fp32": "f32", "bf16": "bf16"}[w["dtype"]], "data": "synthetic",
-        "config": {"workload": "%s: N=%d/GPU T=%d U=%d(L=%d) A=%d %s, loss+grad via compute_rnnt_loss"
-                               % (args.workload, w["N"], w["T"], U, w["L"], w["A"], w["dtype"]),
+        "config": {"workload": "%s: N=%d/GPU T=%d U=%d(L=%d) A=%d %s, loss+grad via compute_rnnt_loss%s"
+                               % (args.workload, w["N"], w["T"], U, w["L"], w["A"], w["dtype"],
+                                  ", VARIABLE lengths T_b~U[T/2,T] L_b~U[L/2,L]" if args.varlen else ""),
                    "global_batch": w["N"] * world, "per_gpu_batch": w["N"],
                    "parallelism": "batch-sharded x%d, one RCCL all-reduce of the summed loss" % world
                    if world > 1 else "single GPU"},

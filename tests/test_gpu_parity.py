@@ -369,3 +369,49 @@ def test_limits_are_reported_not_crashed():
     st = lib.compute_rnnt_loss(x.data_ptr(), None, i.data_ptr(), i.data_ptr(), i.data_ptr(), 2, 1, costs.data_ptr(),
                                x.data_ptr(), opt)
     assert st == 2            # maxU > 1024 -> RNNT_STATUS_INVALID_VALUE (documented limit, as the reference)
+
+
+def test_async_entry_is_graph_capturable(oracle):
+    """compute_rnnt_loss_async only enqueues on the given stream (no allocation, no sync, no host
+    copy), so it can be captured in a HIP graph and replayed on new inputs."""
+    from warprnnt_pytorch import _lib, warp_rnnt
+    acts, labels, tl, ll, blank = case_inputs("var_a40")
+    dev = torch.device("cuda:0")
+    x = torch.tensor(acts, dtype=torch.float32, device=dev)
+    lab, tlen, llen = (torch.tensor(a, device=dev) for a in (labels, tl, ll))
+    costs = torch.zeros(x.shape[0], device=dev)
+    grads = torch.zeros_like(x)
+    N, T, U, A = x.shape
+    ws = torch.empty(_lib.workspace_bytes(T, U, N, True, 4), dtype=torch.uint8, device=dev)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):                       # warm-up outside capture
+        warp_rnnt.gpu_rnnt_async(x, lab, tlen, llen, costs, grads, blank, workspace=ws)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        warp_rnnt.gpu_rnnt_async(x, lab, tlen, llen, costs, grads, blank, workspace=ws)
+    for scale in (1.0, 0.5):                            # replay on changed inputs
+        x.copy_(torch.tensor(acts * scale, dtype=torch.float32))
+        costs.zero_(); grads.zero_()
+        graph.replay()
+        torch.cuda.synchronize()
+        ref_c, ref_g = oracle.rnnt_logits((acts * scale).astype(np.float32).astype(np.float64), labels, tl, ll, blank)
+        assert np.abs(costs.cpu().numpy() - ref_c).max() <= 1e-4 * np.abs(ref_c).max()
+        assert np.abs(grads.cpu().numpy() - ref_g).max() < 1e-4
+
+
+def test_minus_inf_logits(oracle):
+    """Masked vocabulary entries (-inf logits) that are neither the blank nor a label: probability
+    zero, gradient exactly zero there, everything else as the oracle says."""
+    rng = np.random.default_rng(99)
+    N, T, U, A = 2, 9, 4, 40
+    acts = rng.standard_normal((N, T, U, A)).astype(np.float32)
+    labels = rng.integers(1, 10, size=(N, U - 1))
+    acts[..., 20:30] = -np.inf
+    ref_c, ref_g = oracle.rnnt_logits(acts.astype(np.float64), labels, [T, T], [U - 1, U - 1])
+    costs, grads = run_gpu(acts, labels, [T, T], [U - 1, U - 1])
+    assert np.isfinite(costs).all() and np.abs(costs - ref_c).max() < 1e-4 * np.abs(ref_c).max()
+    assert not np.isnan(grads).any() and not grads[..., 20:30].any()
+    assert np.abs(grads - ref_g).max() < 1e-4

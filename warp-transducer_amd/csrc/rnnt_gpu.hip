@@ -227,13 +227,15 @@ static rnntStatus_t run_gpu(const typename Tag::store* acts, typename Tag::store
             const unsigned long long dq = stride / A;
             const int drem = static_cast<int>(stride % A);
             const float invA = 1.0f / static_cast<float>(A);
-#define RNNT_FLAT(SC, PP)                                                                                  \
-    hipLaunchKernelGGL((grad_flat_kernel<Tag, SC, PP>), dim3(grid), dim3(256), 0, stream, acts, grads, rowtab, \
+#define RNNT_FLAT(SC, PP, PS)                                                                                  \
+    hipLaunchKernelGGL((grad_flat_kernel<Tag, SC, PP, PS>), dim3(grid), dim3(256), 0, stream, acts, grads, rowtab, \
                        grad_scale, E, R, A, blank, cells_per_sample, invA, dq, drem)
-            if (grad_scale) RNNT_FLAT(true, 2);
-            else if (ppt == 1) RNNT_FLAT(false, 1);
-            else if (ppt == 4) RNNT_FLAT(false, 4);
-            else RNNT_FLAT(false, 2);
+            const bool padskip = row_bytes >= 8192;     // skip reading padded rows only where rows are long
+            if (grad_scale) { if (padskip) RNNT_FLAT(true, 2, true); else RNNT_FLAT(true, 2, false); }
+            else if (ppt == 1) RNNT_FLAT(false, 1, false);
+            else if (ppt == 4) RNNT_FLAT(false, 4, false);
+            else if (padskip) RNNT_FLAT(false, 2, true);
+            else RNNT_FLAT(false, 2, false);
 #undef RNNT_FLAT
         } else {
             if (grad_scale)

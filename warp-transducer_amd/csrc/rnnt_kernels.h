@@ -670,7 +670,7 @@ __global__ __launch_bounds__(256) void coef_kernel(
 // here, so no memset of the gradient tensor exists (the reference does one: gpu_rnnt.h:107-110).
 // Measured on MI355X (tools/microbench/stream_variants.hip): this structure sustains
 // 6.4-6.5 TB/s read+write with the exp included, the wavefront-per-row form 5.1 TB/s.
-template <typename Tag, bool SCALED, int PPT>      // PPT = packets per thread and iteration
+template <typename Tag, bool SCALED, int PPT, bool PADSKIP>   // PPT = packets per thread and iteration
 __global__ __launch_bounds__(256) void grad_flat_kernel(
         const typename Tag::store* __restrict__ acts, typename Tag::store* __restrict__ grads,
         const Cell<typename Tag::comp>* __restrict__ rowtab, const typename Tag::comp* __restrict__ grad_scale,
@@ -721,8 +721,22 @@ __global__ __launch_bounds__(256) void grad_flat_kernel(
             v0[k] = rr;
             row[k] = r + q;
             if (live[k]) {
-                raw[k] = load_packet<true>(in + pk0 + p);
                 rec[k] = rowtab[row[k]];
+                if constexpr (!PADSKIP) raw[k] = load_packet<true>(in + pk0 + p);
+            }
+        }
+        if constexpr (PADSKIP) {
+            // Long rows only (host: row >= 8 KB): the record comes first, and a packet that lies
+            // wholly inside a PADDED row is only zero-filled, its logits are never read (with T_b,
+            // U_b spread over [max/2, max] that is ~40 % of the rows: c3 gradient pass 2.58 ->
+            // 2.11 ms).  For short rows the extra dependent latency costs more than it saves
+            // (measured +7 % on 2 KB rows), so they keep the unconditional load above.
+#pragma unroll
+            for (int k = 0; k < PPT; ++k) {
+                const int p = k * 256 + threadIdx.x;
+                const bool skip = (v0[k] + V <= A) && static_cast<int>(rec[k].w) == kPadded;
+                raw[k] = make_uint4(0, 0, 0, 0);
+                if (live[k] && !skip) raw[k] = load_packet<true>(in + pk0 + p);
             }
         }
 #pragma unroll

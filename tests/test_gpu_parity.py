@@ -415,3 +415,35 @@ def test_minus_inf_logits(oracle):
     assert np.isfinite(costs).all() and np.abs(costs - ref_c).max() < 1e-4 * np.abs(ref_c).max()
     assert not np.isnan(grads).any() and not grads[..., 20:30].any()
     assert np.abs(grads - ref_g).max() < 1e-4
+
+
+def test_sharded_wrapper_over_rccl_single_rank():
+    """ShardedRNNTLoss on the GPU with backend "nccl" (= RCCL on ROCm), world_size 1: async entry,
+    device-resident costs, the all-reduce of [sum, count] on the compute stream.  (Two ranks are
+    covered on CPU by tests/test_sharded_gloo.py; a single box has one GPU.)"""
+    import os
+    import torch.distributed as dist
+    from warprnnt_pytorch import RNNTLoss
+    from warprnnt_pytorch.sharded import ShardedRNNTLoss
+    acts, labels, tl, ll, blank = case_inputs("blank5_a19")
+    tl[:] = acts.shape[1]; ll[:] = acts.shape[2] - 1
+    dev = torch.device("cuda:0")
+    created = False
+    if not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29577")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+        created = True
+    try:
+        args = [torch.tensor(a, device=dev) for a in (labels, tl, ll)]
+        for reduction in ("mean", "sum", "none"):
+            x1 = torch.tensor(acts, dtype=torch.float32, device=dev, requires_grad=True)
+            x2 = x1.detach().clone().requires_grad_(True)
+            l1 = ShardedRNNTLoss(blank=blank, reduction=reduction)(x1, *args)
+            l2 = RNNTLoss(blank=blank, reduction=reduction)(x2, *args)
+            l1.sum().backward(); l2.sum().backward()
+            assert l1.is_cuda and torch.allclose(l1, l2, rtol=1e-6, atol=1e-5)
+            assert torch.allclose(x1.grad, x2.grad, rtol=1e-5, atol=1e-6)
+    finally:
+        if created:
+            dist.destroy_process_group()

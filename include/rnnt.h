@@ -176,6 +176,27 @@ rnntStatus_t compute_rnnt_loss_async(const void* activations,
                                      rnntOptions options,
                                      int dtype_code);
 
+/* Additive joint ("add network", the reference's add_network branch: README.md:4,
+ * docs/rnnt_notes.tex:56-59,147-153, pytorch_binding/test/test_time.py:51-77).  The joint logits
+ * are h(k,t,u) = trans_acts[b,t,k] + pred_acts[b,u,k]; the (B,T,U,V) tensor is never formed.
+ * trans_acts (B,maxT,V) and pred_acts (B,maxU,V) are dense fp32 DEVICE tensors; trans_grads /
+ * pred_grads receive dL/d(trans_acts) = sum_u dL/dh and dL/d(pred_acts) = sum_t dL/dh (both NULL:
+ * score only).  Same conventions as compute_rnnt_loss_async: `costs_device` is a DEVICE array of
+ * `minibatch` floats, the call only enqueues on options.stream; size the workspace with
+ * get_workspace_size(maxT, maxU, minibatch, true, &bytes, 4). */
+rnntStatus_t compute_rnnt_loss_add(const float* const trans_acts,
+                                   const float* const pred_acts,
+                                   float* trans_grads,
+                                   float* pred_grads,
+                                   const int* const flat_labels,
+                                   const int* const label_lengths,
+                                   const int* const input_lengths,
+                                   int alphabet_size,
+                                   int minibatch,
+                                   float* costs_device,
+                                   void* workspace,
+                                   rnntOptions options);
+
 /* Stage timing for benchmarks.  rnnt_profile_enable(1) makes every following
  * GPU call record HIP events around its kernels on options.stream (no extra
  * synchronisation); rnnt_profile_read() fills `ms` with the accumulated

@@ -1,0 +1,107 @@
+"""-m gpu: the additive-joint entry (compute_rnnt_loss_add) against the CPU
+oracle run on the MATERIALISED joint  z[b,t,u,:] = f[b,t,:] + g[b,u,:]  -- costs, and
+df = sum_u dz, dg = sum_t dz (docs/rnnt_notes.tex:147-153) -- and against this library's own
+materialised path."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+SHAPES = [  # N, T, U, A
+    (2, 7, 4, 5), (3, 20, 9, 40), (2, 33, 21, 257), (1, 50, 130, 12), (2, 9, 300, 7), (1, 70, 3, 1000),
+    (2, 40, 16, 64), (1, 1, 1, 9), (2, 5, 1, 33), (2, 1, 6, 31), (3, 65, 33, 100),
+]
+
+
+def problem(shape, seed):
+    N, T, U, A = shape
+    rng = np.random.default_rng(seed)
+    f = (rng.standard_normal((N, T, A)) * 1.5).astype(np.float32)
+    g = (rng.standard_normal((N, U, A)) * 1.5).astype(np.float32)
+    blank = int(rng.integers(0, A))
+    labels = rng.integers(0, A, size=(N, U - 1))
+    labels[labels == blank] = (blank + 1) % A
+    tl = rng.integers(1, T + 1, size=N); tl[0] = T
+    ll = rng.integers(0, U, size=N); ll[-1] = U - 1
+    if N == 1:
+        tl[0], ll[0] = T, U - 1
+    return f, g, labels.astype(np.int32), tl.astype(np.int32), ll.astype(np.int32), blank
+
+
+def run_add(f, g, labels, tl, ll, blank, reduction="none"):
+    from warprnnt_pytorch.add_network import RNNTLossAdd
+    dev = torch.device("cuda:0")
+    tf = torch.tensor(f, device=dev, requires_grad=True)
+    tg = torch.tensor(g, device=dev, requires_grad=True)
+    lab = torch.tensor(labels, device=dev) if labels.size else torch.zeros((f.shape[0], 0), dtype=torch.int32, device=dev)
+    loss = RNNTLossAdd(blank=blank, reduction=reduction)(tf, tg, lab, torch.tensor(tl, device=dev),
+                                                        torch.tensor(ll, device=dev))
+    loss.sum().backward()
+    return loss.detach().cpu().numpy().astype(np.float64), tf.grad.cpu().numpy(), tg.grad.cpu().numpy()
+
+
+@pytest.mark.parametrize("shape", SHAPES)
+def test_against_oracle_on_materialised_joint(oracle, shape):
+    f, g, labels, tl, ll, blank = problem(shape, sum(shape))
+    z = f[:, :, None, :].astype(np.float64) + g[:, None, :, :].astype(np.float64)
+    lab = labels if labels.size else np.zeros((shape[0], 1), dtype=np.int32)[:, :0]
+    ref_c, ref_gz = oracle.rnnt_logits(z, lab, tl, ll, blank)
+    costs, df, dg = run_add(f, g, labels, tl, ll, blank)
+    assert np.abs(costs - ref_c).max() <= 1e-4 * max(1.0, np.abs(ref_c).max())
+    # df sums U per-cell gradients, dg sums T of them: the per-element bound of the materialised
+    # path (1e-4 .. 1e-3, north_star) accumulates, so the absolute tolerance scales with the count
+    # (the blank column of dg reaches -T: fp32 accumulation adds a relative 5e-5; summing the
+    # MATERIALISED GPU path's gradients over t shows the same error)
+    N, T, U, A = shape
+    rdf, rdg = ref_gz.sum(axis=2), ref_gz.sum(axis=1)
+    assert (np.abs(df - rdf) <= 2e-4 * max(1.0, U / 32) + 5e-5 * np.abs(rdf)).all()
+    assert (np.abs(dg - rdg) <= 2e-4 * max(1.0, T / 32) + 5e-5 * np.abs(rdg)).all()
+    for b in range(shape[0]):                      # padded time steps / label positions get zero gradient
+        assert not df[b, tl[b]:].any() and not dg[b, ll[b] + 1:].any()
+
+
+def test_equals_materialised_gpu_path():
+    from warprnnt_pytorch import RNNTLoss
+    f, g, labels, tl, ll, blank = problem((4, 30, 12, 300), 5)
+    dev = torch.device("cuda:0")
+    tf = torch.tensor(f, device=dev, requires_grad=True)
+    tg = torch.tensor(g, device=dev, requires_grad=True)
+    args = [torch.tensor(a, device=dev) for a in (labels, tl, ll)]
+    joint = tf.unsqueeze(2) + tg.unsqueeze(1)
+    ref = RNNTLoss(blank=blank, reduction="mean")(joint.contiguous(), *args)
+    ref.sum().backward()
+    costs, df, dg = run_add(f, g, labels, tl, ll, blank, reduction="mean")
+    assert np.allclose(costs, ref.item(), rtol=1e-5)
+    assert np.allclose(df, tf.grad.cpu().numpy(), rtol=2e-4, atol=2e-5)
+    assert np.allclose(dg, tg.grad.cpu().numpy(), rtol=2e-4, atol=5e-5)
+
+
+def test_large_logit_range_is_safe(oracle):
+    """Online log-sum-exp: rows whose best f column and best g column differ by 100+ nats."""
+    f, g, labels, tl, ll, blank = problem((1, 6, 4, 50), 77)
+    f[..., 3] += 120.0
+    g[..., 40] += 150.0
+    z = f[:, :, None, :].astype(np.float64) + g[:, None, :, :].astype(np.float64)
+    ref_c, ref_gz = oracle.rnnt_logits(z, labels, tl, ll, blank)
+    costs, df, dg = run_add(f, g, labels, tl, ll, blank)
+    assert np.isfinite(costs).all() and np.abs(costs - ref_c).max() <= 2e-4 * np.abs(ref_c).max()
+    assert np.allclose(df, ref_gz.sum(axis=2), rtol=1e-4, atol=5e-4)
+    assert np.allclose(dg, ref_gz.sum(axis=1), rtol=1e-4, atol=5e-4)
+
+
+def test_validation_errors():
+    from warprnnt_pytorch.add_network import rnnt_loss_add
+    dev = torch.device("cuda:0")
+    f, g = torch.zeros(2, 4, 5, device=dev), torch.zeros(2, 3, 5, device=dev)
+    lab = torch.ones(2, 2, dtype=torch.int32, device=dev)
+    tl, ll = torch.tensor([4, 4], dtype=torch.int32, device=dev), torch.tensor([2, 2], dtype=torch.int32, device=dev)
+    rnnt_loss_add(f, g, lab, tl, ll)
+    with pytest.raises(ValueError):
+        rnnt_loss_add(f, torch.zeros(2, 3, 6, device=dev), lab, tl, ll)
+    with pytest.raises(TypeError):
+        rnnt_loss_add(f.double(), g.double(), lab, tl, ll)
+    with pytest.raises(ValueError):
+        rnnt_loss_add(f.cpu(), g.cpu(), lab.cpu(), tl.cpu(), ll.cpu())
+    with pytest.raises(ValueError):
+        rnnt_loss_add(f, g, lab, torch.tensor([3, 3], dtype=torch.int32, device=dev), ll)

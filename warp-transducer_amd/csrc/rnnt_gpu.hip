@@ -16,6 +16,7 @@
 
 #include "../../include/rnnt.h"
 #include "rnnt_cpu.h"
+#include "rnnt_joint_kernels.h"
 #include "rnnt_kernels.h"
 
 namespace rnnt {
@@ -262,6 +263,85 @@ static rnntStatus_t run_gpu(const typename Tag::store* acts, typename Tag::store
     return RNNT_STATUS_SUCCESS;
 }
 
+// ----------------------------------------------------------------------------- additive joint
+// f (N,maxT,A) + g (N,maxU,A) -> costs, df, dg without the (N,T,U,A) tensor (rnnt_joint_kernels.h).
+// Enqueue only: device costs, no host copy, no synchronisation.  fp32.
+static rnntStatus_t run_gpu_joint(const float* f, const float* g, float* df, float* dg, const int* labels,
+                                  const int* label_lengths, const int* input_lengths, int A, int N,
+                                  float* costs_device, void* workspace, const rnntOptions& opt) {
+    using C = float;
+    const int maxT = opt.maxT, maxU = opt.maxU, blank = opt.blank_label;
+    if (blank < 0 || blank >= A) return RNNT_STATUS_INVALID_VALUE;
+    if (maxU > 1024 || N > 65535) return RNNT_STATUS_INVALID_VALUE;
+    if (static_cast<long long>(maxT) * maxU > 0x7fffffffLL / 4) return RNNT_STATUS_INVALID_VALUE;
+    if ((df == nullptr) != (dg == nullptr)) return RNNT_STATUS_INVALID_VALUE;
+    hipStream_t stream = reinterpret_cast<hipStream_t>(opt.stream);
+    const bool training = df != nullptr;
+
+    const Layout lay = make_layout(maxT, maxU, N, sizeof(C));
+    char* ws = reinterpret_cast<char*>(align_up(reinterpret_cast<size_t>(workspace)));
+    auto* lp2 = reinterpret_cast<LogPair<C>*>(ws + lay.lp2);
+    auto* logz = reinterpret_cast<C*>(ws + lay.logz);
+    auto* alpha = reinterpret_cast<C*>(ws + lay.alpha);
+    auto* rowtab = reinterpret_cast<Cell<C>*>(ws + lay.rowtab);
+    auto* beta = reinterpret_cast<C*>(ws + lay.beta);
+    auto* offa = reinterpret_cast<double*>(ws + lay.offa);
+    auto* offb = reinterpret_cast<double*>(ws + lay.offb);
+    auto* llf = reinterpret_cast<double*>(ws + lay.llf);
+    auto* llb = reinterpret_cast<double*>(ws + lay.llb);
+
+    const bool prof = prof_prepare();
+    auto mark = [&](int i) { if (prof) (void)hipEventRecord(g_prof.ev[i], stream); };
+    const int Up = ((maxU + 63) / 64) * 64;
+    const int cells_per_sample = maxT * maxU;
+    bool failed = false;
+    auto check = [&]() { if (hipGetLastError() != hipSuccess) failed = true; };
+
+    mark(0);
+    if (training &&
+        hipMemsetAsync(dg, 0, sizeof(float) * static_cast<size_t>(N) * maxU * A, stream) != hipSuccess)
+        return RNNT_STATUS_MEMOPS_FAILED;            // dg is accumulated with atomics
+    {
+        const int per_row = maxU > 128 ? 1 : 0;
+        const int nT = per_row ? 1 : (256 + maxU - 1) / maxU + 1;
+        const int nU = per_row ? (maxU < 256 ? maxU : 256) : maxU;
+        const size_t lds = static_cast<size_t>(nT + nU) * kJointPad * sizeof(float);
+        const unsigned gx = per_row ? static_cast<unsigned>(maxT) * ((maxU + 255) / 256)
+                                    : static_cast<unsigned>((cells_per_sample + 255) / 256);
+        hipLaunchKernelGGL(joint_stats_kernel, dim3(gx, N), dim3(256), lds, stream, f, g, labels, input_lengths,
+                           label_lengths, lp2, logz, maxT, maxU, Up, A, blank, per_row);
+        check();
+    }
+    mark(1);
+    const int dirs = training ? 2 : 1;
+#define RNNT_LATTICE(MW)                                                                                  \
+    hipLaunchKernelGGL((lattice_kernel<C, MW>), dim3(N * dirs), dim3(Up), 0, stream, lp2, alpha, beta, offa, \
+                       offb, llf, llb, costs_device, input_lengths, label_lengths, maxT, maxU, Up, dirs)
+    if (Up == 64) RNNT_LATTICE(1);
+    else if (Up <= 512) RNNT_LATTICE(8);
+    else RNNT_LATTICE(16);
+#undef RNNT_LATTICE
+    check();
+    mark(2);
+    if (training) {
+        const long long skew_cells = static_cast<long long>(maxT + maxU - 1) * Up;
+        const dim3 cgrid(static_cast<unsigned>(((skew_cells + 255) / 256 + 7) / 8 * 8), N);
+        hipLaunchKernelGGL((coef_kernel<C>), cgrid, dim3(256), 0, stream, lp2, logz, alpha, beta, offa, offb, llf,
+                           labels, input_lengths, label_lengths, rowtab, maxT, maxU, Up);
+        check();
+        mark(3);
+        const dim3 ggrid((A + 63) / 64, (maxT + kJointTS - 1) / kJointTS, N);
+        hipLaunchKernelGGL(joint_grad_kernel, ggrid, dim3(256), 0, stream, f, g, rowtab, input_lengths,
+                           label_lengths, df, dg, maxT, maxU, A, blank);
+        check();
+    } else {
+        mark(3);
+    }
+    mark(4);
+    if (prof) g_prof.pending = true;
+    return failed ? RNNT_STATUS_EXECUTION_FAILED : RNNT_STATUS_SUCCESS;
+}
+
 static bool bad_args(const void* acts, const int* labels, const int* label_lengths,
                      const int* input_lengths, const void* costs, const void* workspace, int A, int N,
                      const rnntOptions& o) {
@@ -386,6 +466,18 @@ rnntStatus_t compute_rnnt_loss_async(const void* activations, void* gradients, c
                                 workspace, options);
         default: return RNNT_STATUS_INVALID_VALUE;
     }
+}
+
+rnntStatus_t compute_rnnt_loss_add(const float* const trans_acts, const float* const pred_acts,
+                                   float* trans_grads, float* pred_grads, const int* const flat_labels,
+                                   const int* const label_lengths, const int* const input_lengths,
+                                   int alphabet_size, int minibatch, float* costs_device, void* workspace,
+                                   rnntOptions options) {
+    if (bad_args(trans_acts, flat_labels, label_lengths, input_lengths, costs_device, workspace, alphabet_size,
+                 minibatch, options) || pred_acts == nullptr || options.loc != RNNT_GPU)
+        return RNNT_STATUS_INVALID_VALUE;
+    return run_gpu_joint(trans_acts, pred_acts, trans_grads, pred_grads, flat_labels, label_lengths,
+                         input_lengths, alphabet_size, minibatch, costs_device, workspace, options);
 }
 
 void rnnt_profile_enable(int on) { g_prof.on = on != 0; }

@@ -1,0 +1,105 @@
+"""Additive-joint ("add network") RNN-T loss: the joint tensor is never materialised.
+
+The reference's add_network branch is called as ``fn(trans_acts, pred_acts, labels, lengths,
+label_lengths)`` (pytorch_binding/test/test_time.py:51-70) on the transcription output
+``trans_acts`` (B,T,V) and the prediction output ``pred_acts`` (B,U+1,V) of Graves' 2012
+transducer, whose joint logits are ``trans_acts[:, :, None] + pred_acts[:, None]``
+(docs/rnnt_notes.tex:56-59).  Mathematically this module equals
+
+    RNNTLoss(...)(trans_acts.unsqueeze(2) + pred_acts.unsqueeze(1), labels, act_lens, label_lens)
+
+but it binds ``compute_rnnt_loss_add`` of include/rnnt.h, whose kernels form f+g on the fly and
+reduce the gradient into d(trans_acts) = sum_u and d(pred_acts) = sum_t in-kernel
+(docs/rnnt_notes.tex:147-153).  GPU, float32.
+"""
+import torch
+from torch.autograd import Function
+from torch.nn import Module
+
+from . import _lib, check_contiguous, check_dim, check_type
+
+__all__ = ["rnnt_loss_add", "RNNTLossAdd"]
+
+
+def _certify(trans_acts, pred_acts, labels, act_lens, label_lens):
+    check_type(labels, torch.int32, "labels")
+    check_type(label_lens, torch.int32, "label_lengths")
+    check_type(act_lens, torch.int32, "lengths")
+    for var, name in ((trans_acts, "trans_acts"), (pred_acts, "pred_acts"), (labels, "labels"),
+                      (act_lens, "lengths"), (label_lens, "label_lengths")):
+        check_contiguous(var, name)
+    check_dim(trans_acts, 3, "trans_acts")
+    check_dim(pred_acts, 3, "pred_acts")
+    check_dim(labels, 2, "labels")
+    check_dim(act_lens, 1, "lengths")
+    check_dim(label_lens, 1, "label_lengths")
+    if not (trans_acts.is_cuda and pred_acts.is_cuda):
+        raise ValueError("the additive-joint loss runs on the GPU only")
+    if trans_acts.dtype is not torch.float32 or pred_acts.dtype is not torch.float32:
+        raise TypeError("trans_acts and pred_acts must be torch.float32")
+    B, T, V = trans_acts.shape
+    if pred_acts.shape[0] != B or pred_acts.shape[2] != V:
+        raise ValueError("trans_acts (B,T,V) and pred_acts (B,U+1,V) disagree")
+    if act_lens.shape[0] != B or label_lens.shape[0] != B:
+        raise ValueError("must have a length per example.")
+    if T != torch.max(act_lens):
+        raise ValueError("Input length mismatch")
+    if pred_acts.shape[1] != torch.max(label_lens) + 1:
+        raise ValueError("Output length mismatch")
+
+
+class _RNNTAdd(Function):
+    @staticmethod
+    def forward(ctx, trans_acts, pred_acts, labels, act_lens, label_lens, blank, reduction):
+        _certify(trans_acts, pred_acts, labels, act_lens, label_lens)
+        lib = _lib.lib()
+        B, T, V = trans_acts.shape
+        U = pred_acts.shape[1]
+        need_grad = trans_acts.requires_grad or pred_acts.requires_grad
+        dev = trans_acts.device
+        with torch.cuda.device(dev):
+            df = torch.empty_like(trans_acts) if need_grad else None
+            dg = torch.empty_like(pred_acts) if need_grad else None
+            costs = torch.empty(B, dtype=torch.float32, device=dev)
+            ws = torch.empty(_lib.workspace_bytes(T, U, B, True, 4), dtype=torch.uint8, device=dev)
+            opt = _lib.rnntOptions(loc=_lib.RNNT_GPU, num_threads=0,
+                                   stream=torch.cuda.current_stream(dev).cuda_stream, blank_label=int(blank),
+                                   maxT=T, maxU=U, batch_first=True)
+            lab_ptr = labels.data_ptr() if labels.numel() else costs.data_ptr()   # maxU == 1: never read
+            st = lib.compute_rnnt_loss_add(trans_acts.data_ptr(), pred_acts.data_ptr(),
+                                           df.data_ptr() if need_grad else None,
+                                           dg.data_ptr() if need_grad else None, lab_ptr,
+                                           label_lens.data_ptr(), act_lens.data_ptr(), V, B, costs.data_ptr(),
+                                           ws.data_ptr(), opt)
+            _lib.check(st, "compute_rnnt_loss_add")
+            ws.record_stream(torch.cuda.current_stream(dev))
+        if reduction in ("sum", "mean"):
+            costs = costs.sum().unsqueeze_(-1)
+            if reduction == "mean":
+                costs /= B
+                if need_grad:
+                    df /= B
+                    dg /= B
+        ctx.grads = (df, dg)
+        return costs
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        df, dg = ctx.grads
+        go = grad_output.view(-1, 1, 1).to(df)
+        return df.mul_(go), dg.mul_(go), None, None, None, None, None
+
+
+def rnnt_loss_add(trans_acts, pred_acts, labels, act_lens, label_lens, blank=0, reduction="mean"):
+    """RNN-T loss of the additive joint ``trans_acts[:, :, None] + pred_acts[:, None]`` without
+    forming it.  Arguments as `rnnt_loss`, with the two activations instead of the joint tensor."""
+    return _RNNTAdd.apply(trans_acts, pred_acts, labels, act_lens, label_lens, blank, reduction)
+
+
+class RNNTLossAdd(Module):
+    def __init__(self, blank=0, reduction="mean"):
+        super().__init__()
+        self.blank, self.reduction = blank, reduction
+
+    def forward(self, trans_acts, pred_acts, labels, act_lens, label_lens):
+        return rnnt_loss_add(trans_acts, pred_acts, labels, act_lens, label_lens, self.blank, self.reduction)

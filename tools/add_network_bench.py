@@ -1,0 +1,67 @@
+#!/usr/bin/env python
+"""Time the additive-joint entry against the materialised path on the BASELINE shapes.
+  fused        : compute_rnnt_loss_add(f, g) -> costs, df, dg
+  materialised : joint = f[:, :, None] + g[:, None]  (torch)  -> compute_rnnt_loss_async -> grads
+                 -> df = grads.sum(2), dg = grads.sum(1)  (torch)   [what a user of the reference does]
+Usage: python tools/add_network_bench.py [c2 c3 c4]"""
+import ctypes as C
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "warp-transducer_amd")):
+    sys.path.insert(0, p)
+import torch
+from warprnnt_pytorch import _lib, warp_rnnt
+
+SHAPES = {"c2": (16, 150, 41, 28), "c3": (128, 150, 21, 5000), "c4": (64, 1500, 301, 50), "c5f32": (128, 200, 41, 1024)}
+dev = torch.device("cuda:0")
+lib = _lib.lib()
+for name in sys.argv[1:] or ["c3"]:
+    N, T, U, A = SHAPES[name]
+    g0 = torch.Generator(device=dev); g0.manual_seed(1)
+    f = torch.rand((N, T, A), generator=g0, device=dev)
+    g = torch.rand((N, U, A), generator=g0, device=dev)
+    labels = torch.randint(1, A, (N, U - 1), generator=g0, device=dev, dtype=torch.int32)
+    tl = torch.full((N,), T, dtype=torch.int32, device=dev)
+    ll = torch.full((N,), U - 1, dtype=torch.int32, device=dev)
+    df, dg = torch.empty_like(f), torch.empty_like(g)
+    costs = torch.empty(N, device=dev)
+    ws = torch.empty(_lib.workspace_bytes(T, U, N, True, 4), dtype=torch.uint8, device=dev)
+    opt = _lib.rnntOptions(loc=1, num_threads=0, stream=torch.cuda.current_stream().cuda_stream, blank_label=0,
+                           maxT=T, maxU=U, batch_first=True)
+
+    def fused():
+        st = lib.compute_rnnt_loss_add(f.data_ptr(), g.data_ptr(), df.data_ptr(), dg.data_ptr(), labels.data_ptr(),
+                                       ll.data_ptr(), tl.data_ptr(), A, N, costs.data_ptr(), ws.data_ptr(), opt)
+        assert st == 0
+
+    grads = torch.empty((N, T, U, A), device=dev)
+
+    def materialised():
+        joint = f.unsqueeze(2) + g.unsqueeze(1)
+        warp_rnnt.gpu_rnnt_async(joint, labels, tl, ll, costs, grads, 0, workspace=ws)
+        return grads.sum(2), grads.sum(1)
+
+    out = {}
+    for label, fn in (("fused", fused), ("materialised", materialised)):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        lib.rnnt_profile_reset(); lib.rnnt_profile_enable(1)
+        t0 = time.perf_counter()
+        reps = 10
+        for _ in range(reps):
+            fn()
+            torch.cuda.synchronize()
+            lib.rnnt_profile_collect()
+        ms = (time.perf_counter() - t0) * 1e3 / reps
+        lib.rnnt_profile_enable(0)
+        st = (C.c_double * 5)(); n = lib.rnnt_profile_read(st, 5)
+        out[label] = (ms, [round(st[i] / max(n, 1), 4) for i in range(5)])
+    c_f = costs.clone(); fused(); torch.cuda.synchronize()
+    print("%s N=%d T=%d U=%d A=%d: fused %.3f ms (stages stats/lattice/coef/grad/span %s) | materialised %.3f ms "
+          "(library stages %s) | speed-up x%.1f" % (name, N, T, U, A, out["fused"][0], out["fused"][1],
+                                                    out["materialised"][0], out["materialised"][1],
+                                                    out["materialised"][0] / out["fused"][0]))

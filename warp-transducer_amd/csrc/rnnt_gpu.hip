@@ -331,7 +331,7 @@ static rnntStatus_t run_gpu_joint(const float* f, const float* g, float* df, flo
         check();
         mark(3);
         const dim3 ggrid((A + 63) / 64, (maxT + kJointTS - 1) / kJointTS, N);
-        hipLaunchKernelGGL(joint_grad_kernel, ggrid, dim3(256), 0, stream, f, g, rowtab, input_lengths,
+        hipLaunchKernelGGL(joint_grad_kernel, ggrid, dim3(256), 0, stream, f, g, rowtab, labels, input_lengths,
                            label_lengths, df, dg, maxT, maxU, A, blank);
         check();
     } else {

@@ -133,86 +133,90 @@ __global__ __launch_bounds__(256) void joint_stats_kernel(
 // Joint gradient.  With the row table {c, cb, cl, label} of coef_kernel,
 //     dL/dh(k,t,u) = exp(f[t,k] + g[u,k] + c(t,u)) - [k=blank] cb(t,u) - [k=label] cl(t,u)
 // (zero for padded cells), df[t,k] = sum_u, dg[u,k] = sum_t.
-// A block owns 64 vocabulary columns (one per lane), a slice of kJointTS time rows and walks the
-// label axis in windows of <= kJointUW rows whose g values and dg accumulators live in LDS.
-// Wavefront w takes the time rows t = w mod 4 of the slice: f[t,k] sits in a register, the 64
-// records of a label sub-window are fetched with ONE coalesced load (lane j holds record u0+j)
-// and handed round with v_readlane, df[t,k] accumulates in a register (one owner, no atomics),
-// dg[u,k] accumulates with LDS float atomics across the four wavefronts and is added to global
-// memory once per block (dg is zero-filled by the host driver first).
-// grid = (ceil(A/64), ceil(T/kJointTS), N), block = 256.
-constexpr int kJointUW = 128;   // label rows per LDS window
+// A block owns 64 vocabulary columns (one per lane) and a slice of kJointTS = 32 time rows whose
+// f values sit in 32 registers per lane.  Wavefront w takes the label rows u = w, w+4, ...: per
+// row it loads g[u,k] (coalesced), fetches the 32 records (t0..t0+31, u) with one load (lane i
+// holds record i) and runs the fully unrolled loop over the 32 time rows, handing c(t,u) round
+// with v_readlane: dg[u,k] accumulates in ONE register (this wavefront is the only one that
+// touches row u in this block) and goes to global memory as one atomic per (u,k) and block (dg is
+// zero-filled by the host first; blocks of other time slices add to it), df[t,k] accumulates in
+// 32 registers, the four wavefronts' partial sums are combined through LDS at the end and stored
+// by their unique owner.  The blank / label corrections touch two columns per cell, so only
+// blocks whose 64 columns contain the blank or one of the sample's labels run the longer loop.
+// grid = (ceil(A/64), ceil(T/32), N), block = 256.
 constexpr int kJointTS = 32;    // time rows per block
+
+template <bool SPECIAL>
+__device__ __forceinline__ void joint_grad_rows(
+        const float (&fv)[kJointTS], float (&dfacc)[kJointTS], const float* __restrict__ g,
+        const Cell<float>* __restrict__ tab, float* __restrict__ dg, int b, int t0, int maxT, int maxU,
+        int Ub, int A, int k, bool kin, bool is_blank, int lane, int wave) {
+    for (int u = wave; u < Ub; u += 4) {
+        const float gv = kin ? g[(static_cast<size_t>(b) * maxU + u) * A + k] : 0.0f;
+        Cell<float> rec;
+        rec.x = log_zero<float>(); rec.y = 0; rec.z = 0; rec.w = static_cast<float>(kPadded);
+        if (lane < kJointTS && t0 + lane < maxT) rec = tab[static_cast<size_t>(t0 + lane) * maxU + u];
+        float dgacc = 0.0f;
+#pragma unroll
+        for (int i = 0; i < kJointTS; ++i) {
+            const float c = lane_get(rec.x, i);                 // log_zero for padded cells -> p = 0
+            float p = fast_exp(fv[i] + (gv + c));
+            if constexpr (SPECIAL) {
+                const float cb = lane_get(rec.y, i), cl = lane_get(rec.z, i);
+                const int lab = static_cast<int>(lane_get(rec.w, i));
+                if (is_blank) p -= cb;
+                if (k == lab) p -= cl;
+            }
+            dfacc[i] += p;
+            dgacc += p;
+        }
+        if (kin) atomicAdd(dg + (static_cast<size_t>(b) * maxU + u) * A + k, dgacc);
+    }
+}
 
 __global__ __launch_bounds__(256) void joint_grad_kernel(
         const float* __restrict__ f, const float* __restrict__ g, const Cell<float>* __restrict__ rowtab,
-        const int* __restrict__ xlen, const int* __restrict__ ylen, float* __restrict__ df,
-        float* __restrict__ dg, int maxT, int maxU, int A, int blank) {
-    __shared__ float gtile[kJointUW][64];
-    __shared__ float dgt[kJointUW][64];
+        const int* __restrict__ labels, const int* __restrict__ xlen, const int* __restrict__ ylen,
+        float* __restrict__ df, float* __restrict__ dg, int maxT, int maxU, int A, int blank) {
+    __shared__ float dft[4][kJointTS][64];
     const int b = blockIdx.z;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int k = blockIdx.x * 64 + lane;                  // vocabulary column of this lane
+    const int k0 = blockIdx.x * 64;
+    const int k = k0 + lane;                               // vocabulary column of this lane
     const bool kin = k < A;
     const int t0 = blockIdx.y * kJointTS;
-    int t1 = t0 + kJointTS;
-    if (t1 > maxT) t1 = maxT;
     const int Tb = xlen[b], Ub = ylen[b] + 1;
     const bool is_blank = (k == blank);
-    const float* gb = g + static_cast<size_t>(b) * maxU * A;
     const Cell<float>* tab = rowtab + static_cast<size_t>(b) * maxT * maxU;
 
-    for (int uw = 0; uw < maxU; uw += kJointUW) {
-        const int nu = maxU - uw < kJointUW ? maxU - uw : kJointUW;
-        // stage g rows of the window (256 B per row and block: coalesced), clear the accumulators
-        for (int i = threadIdx.x; i < nu * 64; i += 256) {
-            const int r = i >> 6, c = i & 63;
-            const int kc = blockIdx.x * 64 + c;
-            gtile[r][c] = (kc < A) ? gb[static_cast<size_t>(uw + r) * A + kc] : 0.0f;
-            dgt[r][c] = 0.0f;
-        }
-        __syncthreads();
-        if (uw < Ub) {                                     // block-uniform: rows past U_b are padding
-            for (int t = t0 + wave; t < t1; t += 4) {
-                float dfacc = 0.0f;
-                if (t < Tb) {
-                    const float fv = kin ? f[(static_cast<size_t>(b) * maxT + t) * A + k] : 0.0f;
-                    const Cell<float>* trow = tab + static_cast<size_t>(t) * maxU + uw;
-                    for (int us = 0; us < nu; us += 64) {
-                        const int cnt = nu - us < 64 ? nu - us : 64;
-                        Cell<float> rec;
-                        rec.x = 0; rec.y = 0; rec.z = 0; rec.w = static_cast<float>(kPadded);
-                        if (lane < cnt) rec = trow[us + lane];
-                        for (int j = 0; j < cnt; ++j) {
-                            const int labj = static_cast<int>(lane_get(rec.w, j));
-                            if (labj == kPadded) continue;                    // wave-uniform
-                            const float cj = lane_get(rec.x, j);
-                            const float cbj = lane_get(rec.y, j);
-                            const float clj = lane_get(rec.z, j);
-                            float p = fast_exp(fv + gtile[us + j][lane] + cj);
-                            if (is_blank) p -= cbj;
-                            if (k == labj) p -= clj;
-                            if (!kin) p = 0.0f;
-                            dfacc += p;
-                            atomicAdd(&dgt[us + j][lane], p);
-                        }
-                    }
-                }
-                if (kin) {
-                    float* dst = df + (static_cast<size_t>(b) * maxT + t) * A + k;
-                    *dst = (uw == 0) ? dfacc : *dst + dfacc;   // this thread owns (t,k) in every window
-                }
-            }
-        }
-        __syncthreads();
-        // one global atomic per (u,k) of the window and block
-        for (int i = threadIdx.x; i < nu * 64; i += 256) {
-            const int r = i >> 6, c = i & 63;
-            const int kc = blockIdx.x * 64 + c;
-            const float v = dgt[r][c];
-            if (kc < A && v != 0.0f) atomicAdd(dg + (static_cast<size_t>(b) * maxU + uw + r) * A + kc, v);
-        }
-        __syncthreads();
+    // does this block's column range hold the blank or one of the sample's labels?
+    int hit = (blank >= k0 && blank < k0 + 64) ? 1 : 0;
+    for (int i = threadIdx.x; i < Ub - 1; i += 256) {
+        const int lab = labels[static_cast<size_t>(b) * (maxU - 1) + i];
+        hit |= (lab >= k0 && lab < k0 + 64) ? 1 : 0;
+    }
+    const bool special = __syncthreads_or(hit) != 0;
+
+    float fv[kJointTS], dfacc[kJointTS];
+#pragma unroll
+    for (int i = 0; i < kJointTS; ++i) {
+        const int t = t0 + i;
+        fv[i] = (kin && t < Tb) ? f[(static_cast<size_t>(b) * maxT + t) * A + k] : 0.0f;
+        dfacc[i] = 0.0f;
+    }
+    if (t0 < Tb) {                                         // block-uniform: time rows past T_b are padding
+        if (special)
+            joint_grad_rows<true>(fv, dfacc, g, tab, dg, b, t0, maxT, maxU, Ub, A, k, kin, is_blank, lane, wave);
+        else
+            joint_grad_rows<false>(fv, dfacc, g, tab, dg, b, t0, maxT, maxU, Ub, A, k, kin, is_blank, lane, wave);
+    }
+#pragma unroll
+    for (int i = 0; i < kJointTS; ++i) dft[wave][i][lane] = dfacc[i];
+    __syncthreads();
+    for (int i = wave; i < kJointTS; i += 4) {
+        const int t = t0 + i;
+        if (kin && t < maxT)
+            df[(static_cast<size_t>(b) * maxT + t) * A + k] = dft[0][i][lane] + dft[1][i][lane] + dft[2][i][lane] + dft[3][i][lane];
     }
 }
 

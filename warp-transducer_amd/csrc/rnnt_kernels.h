@@ -625,8 +625,8 @@ __global__ __launch_bounds__(256) void coef_kernel(
     const int t = n - u;
     if (u >= maxU || t < 0 || t >= maxT) return;              // not a row of the tensor
     const int Tb = xlen[b], Ub = ylen[b] + 1;
-    Cell<L> o;
-    o.x = 0; o.y = 0; o.z = 0; o.w = static_cast<L>(kPadded);
+    Cell<L> o;      // padded row: c = "log zero" (exp(x + c) = 0 for any x), no corrections, flagged
+    o.x = log_zero<L>(); o.y = 0; o.z = 0; o.w = static_cast<L>(kPadded);
     if (t < Tb && u < Ub) {
         const size_t Dp = lat_rows(maxT, maxU);
         const int W = Up >> 6;

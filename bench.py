@@ -61,13 +61,16 @@ def make_inputs(w, dev, seed):
     return acts, labels, act_lens, label_lens
 
 
-def algorithmic_bytes(w):
-    """acts read twice, grads written once, plus the fp32 lattice side arrays."""
+def algorithmic_bytes(w, valid_rows=None):
+    """acts read twice, grads written once, plus the fp32 lattice side arrays.
+    With variable lengths only the valid (t < T_b, u < U_b) rows have to be READ; every row of
+    the gradient tensor is still written (zeros in the padding)."""
     N, T, U, A, s = w["N"], w["T"], w["L"] + 1, w["A"], ESIZE[w["dtype"]]
     R = N * T * U
-    E = R * A
-    return dict(E=E, R=R, path=3 * E * s + 48 * R, grad_kernel=2 * E * s + 16 * R,
-                stats_kernel=E * s + 16 * R)
+    Rv = R if valid_rows is None else valid_rows
+    E, Ev = R * A, Rv * A
+    return dict(E=E, R=R, path=2 * Ev * s + E * s + 48 * Rv, grad_kernel=Ev * s + E * s + 16 * R,
+                stats_kernel=Ev * s + 16 * Rv)
 
 
 def cpu_baseline(w, acts, labels, act_lens, label_lens, budget_samples):
@@ -203,7 +206,8 @@ def main():
         stage = (C.c_double * 5)()
         calls = lib.rnnt_profile_read(stage, 5)
         stage_ms = [stage[i] / calls for i in range(5)] if calls else None
-        ab = algorithmic_bytes(w)
+        valid_rows = int((act_lens.long() * (label_lens.long() + 1)).sum().item()) if args.varlen else None
+        ab = algorithmic_bytes(w, valid_rows)
         res = dict(workload=name, ms_per_step=ms_step, stage_ms=stage_ms, bytes=ab, w=w,
                    loss_sum=float(out.sum()) if not sharded else float(out[0]))
         if with_cpu and rank == 0:
@@ -241,7 +245,7 @@ def main():
         traffic = None
         try:   # PMC-measured HBM bytes per launch of this kernel, from the committed rocprofv3 passes
             tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
-            if not args.override:
+            if not args.override and not args.varlen:
                 traffic = tj[args.workload]["grad_flat_kernel"]["traffic_bytes"]
         except (OSError, KeyError, ValueError):
             pass

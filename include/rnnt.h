@@ -176,6 +176,36 @@ rnntStatus_t compute_rnnt_loss_async(const void* activations,
                                      rnntOptions options,
                                      int dtype_code);
 
+/* Two-phase form for autograd frameworks ("fused backward").
+ * compute_rnnt_loss_fwd enqueues the row statistics, the lattice and -- with prepare_backward != 0 --
+ * the gradient-coefficient table, and writes the costs to `costs_device`; compute_rnnt_loss_bwd,
+ * called later with the SAME activations, workspace and options, enqueues only the gradient kernel,
+ * multiplying sample b's gradient by grad_scale_device[b] (float; double for fp64; NULL = 1).
+ * Between the two calls only the workspace has to stay alive and untouched -- not a gradient tensor
+ * the size of the activations, which the reference's binding keeps in its autograd context and
+ * then rescales twice (pytorch_binding/warprnnt_pytorch/__init__.py:24,36-50).  Enqueue only, no
+ * synchronisation, DEVICE costs; dtype_code as compute_rnnt_loss_async. */
+rnntStatus_t compute_rnnt_loss_fwd(const void* activations,
+                                   const int* const flat_labels,
+                                   const int* const label_lengths,
+                                   const int* const input_lengths,
+                                   int alphabet_size,
+                                   int minibatch,
+                                   void* costs_device,
+                                   void* workspace,
+                                   rnntOptions options,
+                                   int dtype_code,
+                                   int prepare_backward);
+
+rnntStatus_t compute_rnnt_loss_bwd(const void* activations,
+                                   void* gradients,
+                                   const void* grad_scale_device,
+                                   int alphabet_size,
+                                   int minibatch,
+                                   void* workspace,
+                                   rnntOptions options,
+                                   int dtype_code);
+
 /* Additive joint ("add network", the reference's add_network branch: README.md:4,
  * docs/rnnt_notes.tex:56-59,147-153, pytorch_binding/test/test_time.py:51-77).  The joint logits
  * are h(k,t,u) = trans_acts[b,t,k] + pred_acts[b,u,k]; the (B,T,U,V) tensor is never formed.

@@ -1,0 +1,52 @@
+#!/usr/bin/env python
+"""End-to-end PyTorch training-step time of the loss: RNNTLoss(reduction='mean') forward + backward
+on a (N,T,U,A) logits tensor that requires grad.  Two routes of the wrapper:
+  two-phase : compute_rnnt_loss_fwd in forward (keeps only the workspace), compute_rnnt_loss_bwd in
+              backward with 1/N and grad_output folded into the gradient kernel        (default)
+  reference : gradients computed in forward, kept in ctx, divided by N, multiplied by grad_output in
+              backward -- the reference binding's flow (WARPRNNT_SYNC_API=1)
+Usage: python tools/train_step_bench.py [c3 c5 ...]"""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "warp-transducer_amd")):
+    sys.path.insert(0, p)
+import torch
+import warprnnt_pytorch
+from warprnnt_pytorch import RNNTLoss
+
+SHAPES = {"c2": (16, 150, 41, 28, torch.float32), "c3": (128, 150, 21, 5000, torch.float32),
+          "c4": (64, 1500, 301, 50, torch.float32), "c5": (128, 200, 41, 1024, torch.bfloat16)}
+dev = torch.device("cuda:0")
+for name in sys.argv[1:] or ["c3"]:
+    N, T, U, A, dt = SHAPES[name]
+    g = torch.Generator(device=dev); g.manual_seed(3)
+    acts = torch.rand((N, T, U, A), generator=g, device=dev).to(dt).requires_grad_(True)
+    labels = torch.randint(1, A, (N, U - 1), generator=g, device=dev, dtype=torch.int32)
+    tl = torch.full((N,), T, dtype=torch.int32, device=dev)
+    ll = torch.full((N,), U - 1, dtype=torch.int32, device=dev)
+    res = {}
+    for route, flag in (("two-phase", True), ("reference-flow", False)):
+        warprnnt_pytorch._ASYNC_GPU = flag
+        fn = RNNTLoss(reduction="mean")
+        for _ in range(3):
+            acts.grad = None
+            fn(acts, labels, tl, ll).backward()
+        torch.cuda.synchronize()
+        torch.cuda.reset_peak_memory_stats()
+        base = torch.cuda.memory_allocated()
+        t0 = time.perf_counter()
+        reps = 10
+        for _ in range(reps):
+            acts.grad = None
+            loss = fn(acts, labels, tl, ll)
+            loss.backward()
+        torch.cuda.synchronize()
+        res[route] = ((time.perf_counter() - t0) * 1e3 / reps, (torch.cuda.max_memory_allocated() - base) / 2**30,
+                      float(loss.detach()))
+    a, b = res["two-phase"], res["reference-flow"]
+    print("%s N=%d T=%d U=%d A=%d %s: two-phase %.3f ms/step (peak extra %.2f GiB) | reference flow %.3f ms/step "
+          "(peak extra %.2f GiB) | x%.2f ; loss %.6f vs %.6f" % (name, N, T, U, A, str(dt).split(".")[-1], a[0], a[1],
+                                                               b[0], b[1], b[0] / a[0], a[2], b[2]))

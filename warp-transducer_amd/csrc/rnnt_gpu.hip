@@ -118,7 +118,10 @@ static rnntStatus_t run_gpu(const typename Tag::store* acts, typename Tag::store
                             const int* labels, const int* label_lengths, const int* input_lengths,
                             int A, int N, typename Tag::comp* costs_host,
                             typename Tag::comp* costs_device_out, const typename Tag::comp* grad_scale,
-                            void* workspace, const rnntOptions& opt) {
+                            void* workspace, const rnntOptions& opt, int phases = 3, int want_grad = -1) {
+    // phases: bit 0 = forward part (row statistics, lattice, and -- when gradients are wanted --
+    // the coefficient table), bit 1 = gradient kernel.  The two-call form (compute_rnnt_loss_fwd /
+    // _bwd) keeps only the workspace alive between them.
     using S = typename Tag::store;
     using C = typename Tag::comp;
     const int maxT = opt.maxT, maxU = opt.maxU, blank = opt.blank_label;
@@ -127,7 +130,9 @@ static rnntStatus_t run_gpu(const typename Tag::store* acts, typename Tag::store
     if (static_cast<long long>(maxT) * maxU > 0x7fffffffLL / 4) return RNNT_STATUS_INVALID_VALUE;
     if (N > 65535) return RNNT_STATUS_INVALID_VALUE;
     hipStream_t stream = reinterpret_cast<hipStream_t>(opt.stream);
-    const bool training = grads != nullptr;
+    const bool training = want_grad < 0 ? grads != nullptr : want_grad != 0;
+    const bool do_fwd = (phases & 1) != 0, do_bwd = (phases & 2) != 0 && training;
+    if (do_bwd && grads == nullptr) return RNNT_STATUS_INVALID_VALUE;
 
     const Layout lay = make_layout(maxT, maxU, N, sizeof(C));
     char* ws = reinterpret_cast<char*>(align_up(reinterpret_cast<size_t>(workspace)));
@@ -146,7 +151,7 @@ static rnntStatus_t run_gpu(const typename Tag::store* acts, typename Tag::store
     const uintptr_t pa = reinterpret_cast<uintptr_t>(acts);
     const uintptr_t pg = reinterpret_cast<uintptr_t>(grads);
     int vec_ok = (pa % sizeof(S) == 0) ? 1 : 0;
-    if (training && ((pa ^ pg) & 15u)) vec_ok = 0;
+    if (grads != nullptr && ((pa ^ pg) & 15u)) vec_ok = 0;
 
     const bool prof = prof_prepare();
     auto mark = [&](int i) { if (prof) (void)hipEventRecord(g_prof.ev[i], stream); };
@@ -159,6 +164,7 @@ static rnntStatus_t run_gpu(const typename Tag::store* acts, typename Tag::store
 
     mark(0);
     const size_t row_bytes = static_cast<size_t>(A) * sizeof(S);
+    if (do_fwd) {
     bool tiled = false;
     if (tn.tile && vec_ok && row_bytes <= static_cast<size_t>(kTileMaxRowBytes)) {
         // smallest lane group G whose tile of 256/G rows fits the LDS budget
@@ -212,7 +218,13 @@ static rnntStatus_t run_gpu(const typename Tag::store* acts, typename Tag::store
         hipLaunchKernelGGL((coef_kernel<C>), cgrid, dim3(256), 0, stream, lp2, logz, alpha, beta, offa, offb, llf,
                            labels, input_lengths, label_lengths, rowtab, maxT, maxU, Up);
         RNNT_LAUNCH_CHECK();
-        mark(3);
+    }
+    } else {   // !do_fwd
+        mark(1);
+        mark(2);
+    }
+    mark(3);
+    if (do_bwd) {
         const unsigned long long R = static_cast<unsigned long long>(N) * cells_per_sample;
         const unsigned long long E = R * A;
         constexpr int V = Vec<Tag>::N;
@@ -247,8 +259,6 @@ static rnntStatus_t run_gpu(const typename Tag::store* acts, typename Tag::store
                                    rowtab, grad_scale, maxT, maxU, A, blank, vec_ok);
         }
         RNNT_LAUNCH_CHECK();
-    } else {
-        mark(3);
     }
     mark(4);
 
@@ -435,6 +445,31 @@ rnntStatus_t compute_rnnt_loss_fp16(const uint16_t* const activations, uint16_t*
                         minibatch, costs, nullptr, nullptr, workspace, options);
 }
 
+// Dispatch of the enqueue-only forms on the dtype code (0 fp32, 1 fp64, 2 bf16, 3 fp16).
+static rnntStatus_t run_async(const void* acts, void* grads, const int* labels, const int* label_lengths,
+                              const int* input_lengths, int A, int N, void* costs_device, const void* scale,
+                              void* workspace, const rnntOptions& o, int dtype_code, int phases, int want_grad) {
+    switch (dtype_code) {
+        case 0:
+            return run_gpu<F32>(static_cast<const float*>(acts), static_cast<float*>(grads), labels, label_lengths,
+                                input_lengths, A, N, nullptr, static_cast<float*>(costs_device),
+                                static_cast<const float*>(scale), workspace, o, phases, want_grad);
+        case 1:
+            return run_gpu<F64>(static_cast<const double*>(acts), static_cast<double*>(grads), labels, label_lengths,
+                                input_lengths, A, N, nullptr, static_cast<double*>(costs_device),
+                                static_cast<const double*>(scale), workspace, o, phases, want_grad);
+        case 2:
+            return run_gpu<BF16>(static_cast<const uint16_t*>(acts), static_cast<uint16_t*>(grads), labels,
+                                 label_lengths, input_lengths, A, N, nullptr, static_cast<float*>(costs_device),
+                                 static_cast<const float*>(scale), workspace, o, phases, want_grad);
+        case 3:
+            return run_gpu<F16>(static_cast<const uint16_t*>(acts), static_cast<uint16_t*>(grads), labels,
+                                label_lengths, input_lengths, A, N, nullptr, static_cast<float*>(costs_device),
+                                static_cast<const float*>(scale), workspace, o, phases, want_grad);
+        default: return RNNT_STATUS_INVALID_VALUE;
+    }
+}
+
 rnntStatus_t compute_rnnt_loss_async(const void* activations, void* gradients, const int* const flat_labels,
                                      const int* const label_lengths, const int* const input_lengths,
                                      int alphabet_size, int minibatch, void* costs_device,
@@ -443,29 +478,29 @@ rnntStatus_t compute_rnnt_loss_async(const void* activations, void* gradients, c
     if (bad_args(activations, flat_labels, label_lengths, input_lengths, costs_device, workspace,
                  alphabet_size, minibatch, options) || options.loc != RNNT_GPU)
         return RNNT_STATUS_INVALID_VALUE;
-    switch (dtype_code) {
-        case 0:
-            return run_gpu<F32>(static_cast<const float*>(activations), static_cast<float*>(gradients),
-                                flat_labels, label_lengths, input_lengths, alphabet_size, minibatch, nullptr,
-                                static_cast<float*>(costs_device), static_cast<const float*>(grad_scale_device),
-                                workspace, options);
-        case 1:
-            return run_gpu<F64>(static_cast<const double*>(activations), static_cast<double*>(gradients),
-                                flat_labels, label_lengths, input_lengths, alphabet_size, minibatch, nullptr,
-                                static_cast<double*>(costs_device),
-                                static_cast<const double*>(grad_scale_device), workspace, options);
-        case 2:
-            return run_gpu<BF16>(static_cast<const uint16_t*>(activations), static_cast<uint16_t*>(gradients),
-                                 flat_labels, label_lengths, input_lengths, alphabet_size, minibatch, nullptr,
-                                 static_cast<float*>(costs_device), static_cast<const float*>(grad_scale_device),
-                                 workspace, options);
-        case 3:
-            return run_gpu<F16>(static_cast<const uint16_t*>(activations), static_cast<uint16_t*>(gradients),
-                                flat_labels, label_lengths, input_lengths, alphabet_size, minibatch, nullptr,
-                                static_cast<float*>(costs_device), static_cast<const float*>(grad_scale_device),
-                                workspace, options);
-        default: return RNNT_STATUS_INVALID_VALUE;
-    }
+    return run_async(activations, gradients, flat_labels, label_lengths, input_lengths, alphabet_size, minibatch,
+                     costs_device, grad_scale_device, workspace, options, dtype_code, 3, -1);
+}
+
+rnntStatus_t compute_rnnt_loss_fwd(const void* activations, const int* const flat_labels,
+                                   const int* const label_lengths, const int* const input_lengths,
+                                   int alphabet_size, int minibatch, void* costs_device, void* workspace,
+                                   rnntOptions options, int dtype_code, int prepare_backward) {
+    if (bad_args(activations, flat_labels, label_lengths, input_lengths, costs_device, workspace,
+                 alphabet_size, minibatch, options) || options.loc != RNNT_GPU)
+        return RNNT_STATUS_INVALID_VALUE;
+    return run_async(activations, nullptr, flat_labels, label_lengths, input_lengths, alphabet_size, minibatch,
+                     costs_device, nullptr, workspace, options, dtype_code, 1, prepare_backward ? 1 : 0);
+}
+
+rnntStatus_t compute_rnnt_loss_bwd(const void* activations, void* gradients, const void* grad_scale_device,
+                                   int alphabet_size, int minibatch, void* workspace, rnntOptions options,
+                                   int dtype_code) {
+    if (activations == nullptr || gradients == nullptr || workspace == nullptr || alphabet_size <= 0 ||
+        minibatch <= 0 || options.maxT <= 0 || options.maxU <= 0 || options.loc != RNNT_GPU)
+        return RNNT_STATUS_INVALID_VALUE;
+    return run_async(activations, gradients, nullptr, nullptr, nullptr, alphabet_size, minibatch, nullptr,
+                     grad_scale_device, workspace, options, dtype_code, 2, 1);
 }
 
 rnntStatus_t compute_rnnt_loss_add(const float* const trans_acts, const float* const pred_acts,

@@ -34,19 +34,28 @@ class _RNNT(Function):
         is_cuda = acts.is_cuda
         certify_inputs(acts, labels, act_lens, label_lens)
 
-        # The library overwrites every element of grads (zeros in the padded region), so no
-        # zero-fill is needed (the reference allocates zeros_like: __init__.py:24).
-        grads = torch.empty_like(acts) if acts.requires_grad else torch.zeros(0).to(acts)
         minibatch_size = acts.size(0)
         cost_dtype = acts.dtype if acts.dtype in (torch.float32, torch.float64) else torch.float32
-        if is_cuda and _ASYNC_GPU:
-            # The reference copies the costs to the host inside the library and back to the device
-            # here (__init__.py:26,42).  The asynchronous entry leaves them on the device: same
-            # result, no D2H/H2D round trip and no stream synchronisation in the training step.
+        ctx.two_phase = bool(is_cuda and _ASYNC_GPU)
+        if ctx.two_phase:
+            # Two-phase route (compute_rnnt_loss_fwd / _bwd).  The reference computes the full gradient
+            # tensor here, keeps it in ctx, divides it by N for 'mean' and multiplies it by grad_output
+            # in backward (__init__.py:24,36-50): two extra read+write passes over the (B,T,U,V) tensor
+            # and a tensor of that size alive between forward and backward.  Here forward leaves only
+            # the workspace (lattice + coefficient table) behind; backward runs the gradient kernel
+            # once with the 1/N and grad_output factors folded in.  Same values, costs stay on device.
             costs = torch.empty(minibatch_size, dtype=cost_dtype, device=acts.device)
-            ws = warp_rnnt.gpu_rnnt_async(acts, labels, act_lens, label_lens, costs, grads, blank)
+            ws = warp_rnnt.gpu_rnnt_fwd(acts, labels, act_lens, label_lens, costs, blank, acts.requires_grad)
             ws.record_stream(torch.cuda.current_stream(acts.device))
+            ctx.save_for_backward(acts)
+            ctx.workspace = ws if acts.requires_grad else None
+            ctx.blank = blank
+            ctx.mean_scale = 1.0 / minibatch_size if reduction == 'mean' else 1.0
+            grads = None
         else:
+            # The library overwrites every element of grads (zeros in the padded region), so no
+            # zero-fill is needed (the reference allocates zeros_like: __init__.py:24).
+            grads = torch.empty_like(acts) if acts.requires_grad else torch.zeros(0).to(acts)
             loss_func = warp_rnnt.gpu_rnnt if is_cuda else warp_rnnt.cpu_rnnt
             costs = torch.zeros(minibatch_size, dtype=cost_dtype)   # host, as the C-ABI requires
             loss_func(acts, labels, act_lens, label_lens, costs, grads, blank, 0)
@@ -55,14 +64,24 @@ class _RNNT(Function):
             costs = costs.sum().unsqueeze_(-1)
             if reduction == 'mean':
                 costs /= minibatch_size
-                grads /= minibatch_size
+                if grads is not None:
+                    grads /= minibatch_size
 
         costs = costs.to(acts.device)
         ctx.grads = grads
+
         return costs
 
     @staticmethod
     def backward(ctx, grad_output):
+        if ctx.two_phase:
+            (acts,) = ctx.saved_tensors
+            n = acts.size(0)
+            sdt = torch.float64 if acts.dtype == torch.float64 else torch.float32
+            scale = (grad_output.reshape(-1).to(device=acts.device, dtype=sdt) * ctx.mean_scale).expand(n).contiguous()
+            grads = torch.empty_like(acts)
+            warp_rnnt.gpu_rnnt_bwd(acts, grads, scale, ctx.workspace, ctx.blank)
+            return grads, None, None, None, None, None
         grad_output = grad_output.view(-1, 1, 1, 1).to(ctx.grads)
         return ctx.grads.mul_(grad_output), None, None, None, None, None
 

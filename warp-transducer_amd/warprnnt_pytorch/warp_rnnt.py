@@ -92,3 +92,39 @@ def gpu_rnnt_async(acts, labels, input_lengths, label_lengths, costs_device, gra
                                          opt, code[0])
     _lib.check(st, "compute_rnnt_loss_async")
     return workspace
+
+
+_DT = {torch.float32: (_lib.DT_F32, 4), torch.float64: (_lib.DT_F64, 8),
+       torch.bfloat16: (_lib.DT_BF16, 2), torch.float16: (_lib.DT_F16, 2)}
+
+
+def gpu_rnnt_fwd(acts, labels, input_lengths, label_lengths, costs_device, blank_label, prepare_backward):
+    """Extension: forward phase only (compute_rnnt_loss_fwd).  Returns the workspace tensor; with
+    ``prepare_backward`` it holds the gradient-coefficient table `gpu_rnnt_bwd` needs and must be
+    kept (untouched) until then.  Enqueue only."""
+    lib = _lib.lib()
+    N, T, U, A = acts.shape
+    code, esz = _DT[acts.dtype]
+    with torch.cuda.device(acts.device):
+        ws = torch.empty(_lib.workspace_bytes(T, U, N, True, esz), dtype=torch.uint8, device=acts.device)
+        opt = _options(_lib.RNNT_GPU, acts, blank_label, 0, torch.cuda.current_stream(acts.device).cuda_stream)
+        lab_ptr = labels.data_ptr() if labels.numel() else costs_device.data_ptr()   # maxU == 1: never read
+        st = lib.compute_rnnt_loss_fwd(acts.data_ptr(), lab_ptr, label_lengths.data_ptr(),
+                                       input_lengths.data_ptr(), A, N, costs_device.data_ptr(), ws.data_ptr(), opt,
+                                       code, 1 if prepare_backward else 0)
+    _lib.check(st, "compute_rnnt_loss_fwd")
+    return ws
+
+
+def gpu_rnnt_bwd(acts, grads, grad_scale, workspace, blank_label):
+    """Extension: gradient phase (compute_rnnt_loss_bwd) from the workspace of `gpu_rnnt_fwd`;
+    ``grad_scale`` is a per-sample device vector (float32; float64 for float64 acts) or None."""
+    lib = _lib.lib()
+    N, T, U, A = acts.shape
+    code, _ = _DT[acts.dtype]
+    with torch.cuda.device(acts.device):
+        opt = _options(_lib.RNNT_GPU, acts, blank_label, 0, torch.cuda.current_stream(acts.device).cuda_stream)
+        st = lib.compute_rnnt_loss_bwd(acts.data_ptr(), grads.data_ptr(), _ptr(grad_scale), A, N,
+                                       workspace.data_ptr(), opt, code)
+    _lib.check(st, "compute_rnnt_loss_bwd")
+    return 0

@@ -19,27 +19,27 @@ from . import certify_inputs, warp_rnnt
 __all__ = ["sharded_rnnt_loss", "ShardedRNNTLoss"]
 
 
-def _local_costs_and_grads(acts, labels, act_lens, label_lens, blank, need_grad):
-    """Per-sample costs ON THE DEVICE of acts (no host round trip on the GPU) and local grads."""
-    n = acts.size(0)
-    cost_dtype = acts.dtype if acts.dtype in (torch.float32, torch.float64) else torch.float32
-    grads = torch.empty_like(acts) if need_grad else torch.zeros(0).to(acts)
-    if acts.is_cuda:
-        costs = torch.empty(n, dtype=cost_dtype, device=acts.device)
-        ws = warp_rnnt.gpu_rnnt_async(acts, labels, act_lens, label_lens, costs, grads, blank)
-        ws.record_stream(torch.cuda.current_stream(acts.device))
-    else:
-        costs = torch.zeros(n, dtype=cost_dtype)
-        warp_rnnt.cpu_rnnt(acts, labels, act_lens, label_lens, costs, grads, blank, 0)
-    return costs, grads
-
-
 class _ShardedRNNT(Function):
     @staticmethod
     def forward(ctx, acts, labels, act_lens, label_lens, blank, reduction, group):
         certify_inputs(acts, labels, act_lens, label_lens)
-        costs, grads = _local_costs_and_grads(acts, labels, act_lens, label_lens, blank, acts.requires_grad)
+        n = acts.size(0)
+        cost_dtype = acts.dtype if acts.dtype in (torch.float32, torch.float64) else torch.float32
+        ctx.on_gpu = acts.is_cuda
+        if acts.is_cuda:
+            # forward phase only: costs stay on the device, the workspace carries the coefficient
+            # table to backward (compute_rnnt_loss_fwd / _bwd), no gradient tensor is kept
+            costs = torch.empty(n, dtype=cost_dtype, device=acts.device)
+            ws = warp_rnnt.gpu_rnnt_fwd(acts, labels, act_lens, label_lens, costs, blank, acts.requires_grad)
+            ws.record_stream(torch.cuda.current_stream(acts.device))
+            ctx.save_for_backward(acts)
+            ctx.workspace, ctx.blank, grads = ws, blank, None
+        else:
+            costs = torch.zeros(n, dtype=cost_dtype)
+            grads = torch.empty_like(acts) if acts.requires_grad else torch.zeros(0).to(acts)
+            warp_rnnt.cpu_rnnt(acts, labels, act_lens, label_lens, costs, grads, blank, 0)
         distributed = dist.is_available() and dist.is_initialized()
+        ctx.scale = 1.0
         if reduction == "none":
             if distributed:
                 world = dist.get_world_size(group)
@@ -48,18 +48,17 @@ class _ShardedRNNT(Function):
                 out = torch.cat(parts)
             else:
                 out = costs
-            ctx.rank_offset = (dist.get_rank(group) if distributed else 0) * costs.numel()
-            ctx.local_n = costs.numel()
+            ctx.rank_offset = (dist.get_rank(group) if distributed else 0) * n
+            ctx.local_n = n
         else:
             packed = torch.stack([costs.sum(dtype=torch.float64),
-                                  torch.tensor(float(costs.numel()), dtype=torch.float64, device=costs.device)])
+                                  torch.tensor(float(n), dtype=torch.float64, device=costs.device)])
             if distributed:
                 dist.all_reduce(packed, op=dist.ReduceOp.SUM, group=group)   # the single collective
             out = packed[0:1].to(costs.dtype)
             if reduction == "mean":
                 out = out / packed[1].to(costs.dtype)
-                if grads.numel():
-                    grads.mul_((1.0 / packed[1]).to(grads.dtype))
+                ctx.scale = 1.0 / packed[1]          # 1 / GLOBAL batch size (a 0-dim device tensor)
         ctx.grads = grads
         ctx.reduction = reduction
         return out
@@ -69,8 +68,17 @@ class _ShardedRNNT(Function):
         g = grad_output
         if ctx.reduction == "none":
             g = g[ctx.rank_offset:ctx.rank_offset + ctx.local_n]
+        if ctx.on_gpu:
+            (acts,) = ctx.saved_tensors
+            sdt = torch.float64 if acts.dtype == torch.float64 else torch.float32
+            scale = (g.reshape(-1).to(device=acts.device, dtype=sdt) * ctx.scale).to(sdt).expand(acts.size(0)).contiguous()
+            grads = torch.empty_like(acts)
+            warp_rnnt.gpu_rnnt_bwd(acts, grads, scale, ctx.workspace, ctx.blank)
+            return grads, None, None, None, None, None, None
         g = g.reshape(-1, 1, 1, 1).to(ctx.grads)
-        return ctx.grads.mul_(g), None, None, None, None, None, None
+        if not isinstance(ctx.scale, float) or ctx.scale != 1.0:
+            g = g * ctx.scale
+        return ctx.grads.mul_(g.to(ctx.grads.dtype)), None, None, None, None, None, None
 
 
 def sharded_rnnt_loss(acts, labels, act_lens, label_lens, blank=0, reduction="mean", group=None):

@@ -88,7 +88,7 @@ static void prof_accumulate() {
 // measured best; see profiles/).  sw = waves per block of the row-stats kernel (2|4|8),
 // nta = non-temporal stats loads, gmax = grid cap of the flat gradient kernel, rows = 1 forces
 // the row-form gradient kernel.
-struct Tune { int gw = 4, sw = 4, nta = 1, gmax = 4194304, rows = 0, tile = 1, tilekb = 48, ppt = 2; };
+struct Tune { int gw = 4, sw = 4, nta = 1, gmax = 4194304, rows = 0, tile = 1, tilekb = 48, ppt = 2, skew = -1; };
 static Tune g_tune;
 static bool g_tune_read = false;
 static const Tune& tune() {
@@ -101,7 +101,7 @@ static const Tune& tune() {
             };
             get("gw", g_tune.gw); get("sw", g_tune.sw); get("nta", g_tune.nta);
             get("gmax", g_tune.gmax); get("rows", g_tune.rows); get("tile", g_tune.tile);
-            get("tilekb", g_tune.tilekb); get("ppt", g_tune.ppt);
+            get("tilekb", g_tune.tilekb); get("ppt", g_tune.ppt); get("skew", g_tune.skew);
         }
     }
     return g_tune;
@@ -175,11 +175,15 @@ static rnntStatus_t run_gpu(const typename Tag::store* acts, typename Tag::store
         const size_t lds = RT * row_bytes + 32;
         const unsigned long long Rall = static_cast<unsigned long long>(N) * cells_per_sample;
         const unsigned tgrid = static_cast<unsigned>((Rall + RT - 1) / RT);
+        // large lattices: coalesced natural-order records (parked in the not-yet-used row table)
+        // + an LDS-tiled natural->skewed pass instead of two scattered stores per row
+        const bool via_natural = tn.skew >= 0 ? tn.skew != 0 : Rall >= (1ull << 20);
+        Cell<C>* natural = via_natural ? rowtab : nullptr;
         if (lds <= 64 * 1024) {
             tiled = true;
 #define RNNT_TILE(GG)                                                                                   \
     hipLaunchKernelGGL((row_stats_tile_kernel<Tag, GG>), dim3(tgrid), dim3(256), lds, stream, acts, labels, \
-                       input_lengths, label_lengths, lp2, logz, Rall, maxT, maxU, Up, A, blank)
+                       input_lengths, label_lengths, lp2, logz, natural, Rall, maxT, maxU, Up, A, blank)
             switch (G) {
                 case 1: RNNT_TILE(1); break;
                 case 2: RNNT_TILE(2); break;
@@ -190,6 +194,11 @@ static rnntStatus_t run_gpu(const typename Tag::store* acts, typename Tag::store
                 default: RNNT_TILE(64); break;
             }
 #undef RNNT_TILE
+            if (via_natural) {
+                RNNT_LAUNCH_CHECK();
+                const dim3 sgrid((maxU + kSkewU - 1) / kSkewU, (maxT + kSkewT - 1) / kSkewT, N);
+                hipLaunchKernelGGL((skew_kernel<C>), sgrid, dim3(256), 0, stream, rowtab, lp2, logz, maxT, maxU, Up);
+            }
         }
     }
     if (!tiled) {

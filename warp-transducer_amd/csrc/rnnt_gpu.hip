@@ -108,83 +108,73 @@ static const Tune& tune() {
 }
 
 // ----------------------------------------------------------------------------- launch
-#define RNNT_LAUNCH_CHECK()                                        \
-    do {                                                           \
-        if (hipGetLastError() != hipSuccess) return RNNT_STATUS_EXECUTION_FAILED; \
-    } while (0)
+// Everything one call needs: problem dimensions, the carved workspace, the stream.
+template <typename C> struct Plan {
+    int N, maxT, maxU, Up, A, blank;
+    int cells_per_sample;          // maxT * maxU
+    hipStream_t stream;
+    const int *labels, *input_lengths, *label_lengths;
+    LogPair<C>* lp2; C *logz, *alpha, *beta; Cell<C>* rowtab;
+    double *offa, *offb, *llf, *llb;
+    C* costs_dev;
+    bool failed = false;
+    void check() { if (hipGetLastError() != hipSuccess) failed = true; }
+};
 
+template <typename C>
+static bool make_plan(Plan<C>& p, int A, int N, const rnntOptions& opt, void* workspace, const int* labels,
+                      const int* label_lengths, const int* input_lengths, C* costs_device_out) {
+    p.N = N; p.maxT = opt.maxT; p.maxU = opt.maxU; p.A = A; p.blank = opt.blank_label;
+    if (p.blank < 0 || p.blank >= A) return false;
+    if (p.maxU > 1024) return false;               // one lane per label position (as the reference)
+    if (static_cast<long long>(p.maxT) * p.maxU > 0x7fffffffLL / 4) return false;
+    if (N > 65535) return false;
+    p.Up = ((p.maxU + 63) / 64) * 64;
+    p.cells_per_sample = p.maxT * p.maxU;
+    p.stream = reinterpret_cast<hipStream_t>(opt.stream);
+    p.labels = labels; p.input_lengths = input_lengths; p.label_lengths = label_lengths;
+    const Layout lay = make_layout(p.maxT, p.maxU, N, sizeof(C));
+    char* ws = reinterpret_cast<char*>(align_up(reinterpret_cast<size_t>(workspace)));
+    p.lp2 = reinterpret_cast<LogPair<C>*>(ws + lay.lp2);
+    p.logz = reinterpret_cast<C*>(ws + lay.logz);
+    p.alpha = reinterpret_cast<C*>(ws + lay.alpha);
+    p.rowtab = reinterpret_cast<Cell<C>*>(ws + lay.rowtab);
+    p.beta = reinterpret_cast<C*>(ws + lay.beta);
+    p.offa = reinterpret_cast<double*>(ws + lay.offa);
+    p.offb = reinterpret_cast<double*>(ws + lay.offb);
+    p.llf = reinterpret_cast<double*>(ws + lay.llf);
+    p.llb = reinterpret_cast<double*>(ws + lay.llb);
+    p.costs_dev = costs_device_out ? costs_device_out : reinterpret_cast<C*>(ws + lay.costs);
+    return true;
+}
+
+// Stage 1 (materialised path): log-softmax statistics of every (b,t,u) row.
 template <typename Tag>
-static rnntStatus_t run_gpu(const typename Tag::store* acts, typename Tag::store* grads,
-                            const int* labels, const int* label_lengths, const int* input_lengths,
-                            int A, int N, typename Tag::comp* costs_host,
-                            typename Tag::comp* costs_device_out, const typename Tag::comp* grad_scale,
-                            void* workspace, const rnntOptions& opt, int phases = 3, int want_grad = -1) {
-    // phases: bit 0 = forward part (row statistics, lattice, and -- when gradients are wanted --
-    // the coefficient table), bit 1 = gradient kernel.  The two-call form (compute_rnnt_loss_fwd /
-    // _bwd) keeps only the workspace alive between them.
+static void launch_row_stats(Plan<typename Tag::comp>& p, const typename Tag::store* acts, int vec_ok) {
     using S = typename Tag::store;
     using C = typename Tag::comp;
-    const int maxT = opt.maxT, maxU = opt.maxU, blank = opt.blank_label;
-    if (blank < 0 || blank >= A) return RNNT_STATUS_INVALID_VALUE;
-    if (maxU > 1024) return RNNT_STATUS_INVALID_VALUE;   // one lane per label position (as the reference)
-    if (static_cast<long long>(maxT) * maxU > 0x7fffffffLL / 4) return RNNT_STATUS_INVALID_VALUE;
-    if (N > 65535) return RNNT_STATUS_INVALID_VALUE;
-    hipStream_t stream = reinterpret_cast<hipStream_t>(opt.stream);
-    const bool training = want_grad < 0 ? grads != nullptr : want_grad != 0;
-    const bool do_fwd = (phases & 1) != 0, do_bwd = (phases & 2) != 0 && training;
-    if (do_bwd && grads == nullptr) return RNNT_STATUS_INVALID_VALUE;
-
-    const Layout lay = make_layout(maxT, maxU, N, sizeof(C));
-    char* ws = reinterpret_cast<char*>(align_up(reinterpret_cast<size_t>(workspace)));
-    auto* lp2 = reinterpret_cast<LogPair<C>*>(ws + lay.lp2);
-    auto* logz = reinterpret_cast<C*>(ws + lay.logz);
-    auto* alpha = reinterpret_cast<C*>(ws + lay.alpha);
-    auto* rowtab = reinterpret_cast<Cell<C>*>(ws + lay.rowtab);
-    auto* beta = reinterpret_cast<C*>(ws + lay.beta);
-    auto* offa = reinterpret_cast<double*>(ws + lay.offa);
-    auto* offb = reinterpret_cast<double*>(ws + lay.offb);
-    auto* llf = reinterpret_cast<double*>(ws + lay.llf);
-    auto* llb = reinterpret_cast<double*>(ws + lay.llb);
-    C* costs_dev = costs_device_out ? costs_device_out : reinterpret_cast<C*>(ws + lay.costs);
-
-    // 16-byte packets need acts and grads rows to share their alignment phase.
-    const uintptr_t pa = reinterpret_cast<uintptr_t>(acts);
-    const uintptr_t pg = reinterpret_cast<uintptr_t>(grads);
-    int vec_ok = (pa % sizeof(S) == 0) ? 1 : 0;
-    if (grads != nullptr && ((pa ^ pg) & 15u)) vec_ok = 0;
-
-    const bool prof = prof_prepare();
-    auto mark = [&](int i) { if (prof) (void)hipEventRecord(g_prof.ev[i], stream); };
-
     const Tune& tn = tune();
-    const int cells_per_sample = maxT * maxU;
-    auto row_grid = [&](int waves) { return dim3((cells_per_sample + waves - 1) / waves, N); };
-    const int Up = ((maxU + 63) / 64) * 64;
-    const int lat_threads = Up;
-
-    mark(0);
-    const size_t row_bytes = static_cast<size_t>(A) * sizeof(S);
-    if (do_fwd) {
-    bool tiled = false;
+    const size_t row_bytes = static_cast<size_t>(p.A) * sizeof(S);
     if (tn.tile && vec_ok && row_bytes <= static_cast<size_t>(kTileMaxRowBytes)) {
-        // smallest lane group G whose tile of 256/G rows fits the LDS budget
+        // short rows: LDS-tile kernel; smallest lane group G whose tile of 256/G rows fits the budget
         const size_t budget = static_cast<size_t>(tn.tilekb) * 1024;
         int G = 1;
         while (G < 64 && (256 / G) * row_bytes + 32 > budget) G *= 2;
         const int RT = 256 / G;
         const size_t lds = RT * row_bytes + 32;
-        const unsigned long long Rall = static_cast<unsigned long long>(N) * cells_per_sample;
+        const unsigned long long Rall = static_cast<unsigned long long>(p.N) * p.cells_per_sample;
         const unsigned tgrid = static_cast<unsigned>((Rall + RT - 1) / RT);
-        // large lattices: coalesced natural-order records (parked in the not-yet-used row table)
-        // + an LDS-tiled natural->skewed pass instead of two scattered stores per row
-        // (measured: +10 % on the stats stage for 2 KB rows, neutral to slightly negative for 200-byte rows)
-        const bool via_natural = tn.skew >= 0 ? tn.skew != 0 : (Rall >= (1ull << 20) && row_bytes >= 512);
-        Cell<C>* natural = via_natural ? rowtab : nullptr;
         if (lds <= 64 * 1024) {
-            tiled = true;
-#define RNNT_TILE(GG)                                                                                   \
-    hipLaunchKernelGGL((row_stats_tile_kernel<Tag, GG>), dim3(tgrid), dim3(256), lds, stream, acts, labels, \
-                       input_lengths, label_lengths, lp2, logz, natural, Rall, maxT, maxU, Up, A, blank)
+            // large lattices of not-too-short rows: coalesced natural-order records (parked in the
+            // not-yet-used row table) + an LDS-tiled natural->skewed pass instead of two scattered
+            // stores per row (measured: +10 % on this stage for 2 KB rows, neutral to slightly
+            // negative for 200-byte rows)
+            const bool via_natural = tn.skew >= 0 ? tn.skew != 0 : (Rall >= (1ull << 20) && row_bytes >= 512);
+            Cell<C>* natural = via_natural ? p.rowtab : nullptr;
+#define RNNT_TILE(GG)                                                                                       \
+    hipLaunchKernelGGL((row_stats_tile_kernel<Tag, GG>), dim3(tgrid), dim3(256), lds, p.stream, acts, p.labels, \
+                       p.input_lengths, p.label_lengths, p.lp2, p.logz, natural, Rall, p.maxT, p.maxU, p.Up,  \
+                       p.A, p.blank)
             switch (G) {
                 case 1: RNNT_TILE(1); break;
                 case 2: RNNT_TILE(2); break;
@@ -195,87 +185,138 @@ static rnntStatus_t run_gpu(const typename Tag::store* acts, typename Tag::store
                 default: RNNT_TILE(64); break;
             }
 #undef RNNT_TILE
+            p.check();
             if (via_natural) {
-                RNNT_LAUNCH_CHECK();
-                const dim3 sgrid((maxU + kSkewU - 1) / kSkewU, (maxT + kSkewT - 1) / kSkewT, N);
-                hipLaunchKernelGGL((skew_kernel<C>), sgrid, dim3(256), 0, stream, rowtab, lp2, logz, maxT, maxU, Up);
+                const dim3 sgrid((p.maxU + kSkewU - 1) / kSkewU, (p.maxT + kSkewT - 1) / kSkewT, p.N);
+                hipLaunchKernelGGL((skew_kernel<C>), sgrid, dim3(256), 0, p.stream, p.rowtab, p.lp2, p.logz, p.maxT,
+                                   p.maxU, p.Up);
+                p.check();
             }
+            return;
         }
     }
-    if (!tiled) {
-#define RNNT_STATS(W, NT)                                                                             \
-    hipLaunchKernelGGL((row_stats_kernel<Tag, W, NT>), row_grid(W), dim3(W * 64), 0, stream, acts, labels, \
-                       input_lengths, label_lengths, lp2, logz, maxT, maxU, Up, A, blank, vec_ok)
-        if (tn.nta) { if (tn.sw == 8) RNNT_STATS(8, true); else if (tn.sw == 2) RNNT_STATS(2, true); else RNNT_STATS(4, true); }
-        else { if (tn.sw == 8) RNNT_STATS(8, false); else if (tn.sw == 2) RNNT_STATS(2, false); else RNNT_STATS(4, false); }
+    // long rows: one wavefront per row
+#define RNNT_STATS(WV, NT)                                                                                       \
+    hipLaunchKernelGGL((row_stats_kernel<Tag, WV, NT>), dim3((p.cells_per_sample + WV - 1) / WV, p.N), dim3(WV * 64), \
+                       0, p.stream, acts, p.labels, p.input_lengths, p.label_lengths, p.lp2, p.logz, p.maxT, p.maxU, \
+                       p.Up, p.A, p.blank, vec_ok)
+    if (tn.nta) { if (tn.sw == 8) RNNT_STATS(8, true); else if (tn.sw == 2) RNNT_STATS(2, true); else RNNT_STATS(4, true); }
+    else { if (tn.sw == 8) RNNT_STATS(8, false); else if (tn.sw == 2) RNNT_STATS(2, false); else RNNT_STATS(4, false); }
 #undef RNNT_STATS
-    }
-    RNNT_LAUNCH_CHECK();
-    mark(1);
-    const int dirs = training ? 2 : 1;
-#define RNNT_LATTICE(MW)                                                                                  \
-    hipLaunchKernelGGL((lattice_kernel<C, MW>), dim3(N * dirs), dim3(lat_threads), 0, stream, lp2, alpha, beta, \
-                       offa, offb, llf, llb, costs_dev, input_lengths, label_lengths, maxT, maxU, Up, dirs)
-    if (lat_threads == 64) RNNT_LATTICE(1);
-    else if (lat_threads <= 512) RNNT_LATTICE(8);
+    p.check();
+}
+
+// Stage 2: alpha (and, for gradients, beta) recursion; writes the costs.
+template <typename C> static void launch_lattice(Plan<C>& p, bool with_beta) {
+    const int dirs = with_beta ? 2 : 1;
+#define RNNT_LATTICE(MW)                                                                                         \
+    hipLaunchKernelGGL((lattice_kernel<C, MW>), dim3(p.N * dirs), dim3(p.Up), 0, p.stream, p.lp2, p.alpha, p.beta, \
+                       p.offa, p.offb, p.llf, p.llb, p.costs_dev, p.input_lengths, p.label_lengths, p.maxT, p.maxU, \
+                       p.Up, dirs)
+    if (p.Up == 64) RNNT_LATTICE(1);
+    else if (p.Up <= 512) RNNT_LATTICE(8);
     else RNNT_LATTICE(16);
 #undef RNNT_LATTICE
-    RNNT_LAUNCH_CHECK();
-    mark(2);
-    if (training) {
-        const long long skew_cells = static_cast<long long>(maxT + maxU - 1) * Up;
-        const dim3 cgrid(static_cast<unsigned>(((skew_cells + 255) / 256 + 7) / 8 * 8), N);   // multiple of 8: XCD-aware remap
-        hipLaunchKernelGGL((coef_kernel<C>), cgrid, dim3(256), 0, stream, lp2, logz, alpha, beta, offa, offb, llf,
-                           labels, input_lengths, label_lengths, rowtab, maxT, maxU, Up);
-        RNNT_LAUNCH_CHECK();
-    }
-    } else {   // !do_fwd
-        mark(1);
-        mark(2);
-    }
-    mark(3);
-    if (do_bwd) {
-        const unsigned long long R = static_cast<unsigned long long>(N) * cells_per_sample;
-        const unsigned long long E = R * A;
-        constexpr int V = Vec<Tag>::N;
-        const bool flat_ok = vec_ok && (pa & 15u) == 0 && (pg & 15u) == 0 && A <= (1 << 23) && !tn.rows;
-        if (flat_ok) {
-            const unsigned long long npk = E / V;
-            const int ppt = (tn.ppt == 1 || tn.ppt == 4) ? tn.ppt : 2;
-            const unsigned long long cpk = static_cast<unsigned long long>(ppt) * 256;
-            const unsigned long long nchunks = (npk + cpk - 1) / cpk;
-            const unsigned grid = static_cast<unsigned>(nchunks < static_cast<unsigned long long>(tn.gmax)
-                                                            ? (nchunks ? nchunks : 1) : tn.gmax);
-            const unsigned long long stride = static_cast<unsigned long long>(grid) * cpk * V;
-            const unsigned long long dq = stride / A;
-            const int drem = static_cast<int>(stride % A);
-            const float invA = 1.0f / static_cast<float>(A);
-#define RNNT_FLAT(SC, PP, PS)                                                                                  \
-    hipLaunchKernelGGL((grad_flat_kernel<Tag, SC, PP, PS>), dim3(grid), dim3(256), 0, stream, acts, grads, rowtab, \
-                       grad_scale, E, R, A, blank, cells_per_sample, invA, dq, drem)
-            const bool padskip = row_bytes >= 8192;     // skip reading padded rows only where rows are long
-            if (grad_scale) { if (padskip) RNNT_FLAT(true, 2, true); else RNNT_FLAT(true, 2, false); }
-            else if (ppt == 1) RNNT_FLAT(false, 1, false);
-            else if (ppt == 4) RNNT_FLAT(false, 4, false);
-            else if (padskip) RNNT_FLAT(false, 2, true);
-            else RNNT_FLAT(false, 2, false);
+    p.check();
+}
+
+// Stage 3: gradient coefficients per row into the natural-order row table.
+template <typename C> static void launch_coef(Plan<C>& p) {
+    const long long skew_cells = static_cast<long long>(p.maxT + p.maxU - 1) * p.Up;
+    const dim3 cgrid(static_cast<unsigned>(((skew_cells + 255) / 256 + 7) / 8 * 8), p.N);   // multiple of 8: XCD-aware remap
+    hipLaunchKernelGGL((coef_kernel<C>), cgrid, dim3(256), 0, p.stream, p.lp2, p.logz, p.alpha, p.beta, p.offa, p.offb,
+                       p.llf, p.labels, p.input_lengths, p.label_lengths, p.rowtab, p.maxT, p.maxU, p.Up);
+    p.check();
+}
+
+// Stage 4 (materialised path): dense gradient write-back.
+template <typename Tag>
+static void launch_grad(Plan<typename Tag::comp>& p, const typename Tag::store* acts, typename Tag::store* grads,
+                        const typename Tag::comp* grad_scale, int vec_ok) {
+    using S = typename Tag::store;
+    constexpr int V = Vec<Tag>::N;
+    const Tune& tn = tune();
+    const uintptr_t pa = reinterpret_cast<uintptr_t>(acts), pg = reinterpret_cast<uintptr_t>(grads);
+    const size_t row_bytes = static_cast<size_t>(p.A) * sizeof(S);
+    const unsigned long long R = static_cast<unsigned long long>(p.N) * p.cells_per_sample;
+    const unsigned long long E = R * p.A;
+    const bool flat_ok = vec_ok && (pa & 15u) == 0 && (pg & 15u) == 0 && p.A <= (1 << 23) && !tn.rows;
+    if (flat_ok) {
+        const unsigned long long npk = E / V;
+        const int ppt = (tn.ppt == 1 || tn.ppt == 4) ? tn.ppt : 2;
+        const unsigned long long cpk = static_cast<unsigned long long>(ppt) * 256;
+        const unsigned long long nchunks = (npk + cpk - 1) / cpk;
+        const unsigned grid = static_cast<unsigned>(nchunks < static_cast<unsigned long long>(tn.gmax)
+                                                        ? (nchunks ? nchunks : 1) : tn.gmax);
+        const unsigned long long stride = static_cast<unsigned long long>(grid) * cpk * V;
+        const unsigned long long dq = stride / p.A;
+        const int drem = static_cast<int>(stride % p.A);
+        const float invA = 1.0f / static_cast<float>(p.A);
+#define RNNT_FLAT(SC, PP, PS)                                                                                       \
+    hipLaunchKernelGGL((grad_flat_kernel<Tag, SC, PP, PS>), dim3(grid), dim3(256), 0, p.stream, acts, grads, p.rowtab, \
+                       grad_scale, E, R, p.A, p.blank, p.cells_per_sample, invA, dq, drem)
+        const bool padskip = row_bytes >= 8192;     // skip reading padded rows only where rows are long
+        if (grad_scale) { if (padskip) RNNT_FLAT(true, 2, true); else RNNT_FLAT(true, 2, false); }
+        else if (ppt == 1) RNNT_FLAT(false, 1, false);
+        else if (ppt == 4) RNNT_FLAT(false, 4, false);
+        else if (padskip) RNNT_FLAT(false, 2, true);
+        else RNNT_FLAT(false, 2, false);
 #undef RNNT_FLAT
-        } else {
-            if (grad_scale)
-                hipLaunchKernelGGL((grad_rows_kernel<Tag, 4, true>), row_grid(4), dim3(256), 0, stream, acts, grads,
-                                   rowtab, grad_scale, maxT, maxU, A, blank, vec_ok);
-            else
-                hipLaunchKernelGGL((grad_rows_kernel<Tag, 4, false>), row_grid(4), dim3(256), 0, stream, acts, grads,
-                                   rowtab, grad_scale, maxT, maxU, A, blank, vec_ok);
-        }
-        RNNT_LAUNCH_CHECK();
+    } else {
+        const dim3 rg((p.cells_per_sample + 3) / 4, p.N);
+        if (grad_scale)
+            hipLaunchKernelGGL((grad_rows_kernel<Tag, 4, true>), rg, dim3(256), 0, p.stream, acts, grads, p.rowtab,
+                               grad_scale, p.maxT, p.maxU, p.A, p.blank, vec_ok);
+        else
+            hipLaunchKernelGGL((grad_rows_kernel<Tag, 4, false>), rg, dim3(256), 0, p.stream, acts, grads, p.rowtab,
+                               grad_scale, p.maxT, p.maxU, p.A, p.blank, vec_ok);
     }
+    p.check();
+}
+
+// The materialised path.  phases: bit 0 = forward part (row statistics, lattice and -- when gradients
+// are wanted -- the coefficient table), bit 1 = gradient kernel; the two-call form
+// (compute_rnnt_loss_fwd / _bwd) keeps only the workspace alive in between.  want_grad < 0: decided by
+// `grads != nullptr` (the reference's "gradients == NULL means score only").
+template <typename Tag>
+static rnntStatus_t run_gpu(const typename Tag::store* acts, typename Tag::store* grads,
+                            const int* labels, const int* label_lengths, const int* input_lengths,
+                            int A, int N, typename Tag::comp* costs_host,
+                            typename Tag::comp* costs_device_out, const typename Tag::comp* grad_scale,
+                            void* workspace, const rnntOptions& opt, int phases = 3, int want_grad = -1) {
+    using S = typename Tag::store;
+    using C = typename Tag::comp;
+    Plan<C> p;
+    if (!make_plan(p, A, N, opt, workspace, labels, label_lengths, input_lengths, costs_device_out))
+        return RNNT_STATUS_INVALID_VALUE;
+    const bool training = want_grad < 0 ? grads != nullptr : want_grad != 0;
+    const bool do_fwd = (phases & 1) != 0, do_bwd = (phases & 2) != 0 && training;
+    if (do_bwd && grads == nullptr) return RNNT_STATUS_INVALID_VALUE;
+
+    // 16-byte packets need acts and grads rows to share their alignment phase.
+    const uintptr_t pa = reinterpret_cast<uintptr_t>(acts), pg = reinterpret_cast<uintptr_t>(grads);
+    int vec_ok = (pa % sizeof(S) == 0) ? 1 : 0;
+    if (grads != nullptr && ((pa ^ pg) & 15u)) vec_ok = 0;
+
+    const bool prof = prof_prepare();
+    auto mark = [&](int i) { if (prof) (void)hipEventRecord(g_prof.ev[i], p.stream); };
+
+    mark(0);
+    if (do_fwd) launch_row_stats<Tag>(p, acts, vec_ok);
+    mark(1);
+    if (do_fwd) launch_lattice(p, training);
+    mark(2);
+    if (do_fwd && training) launch_coef(p);
+    mark(3);
+    if (do_bwd) launch_grad<Tag>(p, acts, grads, grad_scale, vec_ok);
     mark(4);
+    if (p.failed) return RNNT_STATUS_EXECUTION_FAILED;
 
     if (costs_host) {
-        if (hipMemcpyAsync(costs_host, costs_dev, sizeof(C) * N, hipMemcpyDeviceToHost, stream) != hipSuccess)
+        // the reference contract: costs in HOST memory, call returns after a stream sync (gpu_rnnt.h:208-213)
+        if (hipMemcpyAsync(costs_host, p.costs_dev, sizeof(C) * N, hipMemcpyDeviceToHost, p.stream) != hipSuccess)
             return RNNT_STATUS_MEMOPS_FAILED;
-        if (hipStreamSynchronize(stream) != hipSuccess) return RNNT_STATUS_EXECUTION_FAILED;
+        if (hipStreamSynchronize(p.stream) != hipSuccess) return RNNT_STATUS_EXECUTION_FAILED;
         if (prof) prof_accumulate();
     } else if (prof) {
         g_prof.pending = true;     // the caller synchronises, then calls rnnt_profile_collect()
@@ -284,82 +325,51 @@ static rnntStatus_t run_gpu(const typename Tag::store* acts, typename Tag::store
 }
 
 // ----------------------------------------------------------------------------- additive joint
-// f (N,maxT,A) + g (N,maxU,A) -> costs, df, dg without the (N,T,U,A) tensor (rnnt_joint_kernels.h).
+// f (N,maxT,A) + g (N,maxU,A) -> costs, df, dg without the (N,T,U,A) tensor (rnnt_joint_kernels.h):
+// the two streaming stages are replaced, lattice and coefficients are the same launches as above.
 // Enqueue only: device costs, no host copy, no synchronisation.  fp32.
 static rnntStatus_t run_gpu_joint(const float* f, const float* g, float* df, float* dg, const int* labels,
                                   const int* label_lengths, const int* input_lengths, int A, int N,
                                   float* costs_device, void* workspace, const rnntOptions& opt) {
-    using C = float;
-    const int maxT = opt.maxT, maxU = opt.maxU, blank = opt.blank_label;
-    if (blank < 0 || blank >= A) return RNNT_STATUS_INVALID_VALUE;
-    if (maxU > 1024 || N > 65535) return RNNT_STATUS_INVALID_VALUE;
-    if (static_cast<long long>(maxT) * maxU > 0x7fffffffLL / 4) return RNNT_STATUS_INVALID_VALUE;
+    Plan<float> p;
+    if (!make_plan(p, A, N, opt, workspace, labels, label_lengths, input_lengths, costs_device))
+        return RNNT_STATUS_INVALID_VALUE;
     if ((df == nullptr) != (dg == nullptr)) return RNNT_STATUS_INVALID_VALUE;
-    hipStream_t stream = reinterpret_cast<hipStream_t>(opt.stream);
     const bool training = df != nullptr;
-
-    const Layout lay = make_layout(maxT, maxU, N, sizeof(C));
-    char* ws = reinterpret_cast<char*>(align_up(reinterpret_cast<size_t>(workspace)));
-    auto* lp2 = reinterpret_cast<LogPair<C>*>(ws + lay.lp2);
-    auto* logz = reinterpret_cast<C*>(ws + lay.logz);
-    auto* alpha = reinterpret_cast<C*>(ws + lay.alpha);
-    auto* rowtab = reinterpret_cast<Cell<C>*>(ws + lay.rowtab);
-    auto* beta = reinterpret_cast<C*>(ws + lay.beta);
-    auto* offa = reinterpret_cast<double*>(ws + lay.offa);
-    auto* offb = reinterpret_cast<double*>(ws + lay.offb);
-    auto* llf = reinterpret_cast<double*>(ws + lay.llf);
-    auto* llb = reinterpret_cast<double*>(ws + lay.llb);
-
     const bool prof = prof_prepare();
-    auto mark = [&](int i) { if (prof) (void)hipEventRecord(g_prof.ev[i], stream); };
-    const int Up = ((maxU + 63) / 64) * 64;
-    const int cells_per_sample = maxT * maxU;
-    bool failed = false;
-    auto check = [&]() { if (hipGetLastError() != hipSuccess) failed = true; };
+    auto mark = [&](int i) { if (prof) (void)hipEventRecord(g_prof.ev[i], p.stream); };
 
     mark(0);
     if (training &&
-        hipMemsetAsync(dg, 0, sizeof(float) * static_cast<size_t>(N) * maxU * A, stream) != hipSuccess)
+        hipMemsetAsync(dg, 0, sizeof(float) * static_cast<size_t>(N) * p.maxU * A, p.stream) != hipSuccess)
         return RNNT_STATUS_MEMOPS_FAILED;            // dg is accumulated with atomics
     {
-        const int per_row = maxU > 128 ? 1 : 0;
-        const int nT = per_row ? 1 : (256 + maxU - 1) / maxU + 1;
-        const int nU = per_row ? (maxU < 256 ? maxU : 256) : maxU;
+        const int per_row = p.maxU > 128 ? 1 : 0;
+        const int nT = per_row ? 1 : (256 + p.maxU - 1) / p.maxU + 1;
+        const int nU = per_row ? (p.maxU < 256 ? p.maxU : 256) : p.maxU;
         const size_t lds = static_cast<size_t>(nT + nU) * kJointPad * sizeof(float);
-        const unsigned gx = per_row ? static_cast<unsigned>(maxT) * ((maxU + 255) / 256)
-                                    : static_cast<unsigned>((cells_per_sample + 255) / 256);
-        hipLaunchKernelGGL(joint_stats_kernel, dim3(gx, N), dim3(256), lds, stream, f, g, labels, input_lengths,
-                           label_lengths, lp2, logz, maxT, maxU, Up, A, blank, per_row);
-        check();
+        const unsigned gx = per_row ? static_cast<unsigned>(p.maxT) * ((p.maxU + 255) / 256)
+                                    : static_cast<unsigned>((p.cells_per_sample + 255) / 256);
+        hipLaunchKernelGGL(joint_stats_kernel, dim3(gx, N), dim3(256), lds, p.stream, f, g, labels, input_lengths,
+                           label_lengths, p.lp2, p.logz, p.maxT, p.maxU, p.Up, A, p.blank, per_row);
+        p.check();
     }
     mark(1);
-    const int dirs = training ? 2 : 1;
-#define RNNT_LATTICE(MW)                                                                                  \
-    hipLaunchKernelGGL((lattice_kernel<C, MW>), dim3(N * dirs), dim3(Up), 0, stream, lp2, alpha, beta, offa, \
-                       offb, llf, llb, costs_device, input_lengths, label_lengths, maxT, maxU, Up, dirs)
-    if (Up == 64) RNNT_LATTICE(1);
-    else if (Up <= 512) RNNT_LATTICE(8);
-    else RNNT_LATTICE(16);
-#undef RNNT_LATTICE
-    check();
+    launch_lattice(p, training);
     mark(2);
     if (training) {
-        const long long skew_cells = static_cast<long long>(maxT + maxU - 1) * Up;
-        const dim3 cgrid(static_cast<unsigned>(((skew_cells + 255) / 256 + 7) / 8 * 8), N);
-        hipLaunchKernelGGL((coef_kernel<C>), cgrid, dim3(256), 0, stream, lp2, logz, alpha, beta, offa, offb, llf,
-                           labels, input_lengths, label_lengths, rowtab, maxT, maxU, Up);
-        check();
+        launch_coef(p);
         mark(3);
-        const dim3 ggrid((A + 63) / 64, (maxT + kJointTS - 1) / kJointTS, N);
-        hipLaunchKernelGGL(joint_grad_kernel, ggrid, dim3(256), 0, stream, f, g, rowtab, labels, input_lengths,
-                           label_lengths, df, dg, maxT, maxU, A, blank);
-        check();
+        const dim3 ggrid((A + 63) / 64, (p.maxT + kJointTS - 1) / kJointTS, N);
+        hipLaunchKernelGGL(joint_grad_kernel, ggrid, dim3(256), 0, p.stream, f, g, p.rowtab, labels, input_lengths,
+                           label_lengths, df, dg, p.maxT, p.maxU, A, p.blank);
+        p.check();
     } else {
         mark(3);
     }
     mark(4);
     if (prof) g_prof.pending = true;
-    return failed ? RNNT_STATUS_EXECUTION_FAILED : RNNT_STATUS_SUCCESS;
+    return p.failed ? RNNT_STATUS_EXECUTION_FAILED : RNNT_STATUS_SUCCESS;
 }
 
 static bool bad_args(const void* acts, const int* labels, const int* label_lengths,

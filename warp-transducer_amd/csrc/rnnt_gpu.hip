@@ -87,8 +87,10 @@ static void prof_accumulate() {
 // Development A/B switches, read once from RNNT_TUNE="key=value,key=value" (defaults are the
 // measured best; see profiles/).  sw = waves per block of the row-stats kernel (2|4|8),
 // nta = non-temporal stats loads, gmax = grid cap of the flat gradient kernel, rows = 1 forces
-// the row-form gradient kernel.
-struct Tune { int gw = 4, sw = 4, nta = 1, gmax = 4194304, rows = 0, tile = 1, tilekb = 48, ppt = 2, skew = -1; };
+// the row-form gradient kernel, tile / tilekb = LDS-tile stats kernel on/off and its LDS budget,
+// ppt = packets per thread of the flat gradient kernel, skew = 0/1 forces the natural-order +
+// skew_kernel route of the tile path off/on (-1: heuristic).
+struct Tune { int sw = 4, nta = 1, gmax = 4194304, rows = 0, tile = 1, tilekb = 48, ppt = 2, skew = -1; };
 static Tune g_tune;
 static bool g_tune_read = false;
 static const Tune& tune() {
@@ -99,7 +101,7 @@ static const Tune& tune() {
                 const char* p = strstr(e, key);
                 if (p && p[strlen(key)] == '=') dst = atoi(p + strlen(key) + 1);
             };
-            get("gw", g_tune.gw); get("sw", g_tune.sw); get("nta", g_tune.nta);
+            get("sw", g_tune.sw); get("nta", g_tune.nta);
             get("gmax", g_tune.gmax); get("rows", g_tune.rows); get("tile", g_tune.tile);
             get("tilekb", g_tune.tilekb); get("ppt", g_tune.ppt); get("skew", g_tune.skew);
         }

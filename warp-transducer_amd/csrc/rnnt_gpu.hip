@@ -26,7 +26,7 @@ constexpr size_t kAlign = 256;
 static inline size_t align_up(size_t x) { return (x + kAlign - 1) / kAlign * kAlign; }
 
 struct Layout {
-    size_t lp2, logz, alpha, rowtab, beta, offa, offb, llf, llb, costs, total;
+    size_t lp2, logz, alpha, rowtab, beta, offa, offb, llf, llb, costs, rowmax, total;
 };
 
 // lat = bytes of one lattice value (4: fp32 lattice for 16/32-bit activations, 8: fp64).
@@ -47,6 +47,7 @@ static Layout make_layout(int maxT, int maxU, int N, size_t lat) {
     l.llf = o;   o = align_up(o + N * sizeof(double));
     l.llb = o;   o = align_up(o + N * sizeof(double));
     l.costs = o; o = align_up(o + N * sizeof(double));
+    l.rowmax = o; o = align_up(o + (static_cast<size_t>(maxT) + maxU) * N * sizeof(float));   // additive joint: row maxima of f, g
     l.total = o + kAlign;                       // slack to align the caller's base pointer
     return l;
 }
@@ -118,6 +119,7 @@ template <typename C> struct Plan {
     const int *labels, *input_lengths, *label_lengths;
     LogPair<C>* lp2; C *logz, *alpha, *beta; Cell<C>* rowtab;
     double *offa, *offb, *llf, *llb;
+    float* rowmax;
     C* costs_dev;
     bool failed = false;
     void check() { if (hipGetLastError() != hipSuccess) failed = true; }
@@ -146,6 +148,7 @@ static bool make_plan(Plan<C>& p, int A, int N, const rnntOptions& opt, void* wo
     p.offb = reinterpret_cast<double*>(ws + lay.offb);
     p.llf = reinterpret_cast<double*>(ws + lay.llf);
     p.llb = reinterpret_cast<double*>(ws + lay.llb);
+    p.rowmax = reinterpret_cast<float*>(ws + lay.rowmax);
     p.costs_dev = costs_device_out ? costs_device_out : reinterpret_cast<C*>(ws + lay.costs);
     return true;
 }
@@ -341,19 +344,32 @@ static rnntStatus_t run_gpu_joint(const float* f, const float* g, float* df, flo
     const bool prof = prof_prepare();
     auto mark = [&](int i) { if (prof) (void)hipEventRecord(g_prof.ev[i], p.stream); };
 
+    const int maxT = p.maxT, maxU = p.maxU;
+    const bool vec = (A % 4 == 0) && ((reinterpret_cast<uintptr_t>(f) | reinterpret_cast<uintptr_t>(g)) & 15u) == 0;
+    const int tilesT = (maxT + 31) / 32, tilesU = (maxU + 31) / 32, tiles = tilesT * tilesU;
     mark(0);
-    if (training &&
-        hipMemsetAsync(dg, 0, sizeof(float) * static_cast<size_t>(N) * p.maxU * A, p.stream) != hipSuccess)
-        return RNNT_STATUS_MEMOPS_FAILED;            // dg is accumulated with atomics
-    {
-        const int per_row = p.maxU > 128 ? 1 : 0;
-        const int nT = per_row ? 1 : (256 + p.maxU - 1) / p.maxU + 1;
-        const int nU = per_row ? (p.maxU < 256 ? p.maxU : 256) : p.maxU;
-        const size_t lds = static_cast<size_t>(nT + nU) * kJointPad * sizeof(float);
-        const unsigned gx = per_row ? static_cast<unsigned>(p.maxT) * ((p.maxU + 255) / 256)
-                                    : static_cast<unsigned>((p.cells_per_sample + 255) / 256);
-        hipLaunchKernelGGL(joint_stats_kernel, dim3(gx, N), dim3(256), lds, p.stream, f, g, labels, input_lengths,
-                           label_lengths, p.lp2, p.logz, p.maxT, p.maxU, p.Up, A, p.blank, per_row);
+    {   // row maxima, then the partition-function GEMM with the log-prob epilogue
+        const long long rows = static_cast<long long>(N) * (maxT + maxU);
+        const dim3 rgrid(static_cast<unsigned>((rows + 3) / 4));
+        if (vec)
+            hipLaunchKernelGGL(joint_rowmax_kernel<true>, rgrid, dim3(256), 0, p.stream, f, g, input_lengths,
+                               label_lengths, p.rowmax, maxT, maxU, A, N);
+        else
+            hipLaunchKernelGGL(joint_rowmax_kernel<false>, rgrid, dim3(256), 0, p.stream, f, g, input_lengths,
+                               label_lengths, p.rowmax, maxT, maxU, A, N);
+        p.check();
+        // vocabulary slices per tile: few tiles and a long contraction -> split it over 4 or 8 wavefronts
+        const long long all_tiles = static_cast<long long>(N) * tiles;
+        const int nchunk = (A + 15) / 16;
+        const int S = (all_tiles >= 4096 || nchunk < 32) ? 1 : ((all_tiles < 1024 && nchunk >= 64) ? 8 : 4);
+#define RNNT_JZ(SS, VV)                                                                                          \
+    hipLaunchKernelGGL((joint_z_kernel<SS, VV>), dim3(SS == 1 ? (tiles + 3) / 4 : tiles, N),                      \
+                       dim3(SS == 1 ? 256 : SS * 64), 0, p.stream, f, g, p.rowmax, labels, input_lengths,        \
+                       label_lengths, p.lp2, p.logz, maxT, maxU, p.Up, A, p.blank, tilesU, tiles, N)
+        if (S == 8) { if (vec) RNNT_JZ(8, true); else RNNT_JZ(8, false); }
+        else if (S == 4) { if (vec) RNNT_JZ(4, true); else RNNT_JZ(4, false); }
+        else { if (vec) RNNT_JZ(1, true); else RNNT_JZ(1, false); }
+#undef RNNT_JZ
         p.check();
     }
     mark(1);
@@ -362,9 +378,24 @@ static rnntStatus_t run_gpu_joint(const float* f, const float* g, float* df, flo
     if (training) {
         launch_coef(p);
         mark(3);
-        const dim3 ggrid((A + 63) / 64, (p.maxT + kJointTS - 1) / kJointTS, N);
-        hipLaunchKernelGGL(joint_grad_kernel, ggrid, dim3(256), 0, p.stream, f, g, p.rowtab, labels, input_lengths,
-                           label_lengths, df, dg, p.maxT, p.maxU, A, p.blank);
+        // gradient GEMMs (plain stores of every element, padding included), then the corrections
+        if (A >= 256) {
+            const unsigned gx = static_cast<unsigned>((A + 255) / 256);
+            hipLaunchKernelGGL(joint_df_kernel<2>, dim3(gx, tilesT, N), dim3(256), 0, p.stream, f, g, p.rowmax,
+                               p.rowtab, input_lengths, label_lengths, df, maxT, maxU, A, N);
+            hipLaunchKernelGGL(joint_dg_kernel<2>, dim3(gx, tilesU, N), dim3(256), 0, p.stream, f, g, p.rowmax,
+                               p.rowtab, input_lengths, label_lengths, dg, maxT, maxU, A, N);
+        } else {
+            const unsigned gx = static_cast<unsigned>((A + 127) / 128);
+            hipLaunchKernelGGL(joint_df_kernel<1>, dim3(gx, tilesT, N), dim3(256), 0, p.stream, f, g, p.rowmax,
+                               p.rowtab, input_lengths, label_lengths, df, maxT, maxU, A, N);
+            hipLaunchKernelGGL(joint_dg_kernel<1>, dim3(gx, tilesU, N), dim3(256), 0, p.stream, f, g, p.rowmax,
+                               p.rowtab, input_lengths, label_lengths, dg, maxT, maxU, A, N);
+        }
+        p.check();
+        hipLaunchKernelGGL(joint_fix_kernel, dim3((maxU + 63) / 64, (maxT + kJointFixT - 1) / kJointFixT, N),
+                           dim3(256), 0, p.stream, f, g, p.rowmax, p.rowtab, labels, input_lengths, label_lengths,
+                           df, dg, maxT, maxU, A, p.blank, N);
         p.check();
     } else {
         mark(3);

@@ -26,7 +26,7 @@ constexpr size_t kAlign = 256;
 static inline size_t align_up(size_t x) { return (x + kAlign - 1) / kAlign * kAlign; }
 
 struct Layout {
-    size_t lp2, logz, alpha, rowtab, beta, offa, offb, llf, llb, costs, rowmax, total;
+    size_t lp2, logz, alpha, rowtab, beta, offa, offb, llf, llb, costs, rowmax, wmat, total;
 };
 
 // lat = bytes of one lattice value (4: fp32 lattice for 16/32-bit activations, 8: fp64).
@@ -47,7 +47,9 @@ static Layout make_layout(int maxT, int maxU, int N, size_t lat) {
     l.llf = o;   o = align_up(o + N * sizeof(double));
     l.llb = o;   o = align_up(o + N * sizeof(double));
     l.costs = o; o = align_up(o + N * sizeof(double));
-    l.rowmax = o; o = align_up(o + (static_cast<size_t>(maxT) + maxU) * N * sizeof(float));   // additive joint: row maxima of f, g
+    // additive joint only: row maxima of f and g, dense weight matrix W (row stride = maxU rounded up to 4)
+    l.rowmax = o; o = align_up(o + (static_cast<size_t>(maxT) + maxU) * N * sizeof(float));
+    l.wmat = o;   o = align_up(o + static_cast<size_t>(maxT) * ((maxU + 3) / 4 * 4) * N * sizeof(float));
     l.total = o + kAlign;                       // slack to align the caller's base pointer
     return l;
 }
@@ -90,8 +92,10 @@ static void prof_accumulate() {
 // nta = non-temporal stats loads, gmax = grid cap of the flat gradient kernel, rows = 1 forces
 // the row-form gradient kernel, tile / tilekb = LDS-tile stats kernel on/off and its LDS budget,
 // ppt = packets per thread of the flat gradient kernel, skew = 0/1 forces the natural-order +
-// skew_kernel route of the tile path off/on (-1: heuristic).
-struct Tune { int sw = 4, nta = 1, gmax = 4194304, rows = 0, tile = 1, tilekb = 48, ppt = 2, skew = -1; };
+// skew_kernel route of the tile path off/on (-1: heuristic).  Additive joint: jfnk / jgnk = columns
+// per lane of the DF / DG kernels (0: widest the alignment allows), jfpf / jgpf = operand ping-pong.
+struct Tune { int sw = 4, nta = 1, gmax = 4194304, rows = 0, tile = 1, tilekb = 48, ppt = 2, skew = -1;
+              int jfnk = 0, jfpf = 0, jgnk = 0, jgpf = 1; };
 static Tune g_tune;
 static bool g_tune_read = false;
 static const Tune& tune() {
@@ -105,6 +109,7 @@ static const Tune& tune() {
             get("sw", g_tune.sw); get("nta", g_tune.nta);
             get("gmax", g_tune.gmax); get("rows", g_tune.rows); get("tile", g_tune.tile);
             get("tilekb", g_tune.tilekb); get("ppt", g_tune.ppt); get("skew", g_tune.skew);
+            get("jfnk", g_tune.jfnk); get("jfpf", g_tune.jfpf); get("jgnk", g_tune.jgnk); get("jgpf", g_tune.jgpf);
         }
     }
     return g_tune;
@@ -119,7 +124,7 @@ template <typename C> struct Plan {
     const int *labels, *input_lengths, *label_lengths;
     LogPair<C>* lp2; C *logz, *alpha, *beta; Cell<C>* rowtab;
     double *offa, *offb, *llf, *llb;
-    float* rowmax;
+    float *rowmax, *wmat;
     C* costs_dev;
     bool failed = false;
     void check() { if (hipGetLastError() != hipSuccess) failed = true; }
@@ -149,6 +154,7 @@ static bool make_plan(Plan<C>& p, int A, int N, const rnntOptions& opt, void* wo
     p.llf = reinterpret_cast<double*>(ws + lay.llf);
     p.llb = reinterpret_cast<double*>(ws + lay.llb);
     p.rowmax = reinterpret_cast<float*>(ws + lay.rowmax);
+    p.wmat = reinterpret_cast<float*>(ws + lay.wmat);
     p.costs_dev = costs_device_out ? costs_device_out : reinterpret_cast<C*>(ws + lay.costs);
     return true;
 }
@@ -226,11 +232,12 @@ template <typename C> static void launch_lattice(Plan<C>& p, bool with_beta) {
 }
 
 // Stage 3: gradient coefficients per row into the natural-order row table.
-template <typename C> static void launch_coef(Plan<C>& p) {
+template <typename C> static void launch_coef(Plan<C>& p, bool joint = false) {
     const long long skew_cells = static_cast<long long>(p.maxT + p.maxU - 1) * p.Up;
     const dim3 cgrid(static_cast<unsigned>(((skew_cells + 255) / 256 + 7) / 8 * 8), p.N);   // multiple of 8: XCD-aware remap
     hipLaunchKernelGGL((coef_kernel<C>), cgrid, dim3(256), 0, p.stream, p.lp2, p.logz, p.alpha, p.beta, p.offa, p.offb,
-                       p.llf, p.labels, p.input_lengths, p.label_lengths, p.rowtab, p.maxT, p.maxU, p.Up);
+                       p.llf, p.labels, p.input_lengths, p.label_lengths, p.rowtab, p.maxT, p.maxU, p.Up,
+                       joint ? p.wmat : nullptr, (p.maxU + 3) / 4 * 4);
     p.check();
 }
 
@@ -360,8 +367,8 @@ static rnntStatus_t run_gpu_joint(const float* f, const float* g, float* df, flo
         p.check();
         // vocabulary slices per tile: few tiles and a long contraction -> split it over 4 or 8 wavefronts
         const long long all_tiles = static_cast<long long>(N) * tiles;
-        const int nchunk = (A + 15) / 16;
-        const int S = (all_tiles >= 4096 || nchunk < 32) ? 1 : ((all_tiles < 1024 && nchunk >= 64) ? 8 : 4);
+        const int nchunk = (A + 31) / 32;
+        const int S = (all_tiles >= 4096 || nchunk < 16) ? 1 : ((all_tiles < 1024 && nchunk >= 32) ? 8 : 4);
 #define RNNT_JZ(SS, VV)                                                                                          \
     hipLaunchKernelGGL((joint_z_kernel<SS, VV>), dim3(SS == 1 ? (tiles + 3) / 4 : tiles, N),                      \
                        dim3(SS == 1 ? 256 : SS * 64), 0, p.stream, f, g, p.rowmax, labels, input_lengths,        \
@@ -376,22 +383,30 @@ static rnntStatus_t run_gpu_joint(const float* f, const float* g, float* df, flo
     launch_lattice(p, training);
     mark(2);
     if (training) {
-        launch_coef(p);
+        launch_coef(p, /*joint=*/true);
         mark(3);
-        // gradient GEMMs (plain stores of every element, padding included), then the corrections
-        if (A >= 256) {
-            const unsigned gx = static_cast<unsigned>((A + 255) / 256);
-            hipLaunchKernelGGL(joint_df_kernel<2>, dim3(gx, tilesT, N), dim3(256), 0, p.stream, f, g, p.rowmax,
-                               p.rowtab, input_lengths, label_lengths, df, maxT, maxU, A, N);
-            hipLaunchKernelGGL(joint_dg_kernel<2>, dim3(gx, tilesU, N), dim3(256), 0, p.stream, f, g, p.rowmax,
-                               p.rowtab, input_lengths, label_lengths, dg, maxT, maxU, A, N);
-        } else {
-            const unsigned gx = static_cast<unsigned>((A + 127) / 128);
-            hipLaunchKernelGGL(joint_df_kernel<1>, dim3(gx, tilesT, N), dim3(256), 0, p.stream, f, g, p.rowmax,
-                               p.rowtab, input_lengths, label_lengths, df, maxT, maxU, A, N);
-            hipLaunchKernelGGL(joint_dg_kernel<1>, dim3(gx, tilesU, N), dim3(256), 0, p.stream, f, g, p.rowmax,
-                               p.rowtab, input_lengths, label_lengths, dg, maxT, maxU, A, N);
-        }
+        // gradient GEMMs (plain stores of every element, padding included), then the corrections.
+        // NK adjacent columns per lane = the widest vector the vocabulary size and alignment allow.
+        const int Upad = (maxU + 3) / 4 * 4;
+        const uintptr_t all4 = reinterpret_cast<uintptr_t>(f) | reinterpret_cast<uintptr_t>(g) |
+                               reinterpret_cast<uintptr_t>(df) | reinterpret_cast<uintptr_t>(dg);
+        const int NKmax = (A % 4 == 0 && (all4 & 15u) == 0 && A >= 96) ? 4
+                        : (A % 2 == 0 && (all4 & 7u) == 0 && A >= 48) ? 2 : 1;
+        const Tune& tn = tune();
+        auto pick = [&](int want) { int nk = want > 0 ? want : NKmax; while (nk > NKmax) nk >>= 1; return nk; };
+        const int NKf = pick(tn.jfnk), NKg = pick(tn.jgnk);
+#define RNNT_JDF(NN, PP)                                                                                         \
+    hipLaunchKernelGGL((joint_df_kernel<NN, PP>), dim3((A + 128 * NN - 1) / (128 * NN), tilesT, N), dim3(256), 0, \
+                       p.stream, f, g, p.rowmax, p.wmat, input_lengths, label_lengths, df, maxT, maxU, Upad, A, N)
+#define RNNT_JDG(NN, PP)                                                                                         \
+    hipLaunchKernelGGL((joint_dg_kernel<NN, PP>), dim3((A + 128 * NN - 1) / (128 * NN), tilesU, N), dim3(256), 0, \
+                       p.stream, f, g, p.rowmax, p.wmat, input_lengths, label_lengths, dg, maxT, maxU, Upad, A, N)
+        if (tn.jfpf) { if (NKf == 4) RNNT_JDF(4, true); else if (NKf == 2) RNNT_JDF(2, true); else RNNT_JDF(1, true); }
+        else         { if (NKf == 4) RNNT_JDF(4, false); else if (NKf == 2) RNNT_JDF(2, false); else RNNT_JDF(1, false); }
+        if (tn.jgpf) { if (NKg == 4) RNNT_JDG(4, true); else if (NKg == 2) RNNT_JDG(2, true); else RNNT_JDG(1, true); }
+        else         { if (NKg == 4) RNNT_JDG(4, false); else if (NKg == 2) RNNT_JDG(2, false); else RNNT_JDG(1, false); }
+#undef RNNT_JDF
+#undef RNNT_JDG
         p.check();
         hipLaunchKernelGGL(joint_fix_kernel, dim3((maxU + 63) / 64, (maxT + kJointFixT - 1) / kJointFixT, N),
                            dim3(256), 0, p.stream, f, g, p.rowmax, p.rowtab, labels, input_lengths, label_lengths,

@@ -14,11 +14,12 @@
 //     DG (U x A) = Eg .* (W^T Ef)  - corrections
 // with (T+U)*A exponentials per pass instead of T*U*A.  The contractions run on the fp32 matrix
 // cores (v_mfma_f32_32x32x2_f32: bit-for-bit an fp32 fma chain, subnormals kept), operands go
-// global memory -> registers -> exp -> MFMA with no LDS staging.  Kernels:
+// as 16-byte vectors.  Kernels:
 //   joint_rowmax_kernel  mf, mg                                              (wave per row)
 //   joint_z_kernel       Z tiles + blank / label log-probs into the skewed lattice arrays
 //   (lattice_kernel, coef_kernel of rnnt_kernels.h run unchanged: the lattice array `logz` holds
-//    the RELATIVE value log Z[t,u], which makes the coefficient record's c equal to log W[t,u])
+//    the RELATIVE value log Z[t,u], which makes the coefficient record's c equal to log W[t,u],
+//    and coef_kernel also writes the dense matrix W)
 //   joint_df_kernel / joint_dg_kernel   the two gradient GEMMs with the exp(f) / exp(g) epilogue
 //   joint_fix_kernel     blank / label corrections (two columns per cell) and the far cells
 //
@@ -37,19 +38,22 @@ namespace rnnt {
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 
 constexpr float kJointFlagZ = 0x1p-60f;   // GEMM sums below this are recomputed directly
-constexpr float kJointFarC = 40.0f;       // log W above this: cell handled by joint_fix_kernel
+// kJointFarC (rnnt_kernels.h): log W above this -> the cell is handled by joint_fix_kernel
 constexpr float kJointMinMax = -3.0e38f;  // row maxima are clamped to a finite value
 
 // C/D fragment of the 32x32 MFMA: register r of lane l holds row (r&3) + 8*(r>>2) + 4*(l>>5),
 // column l&31.  A operand: lane l = A[row l&31][k = l>>5]; B operand: lane l = B[k = l>>5][col l&31].
 __device__ __forceinline__ int mfma_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
 
-__device__ __forceinline__ float joint_exp(float x, float m) {   // exp(x - m), x <= m (or -inf)
-    return fast_exp2((x - m) * static_cast<float>(kLog2e));
+// exp(x - m) with the row maximum kept as m2 = m * log2(e): one fma and one v_exp_f32.  Every
+// kernel uses this same form, so the shift each row actually gets (m2 / log2 e, equal to m up to
+// rounding) is consistent across Z, W and the gradients.  x = -inf or m2 = +inf -> 0.
+__device__ __forceinline__ float joint_exp(float x, float m2) {
+    return fast_exp2(__builtin_fmaf(x, static_cast<float>(kLog2e), -m2));
 }
 
 // ------------------------------------------------------------------------------------------
-// Row maxima.  rowmax[0, N*maxT) = mf, rowmax[N*maxT, N*(maxT+maxU)) = mg.  One wavefront per row;
+// Row maxima, stored TIMES log2(e).  rowmax[0, N*maxT) = mf, rowmax[N*maxT, N*(maxT+maxU)) = mg.  One wavefront per row;
 // rows of the padding (t >= T_b, u > U_b) are skipped.  grid = ceil(rows/4), block = 256.
 template <bool VEC>
 __global__ __launch_bounds__(256) void joint_rowmax_kernel(
@@ -81,41 +85,70 @@ __global__ __launch_bounds__(256) void joint_rowmax_kernel(
         for (int i = lane; i < A; i += 64) m = fmaxf(m, p[i]);
     }
     m = wave_max(m);
-    if (lane == 0) rowmax[row] = fmaxf(m, kJointMinMax);
+    if (lane == 0) rowmax[row] = fmaxf(m, kJointMinMax) * static_cast<float>(kLog2e);
 }
 
-// Eight consecutive columns k..k+7 of a row; columns >= A read as -inf (exp -> 0).
-template <bool VEC>
-__device__ __forceinline__ void joint_load8(const float* __restrict__ row, int k, int A, float (&v)[8]) {
-    if constexpr (VEC) {                       // A % 4 == 0, row 16-byte aligned
-        float4 a = {neg_inf<float>(), neg_inf<float>(), neg_inf<float>(), neg_inf<float>()}, c = a;
-        if (k < A) a = *reinterpret_cast<const float4*>(row + k);
-        if (k + 4 < A) c = *reinterpret_cast<const float4*>(row + k + 4);
-        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
-        v[4] = c.x; v[5] = c.y; v[6] = c.z; v[7] = c.w;
+// Up to four consecutive floats as one 4/8/16-byte access (the address is NK*4-byte aligned).
+template <int NK> __device__ __forceinline__ void joint_loadv(const float* __restrict__ p, float (&v)[NK]) {
+    if constexpr (NK == 4) {
+        const float4 t = *reinterpret_cast<const float4*>(p);
+        v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+    } else if constexpr (NK == 2) {
+        const float2 t = *reinterpret_cast<const float2*>(p);
+        v[0] = t.x; v[1] = t.y;
     } else {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = (k + j < A) ? row[k + j] : neg_inf<float>();
+        v[0] = p[0];
+    }
+}
+template <int NK> __device__ __forceinline__ void joint_storev(float* __restrict__ p, const float (&v)[NK]) {
+    if constexpr (NK == 4) *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+    else if constexpr (NK == 2) *reinterpret_cast<float2*>(p) = make_float2(v[0], v[1]);
+    else p[0] = v[0];
+}
+
+// Four consecutive columns k..k+3 of a row.  VEC (A % 4 == 0, rows 16-byte aligned): a packet past
+// the end is read from the last valid packet instead and the CALLER cancels it (row maximum +inf
+// -> exp(x - inf) = 0); scalar form: columns >= A read as -inf.
+template <bool VEC>
+__device__ __forceinline__ float4 joint_load4(const float* __restrict__ row, int k, int A) {
+    if constexpr (VEC) {
+        return *reinterpret_cast<const float4*>(row + (k < A ? k : A - 4));
+    } else {
+        const float ninf = neg_inf<float>();
+        float4 v = {ninf, ninf, ninf, ninf};
+        if (k < A) v.x = row[k];
+        if (k + 1 < A) v.y = row[k + 1];
+        if (k + 2 < A) v.z = row[k + 2];
+        if (k + 3 < A) v.w = row[k + 3];
+        return v;
     }
 }
 
 // ------------------------------------------------------------------------------------------
 // Partition function.  A wavefront owns a 32 (t) x 32 (u) tile of Z and contracts over its share
-// of the vocabulary.  The k order inside a contraction is free as long as A and B agree, so the
-// two lane halves take the two 8-column halves of a 16-column chunk (two 16-byte loads per row and
-// operand) and MFMA step j pairs column j of both halves.  S wavefronts of a block split the chunks
-// of ONE tile (large vocabulary, few tiles) and add their fragments through LDS; with S = 1 the
-// four wavefronts of a block own four tiles.  The next chunk is loaded while the current one is
-// in the matrix core.
-// Epilogue per cell: log Z -> logz (relative), blank / label log2-probs -> lp2, both in the
-// skewed lattice layout.  grid = (tiles or ceil(tiles/4), N), block = 64 * max(S, 4).
+// of the vocabulary in chunks of 32 columns.  Per chunk it reads the 32 x 32 pieces of f and g as
+// full 128-byte row segments (eight lanes per row, eight rows per 16-byte load instruction), applies
+// exp(x - rowmax) and parks the two pieces in its PRIVATE slice of LDS (row stride 36 floats); the
+// MFMA operands come back as ds_read_b128 in fragment order (lane = row, the two lane halves take
+// the two 16-column halves of the chunk: the k order inside a contraction is free as long as A and
+// B agree).  No block barrier is involved: LDS operations of one wavefront execute in order.  The
+// next chunk's global loads are in flight while the current one is in the matrix core.
+// S wavefronts of a block split the chunks of ONE tile (large vocabulary, few tiles) and add their
+// fragments through LDS at the end; with S = 1 the four wavefronts of a block own four tiles.
+// Epilogue per cell: log Z -> logz (relative), blank / label log2-probs -> lp2, both in the skewed
+// lattice layout.  grid = (tiles or ceil(tiles/4), N), block = 64 * max(S, 4).
+constexpr int kJointZPad = 36;                              // LDS row stride in floats (conflict-free b128)
+constexpr int kJointZSlice = 2 * 32 * kJointZPad;           // floats per wavefront: ef piece + eg piece
+
 template <int S, bool VEC>
 __global__ __launch_bounds__(S == 1 ? 256 : S * 64) void joint_z_kernel(
         const float* __restrict__ f, const float* __restrict__ g, const float* __restrict__ rowmax,
         const int* __restrict__ labels, const int* __restrict__ xlen, const int* __restrict__ ylen,
         LogPair<float>* __restrict__ lp2, float* __restrict__ logz, int maxT, int maxU, int Up, int A,
         int blank, int tilesU, int tiles, int N) {
-    __shared__ float red[S == 1 ? 1 : S][S == 1 ? 1 : 16][64];
+    constexpr int WAVES = S == 1 ? 4 : S;
+    __shared__ float4 stage4[WAVES * kJointZSlice / 4];
+    float* stage = reinterpret_cast<float*>(stage4);
     const int b = blockIdx.y;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5, col = lane & 31;
     const int tile = S == 1 ? static_cast<int>(blockIdx.x) * 4 + wave : static_cast<int>(blockIdx.x);
@@ -125,41 +158,99 @@ __global__ __launch_bounds__(S == 1 ? 256 : S * 64) void joint_z_kernel(
     if (t0 >= Tb || u0 >= Ub) return;                      // tile of padding (block-uniform when S > 1)
     const float* mf = rowmax + static_cast<size_t>(b) * maxT;
     const float* mg = rowmax + static_cast<size_t>(N) * maxT + static_cast<size_t>(b) * maxU;
-    const int ti = t0 + col < Tb ? t0 + col : Tb - 1;     // operand rows past the sample: any valid row
-    const int ui = u0 + col < Ub ? u0 + col : Ub - 1;
-    const float* frow = f + (static_cast<size_t>(b) * maxT + ti) * A;
-    const float* grow = g + (static_cast<size_t>(b) * maxU + ui) * A;
-    const float mft = mf[ti], mgu = mg[ui];
+
+    // loader role: lane l moves columns 4*(l&7).. of rows (l>>3) + 8i, i = 0..3
+    const int lrow = lane >> 3, lcol = (lane & 7) * 4;
+    const float* frow[4];
+    const float* grow4[4];
+    float mfr[4], mgr[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = lrow + 8 * i;
+        const int t = t0 + r < Tb ? t0 + r : Tb - 1;      // rows past the sample: any valid row
+        const int u = u0 + r < Ub ? u0 + r : Ub - 1;
+        frow[i] = f + (static_cast<size_t>(b) * maxT + t) * A;
+        grow4[i] = g + (static_cast<size_t>(b) * maxU + u) * A;
+        mfr[i] = mf[t];
+        mgr[i] = mg[u];
+    }
+    float* fs = stage + wave * kJointZSlice;               // [32][kJointZPad]
+    float* gs = fs + 32 * kJointZPad;
 
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-    const int nchunk = (A + 15) >> 4;
-    int c = S == 1 ? 0 : wave;
-    float fa[8], ga[8];
-    joint_load8<VEC>(frow, c * 16 + half * 8, A, fa);
-    joint_load8<VEC>(grow, c * 16 + half * 8, A, ga);
-    for (; c < nchunk; c += S) {
-        float fn[8], gn[8];
-        const int kn = (c + S) * 16 + half * 8;            // past the end: all -inf, never used
-        joint_load8<VEC>(frow, kn, A, fn);
-        joint_load8<VEC>(grow, kn, A, gn);
+    const int nchunk = (A + 31) >> 5;
+    auto load = [&](float4 (&fv)[4], float4 (&gv)[4], int cc) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j)
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(joint_exp(fa[j], mft), joint_exp(ga[j], mgu), acc, 0, 0, 0);
+        for (int i = 0; i < 4; ++i) {
+            fv[i] = joint_load4<VEC>(frow[i], cc * 32 + lcol, A);
+            gv[i] = joint_load4<VEC>(grow4[i], cc * 32 + lcol, A);
+        }
+    };
+    auto compute = [&](const float4 (&fv)[4], const float4 (&gv)[4], int cc) {
+        const bool in = cc * 32 + lcol < A;                // packets past the end were read elsewhere: cancel
+        const float pinf = -neg_inf<float>();
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { fa[j] = fn[j]; ga[j] = gn[j]; }
+        for (int i = 0; i < 4; ++i) {
+            const float a = in ? mfr[i] : pinf, d = in ? mgr[i] : pinf;
+            float4 e, h;
+            e.x = joint_exp(fv[i].x, a); e.y = joint_exp(fv[i].y, a);
+            e.z = joint_exp(fv[i].z, a); e.w = joint_exp(fv[i].w, a);
+            h.x = joint_exp(gv[i].x, d); h.y = joint_exp(gv[i].y, d);
+            h.z = joint_exp(gv[i].z, d); h.w = joint_exp(gv[i].w, d);
+            *reinterpret_cast<float4*>(fs + (lrow + 8 * i) * kJointZPad + lcol) = e;
+            *reinterpret_cast<float4*>(gs + (lrow + 8 * i) * kJointZPad + lcol) = h;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 a4 = *reinterpret_cast<const float4*>(fs + col * kJointZPad + 16 * half + 4 * q);
+            const float4 b4 = *reinterpret_cast<const float4*>(gs + col * kJointZPad + 16 * half + 4 * q);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b4.x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b4.y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b4.z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b4.w, acc, 0, 0, 0);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
+    // two register sets in ping-pong (a plain "current = next" copy would wait for the loads it
+    // has just issued): while one chunk is computed, the loads of the following one are in flight
+    {
+        float4 f0[4], g0[4], f1[4], g1[4];
+        int c = S == 1 ? 0 : wave;
+        load(f0, g0, c);
+        while (c + S < nchunk) {                           // two chunks per trip, both unconditional: a
+            load(f1, g1, c + S);                           // branch around a compute lets the compiler sink
+            __builtin_amdgcn_sched_barrier(0);             // that chunk's loads into it
+            compute(f0, g0, c);
+            __builtin_amdgcn_sched_barrier(0);
+            load(f0, g0, c + 2 * S);                       // past the end: reads the last packet, unused
+            __builtin_amdgcn_sched_barrier(0);
+            compute(f1, g1, c + S);
+            __builtin_amdgcn_sched_barrier(0);
+            c += 2 * S;
+        }
+        if (c < nchunk) compute(f0, g0, c);
     }
 
     // per-lane constants of the epilogue: this lane's label row u = u0 + col
     const int u = u0 + col;
+    const int ui = u < Ub ? u : Ub - 1;
     const bool has_lab = u < Ub - 1;
     int lab = blank;
     if (has_lab) {
         lab = labels[static_cast<size_t>(b) * (maxU - 1) + u];
         lab = lab < 0 ? 0 : (lab >= A ? A - 1 : lab);
     }
-    const float gbl = grow[blank] - mgu, glab = grow[lab] - mgu;
+    const float* gu = g + (static_cast<size_t>(b) * maxU + ui) * A;
+    const float mgu = mg[ui];
+    const float l2e = static_cast<float>(kLog2e), ln2 = static_cast<float>(kLn2);
+    const float gbl = __builtin_fmaf(gu[blank], l2e, -mgu), glab = __builtin_fmaf(gu[lab], l2e, -mgu);   // base 2
 
     auto finish = [&](int r, float z) {
         const int t = t0 + mfma_row(r, lane);
@@ -180,15 +271,16 @@ __global__ __launch_bounds__(S == 1 ? 256 : S * 64) void joint_z_kernel(
             float s = 0.0f;
             for (int k = lane; k < A; k += 64) s += fast_exp(fr[k] + gr[k] - m);
             s = wave_sum(s);
-            const float v = ((m - mf[tt]) - mg[uu]) + acc_log(s);
+            const float v = (m - (mf[tt] + mg[uu]) * ln2) + acc_log(s);
             if (lane == src) lz = v;
         }
         if (!valid) return;
         const float* ft = f + (static_cast<size_t>(b) * maxT + t) * A;
         const float mt = mf[t];
         LogPair<float> rec;                               // lattice log-probs are kept in base 2
-        rec.x = fmaxf(((ft[blank] - mt) + gbl - lz) * static_cast<float>(kLog2e), log_zero<float>());
-        rec.y = has_lab ? fmaxf(((ft[lab] - mt) + glab - lz) * static_cast<float>(kLog2e), log_zero<float>())
+        const float lz2 = lz * l2e;
+        rec.x = fmaxf(__builtin_fmaf(ft[blank], l2e, -mt) + gbl - lz2, log_zero<float>());
+        rec.y = has_lab ? fmaxf(__builtin_fmaf(ft[lab], l2e, -mt) + glab - lz2, log_zero<float>())
                         : log_zero<float>();
         const size_t idx = lat_index(b, t + u, u, maxT, maxU, Up);
         lp2[idx] = rec;
@@ -199,8 +291,9 @@ __global__ __launch_bounds__(S == 1 ? 256 : S * 64) void joint_z_kernel(
 #pragma unroll
         for (int r = 0; r < 16; ++r) finish(r, acc[r]);
     } else {
+        // the wavefront's own (now idle) LDS slice carries its fragment to the others
 #pragma unroll
-        for (int r = 0; r < 16; ++r) red[wave][r][lane] = acc[r];
+        for (int r = 0; r < 16; ++r) fs[r * 64 + lane] = acc[r];
         __syncthreads();
         constexpr int per = 16 / S;                        // fragment registers finished by each wavefront
 #pragma unroll
@@ -208,98 +301,164 @@ __global__ __launch_bounds__(S == 1 ? 256 : S * 64) void joint_z_kernel(
             const int r = wave * per + i;
             float z = 0.0f;
 #pragma unroll
-            for (int s = 0; s < S; ++s) z += red[s][r][lane];
+            for (int s = 0; s < S; ++s) z += stage[s * kJointZSlice + r * 64 + lane];
             finish(r, z);
         }
     }
 }
 
-// log W -> W for the gradient GEMMs: far cells (and the padding, c = log_zero) contribute nothing.
-__device__ __forceinline__ float joint_weight(float c) { return c > kJointFarC ? 0.0f : fast_exp(c); }
-
 // ------------------------------------------------------------------------------------------
-// DF[t,k] = ef[t,k] * sum_u W[t,u] eg[u,k].  A wavefront owns 32 time rows x 32*NK columns and
-// contracts over the label rows two at a time (lane half h takes u = 2s + h): A operand = W read
-// from the coefficient table, B operand = exp(g[u,k] - mg[u]) (128-byte row segments).  The loop
-// is unrolled kJointUnr steps with all loads first.  Epilogue: multiply by ef (one read of f),
-// store; rows of the padding are written as zeros.  The four wavefronts of a block take adjacent
-// column groups of the same time rows.  grid = (ceil(A / (128 NK)), ceil(maxT/32), N), block = 256.
-constexpr int kJointUnr = 4;
+// DF[t,k] = ef[t,k] * sum_u W[t,u] eg[u,k].  A wavefront owns 32 time rows x 32*NK columns; lane
+// `col` holds the NK ADJACENT columns k0 + NK*col + n (accumulator n), so every access to f, g and
+// df is one 4*NK-byte vector per lane and a half-wavefront covers 128*NK contiguous bytes of a row.
+// The contraction over the label rows runs in steps of eight: lane half h takes u = u2 + 4h + i,
+// A operand = W[t0+col][u] (one 16-byte load of the dense weight row gives four MFMA steps), B
+// operand = exp(g[u,k] - mg[u]).  Two operand sets alternate so the loads of step s+1 are in
+// flight while step s is in the matrix core, and the f values of the epilogue (one read of f) are
+// requested before the loop starts.  Epilogue: multiply by ef, store; rows of the padding are
+// written as zeros.  The four wavefronts of a block take adjacent column groups of the same time
+// rows.  grid = (ceil(A / (128 NK)), ceil(maxT/32), N), block = 256.
+template <int NK> struct JointOperands { float w[4], m[4], x[4][NK]; };
 
 template <int NK>
+__device__ __forceinline__ void joint_mma(const JointOperands<NK>& s, f32x16 (&acc)[NK]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int n = 0; n < NK; ++n)
+            acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(s.w[i], joint_exp(s.x[i][n], s.m[i]), acc[n], 0, 0, 0);
+}
+
+template <int NK, bool PF>   // PF: operand ping-pong + epilogue values requested before the loop (more registers)
 __global__ __launch_bounds__(256) void joint_df_kernel(
         const float* __restrict__ f, const float* __restrict__ g, const float* __restrict__ rowmax,
-        const Cell<float>* __restrict__ rowtab, const int* __restrict__ xlen, const int* __restrict__ ylen,
-        float* __restrict__ df, int maxT, int maxU, int A, int N) {
+        const float* __restrict__ wmat, const int* __restrict__ xlen, const int* __restrict__ ylen,
+        float* __restrict__ df, int maxT, int maxU, int Upad, int A, int N) {
     const int b = blockIdx.z;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5, col = lane & 31;
     const int k0 = (static_cast<int>(blockIdx.x) * 4 + wave) * (32 * NK);
     if (k0 >= A) return;
+    const int kc = k0 + NK * col;                          // first of this lane's NK columns
+    const bool kin = kc < A;                               // A % NK == 0: all NK columns or none
     const int t0 = blockIdx.y * 32;
     const int Tb = xlen[b], Ub = ylen[b] + 1;
     const float* mf = rowmax + static_cast<size_t>(b) * maxT;
     const float* mg = rowmax + static_cast<size_t>(N) * maxT + static_cast<size_t>(b) * maxU;
+    const float* fb = f + static_cast<size_t>(b) * maxT * A + kc;
+    float* dfb = df + static_cast<size_t>(b) * maxT * A + kc;
     f32x16 acc[NK];
 #pragma unroll
     for (int n = 0; n < NK; ++n)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[n][r] = 0.0f;
 
-    if (t0 < Tb) {
-        const bool tin = t0 + col < Tb;
-        const Cell<float>* wrow = rowtab + (static_cast<size_t>(b) * maxT + (tin ? t0 + col : Tb - 1)) * maxU;
-        const float* gb = g + static_cast<size_t>(b) * maxU * A;
-        for (int u2 = 0; u2 < Ub; u2 += 2 * kJointUnr) {
-            float c[kJointUnr], m[kJointUnr], x[kJointUnr][NK];
+    if (t0 >= Tb) {                                        // time rows of the padding: zeros
+        if (!kin) return;
+        float z[NK];
 #pragma unroll
-            for (int i = 0; i < kJointUnr; ++i) {
-                const int u = u2 + 2 * i + half;
-                const bool uin = u < Ub;
-                const int us = uin ? u : Ub - 1;
-                c[i] = (uin && tin) ? wrow[us].x : log_zero<float>();
-                m[i] = mg[us];
+        for (int n = 0; n < NK; ++n) z[n] = 0.0f;
 #pragma unroll
-                for (int n = 0; n < NK; ++n) {
-                    const int k = k0 + 32 * n + col;
-                    x[i][n] = (uin && k < A) ? gb[static_cast<size_t>(us) * A + k] : neg_inf<float>();
-                }
-            }
+        for (int r = 0; r < 16; ++r) {
+            const int t = t0 + mfma_row(r, lane);
+            if (t < maxT) joint_storev<NK>(dfb + static_cast<size_t>(t) * A, z);
+        }
+        return;
+    }
+
+    const bool tin = t0 + col < Tb;
+    const float* wrow = wmat + (static_cast<size_t>(b) * maxT + (tin ? t0 + col : Tb - 1)) * Upad;
+    const float* gb = g + static_cast<size_t>(b) * maxU * A + kc;
+    auto load = [&](JointOperands<NK>& s, int u2) {
+        const int ub = u2 + 4 * half;
+        float4 w4 = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (tin && ub < Ub) w4 = *reinterpret_cast<const float4*>(wrow + ub);   // ub + 3 < Upad
+        s.w[0] = w4.x; s.w[1] = w4.y; s.w[2] = w4.z; s.w[3] = w4.w;
 #pragma unroll
-            for (int i = 0; i < kJointUnr; ++i) {
-                const float w = joint_weight(c[i]);
+        for (int i = 0; i < 4; ++i) {
+            const int u = ub + i;
+            const bool uin = u < Ub;
+            const int us = uin ? u : Ub - 1;
+            if (!uin) s.w[i] = 0.0f;                       // columns past the sample: zero / never written
+            s.m[i] = mg[us];
+            if (uin && kin) {
+                joint_loadv<NK>(gb + static_cast<size_t>(us) * A, s.x[i]);
+            } else {
 #pragma unroll
-                for (int n = 0; n < NK; ++n)
-                    acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(w, joint_exp(x[i][n], m[i]), acc[n], 0, 0, 0);
+                for (int n = 0; n < NK; ++n) s.x[i][n] = neg_inf<float>();
             }
         }
+    };
+
+    float fv[16][NK], mt[16];
+    auto load_f = [&]() {                                  // the epilogue's f values and row maxima
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int t = t0 + mfma_row(r, lane);
+            const int ts = t < Tb ? t : Tb - 1;
+            mt[r] = mf[ts];
+            if (kin) {
+                joint_loadv<NK>(fb + static_cast<size_t>(ts) * A, fv[r]);
+            } else {
+#pragma unroll
+                for (int n = 0; n < NK; ++n) fv[r][n] = 0.0f;
+            }
+        }
+    };
+    if constexpr (PF) {
+        JointOperands<NK> s0, s1;
+        load(s0, 0);
+        load_f();                                          // requested now, consumed after the contraction
+        __builtin_amdgcn_sched_barrier(0);
+        int u2 = 0;
+        while (u2 + 8 < Ub) {                              // two steps per trip, both unconditional (see joint_z_kernel)
+            load(s1, u2 + 8);
+            __builtin_amdgcn_sched_barrier(0);
+            joint_mma<NK>(s0, acc);
+            __builtin_amdgcn_sched_barrier(0);
+            load(s0, u2 + 16);                             // past the sample: no loads, zero weights
+            __builtin_amdgcn_sched_barrier(0);
+            joint_mma<NK>(s1, acc);
+            __builtin_amdgcn_sched_barrier(0);
+            u2 += 16;
+        }
+        if (u2 < Ub) joint_mma<NK>(s0, acc);
+    } else {
+        for (int u2 = 0; u2 < Ub; u2 += 8) {
+            JointOperands<NK> s0;
+            load(s0, u2);
+            joint_mma<NK>(s0, acc);
+        }
+        load_f();
     }
+
+    if (!kin) return;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int t = t0 + mfma_row(r, lane);
         if (t >= maxT) continue;
-        const size_t row = (static_cast<size_t>(b) * maxT + t) * A;
-        const float mt = t < Tb ? mf[t] : 0.0f;
+        float o[NK];
 #pragma unroll
-        for (int n = 0; n < NK; ++n) {
-            const int k = k0 + 32 * n + col;
-            if (k >= A) continue;
-            df[row + k] = t < Tb ? joint_exp(f[row + k], mt) * acc[n][r] : 0.0f;
-        }
+        for (int n = 0; n < NK; ++n) o[n] = t < Tb ? joint_exp(fv[r][n], mt[r]) * acc[n][r] : 0.0f;
+        joint_storev<NK>(dfb + static_cast<size_t>(t) * A, o);
     }
 }
 
-// DG[u,k] = eg[u,k] * sum_t W[t,u] ef[t,k]: the same with the roles of f and g exchanged; the
-// contraction runs over the time rows (A operand = W^T, 32 consecutive records of one time row).
+// DG[u,k] = eg[u,k] * sum_t W[t,u] ef[t,k]: the same with the roles of f and g exchanged.  The
+// contraction runs over the time rows in steps of eight (lane half h takes t = t2 + 4h + i):
+// A operand = W[t][u0+col] (coalesced along u), B operand = exp(f[t,k] - mf[t]), the streaming
+// read of f, again with two alternating operand sets.
 // grid = (ceil(A / (128 NK)), ceil(maxU/32), N), block = 256.
-template <int NK>
+template <int NK, bool PF>
 __global__ __launch_bounds__(256) void joint_dg_kernel(
         const float* __restrict__ f, const float* __restrict__ g, const float* __restrict__ rowmax,
-        const Cell<float>* __restrict__ rowtab, const int* __restrict__ xlen, const int* __restrict__ ylen,
-        float* __restrict__ dg, int maxT, int maxU, int A, int N) {
+        const float* __restrict__ wmat, const int* __restrict__ xlen, const int* __restrict__ ylen,
+        float* __restrict__ dg, int maxT, int maxU, int Upad, int A, int N) {
     const int b = blockIdx.z;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5, col = lane & 31;
     const int k0 = (static_cast<int>(blockIdx.x) * 4 + wave) * (32 * NK);
     if (k0 >= A) return;
+    const int kc = k0 + NK * col;
+    const bool kin = kc < A;
     const int u0 = blockIdx.y * 32;
     const int Tb = xlen[b], Ub = ylen[b] + 1;
     const float* mf = rowmax + static_cast<size_t>(b) * maxT;
@@ -312,44 +471,67 @@ __global__ __launch_bounds__(256) void joint_dg_kernel(
 
     if (u0 < Ub) {
         const bool uin = u0 + col < Ub;
-        const Cell<float>* wcol = rowtab + static_cast<size_t>(b) * maxT * maxU + (uin ? u0 + col : Ub - 1);
-        const float* fb = f + static_cast<size_t>(b) * maxT * A;
-        for (int t2 = 0; t2 < Tb; t2 += 2 * kJointUnr) {
-            float c[kJointUnr], m[kJointUnr], x[kJointUnr][NK];
+        const float* wcol = wmat + static_cast<size_t>(b) * maxT * Upad + (uin ? u0 + col : 0);
+        const float* fb = f + static_cast<size_t>(b) * maxT * A + kc;
+        auto load = [&](JointOperands<NK>& s, int t2) {
 #pragma unroll
-            for (int i = 0; i < kJointUnr; ++i) {
-                const int t = t2 + 2 * i + half;
+            for (int i = 0; i < 4; ++i) {
+                const int t = t2 + 4 * half + i;
                 const bool tin = t < Tb;
                 const int ts = tin ? t : Tb - 1;
-                c[i] = (uin && tin) ? wcol[static_cast<size_t>(ts) * maxU].x : log_zero<float>();
-                m[i] = mf[ts];
+                s.w[i] = (tin && uin) ? wcol[static_cast<size_t>(ts) * Upad] : 0.0f;
+                s.m[i] = mf[ts];
+                if (tin && kin) {
+                    joint_loadv<NK>(fb + static_cast<size_t>(ts) * A, s.x[i]);
+                } else {
 #pragma unroll
-                for (int n = 0; n < NK; ++n) {
-                    const int k = k0 + 32 * n + col;
-                    x[i][n] = (tin && k < A) ? fb[static_cast<size_t>(ts) * A + k] : neg_inf<float>();
+                    for (int n = 0; n < NK; ++n) s.x[i][n] = neg_inf<float>();
                 }
             }
-#pragma unroll
-            for (int i = 0; i < kJointUnr; ++i) {
-                const float w = joint_weight(c[i]);
-#pragma unroll
-                for (int n = 0; n < NK; ++n)
-                    acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(w, joint_exp(x[i][n], m[i]), acc[n], 0, 0, 0);
+        };
+        if constexpr (PF) {
+            JointOperands<NK> s0, s1;
+            load(s0, 0);
+            int t2 = 0;
+            while (t2 + 8 < Tb) {
+                load(s1, t2 + 8);
+                __builtin_amdgcn_sched_barrier(0);
+                joint_mma<NK>(s0, acc);
+                __builtin_amdgcn_sched_barrier(0);
+                load(s0, t2 + 16);
+                __builtin_amdgcn_sched_barrier(0);
+                joint_mma<NK>(s1, acc);
+                __builtin_amdgcn_sched_barrier(0);
+                t2 += 16;
+            }
+            if (t2 < Tb) joint_mma<NK>(s0, acc);
+        } else {
+            for (int t2 = 0; t2 < Tb; t2 += 16) {          // sixteen time rows per trip, all loads first
+                JointOperands<NK> s0, s1;
+                load(s0, t2);
+                load(s1, t2 + 8);
+                joint_mma<NK>(s0, acc);
+                joint_mma<NK>(s1, acc);
             }
         }
     }
+    if (!kin) return;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int u = u0 + mfma_row(r, lane);
         if (u >= maxU) continue;
-        const size_t row = (static_cast<size_t>(b) * maxU + u) * A;
-        const float mu = u < Ub ? mg[u] : 0.0f;
+        const size_t at = (static_cast<size_t>(b) * maxU + u) * A + kc;
+        float o[NK];
+        if (u < Ub) {
+            const float mu = mg[u];
+            joint_loadv<NK>(g + at, o);
 #pragma unroll
-        for (int n = 0; n < NK; ++n) {
-            const int k = k0 + 32 * n + col;
-            if (k >= A) continue;
-            dg[row + k] = u < Ub ? joint_exp(g[row + k], mu) * acc[n][r] : 0.0f;
+            for (int n = 0; n < NK; ++n) o[n] = joint_exp(o[n], mu) * acc[n][r];
+        } else {
+#pragma unroll
+            for (int n = 0; n < NK; ++n) o[n] = 0.0f;
         }
+        joint_storev<NK>(dg + at, o);
     }
 }
 
@@ -400,7 +582,7 @@ __global__ __launch_bounds__(256) void joint_fix_kernel(
             const int src = __ffsll(static_cast<long long>(far)) - 1;
             far &= far - 1;
             const int uu = ub0 + src;
-            const float shift = lane_get(rec.x, src) - mf[t] - mg[uu];
+            const float shift = lane_get(rec.x, src) - (mf[t] + mg[uu]) * static_cast<float>(kLn2);
             const float* fr = f + (static_cast<size_t>(b) * maxT + t) * A;
             const float* gr = g + (static_cast<size_t>(b) * maxU + uu) * A;
             float* dgrow = dg + (static_cast<size_t>(b) * maxU + uu) * A;

@@ -46,6 +46,11 @@ template <typename L> struct alignas(4 * sizeof(L)) Cell { L x, y, z, w; };
 constexpr double kLog2e = 1.4426950408889634;
 constexpr double kLn2 = 0.6931471805599453;
 
+// Additive-joint path (rnnt_joint_kernels.h): coef_kernel also emits the dense weight matrix
+// W[b][t][u] = exp(c) of the gradient GEMMs; cells with c above kJointFarC ("far" cells, whose two
+// logit rows peak at different symbols) and the padding get 0 and are handled outside the GEMMs.
+constexpr float kJointFarC = 40.0f;
+
 // The skewed arrays carry kLatPad spare rows before diagonal 0 and after diagonal D-1 of every
 // sample, so the last (partial) chunk of a sweep can run its full C steps without bounds checks.
 constexpr int kLatPad = 16;
@@ -663,7 +668,7 @@ __global__ __launch_bounds__(256) void coef_kernel(
         const L* __restrict__ beta, const double* __restrict__ offa,
         const double* __restrict__ offb, const double* __restrict__ ll_fwd,
         const int* __restrict__ labels, const int* __restrict__ xlen, const int* __restrict__ ylen,
-        Cell<L>* __restrict__ rowtab, int maxT, int maxU, int Up) {
+        Cell<L>* __restrict__ rowtab, int maxT, int maxU, int Up, float* __restrict__ wmat, int Upad) {
     // Threads run over the SKEWED index space (diagonal n, column u): a wavefront covers 64
     // consecutive columns of one diagonal, so every read of the lattice arrays is one coalesced
     // row segment and the per-diagonal offsets are wave-uniform; the only scattered access is the
@@ -714,6 +719,10 @@ __global__ __launch_bounds__(256) void coef_kernel(
         o.w = static_cast<L>(lab);
     }
     rowtab[(static_cast<size_t>(b) * maxT + t) * maxU + u] = o;
+    if (wmat != nullptr) {                                    // additive joint only: W = exp(c), row stride Upad
+        const float c = static_cast<float>(o.x);
+        wmat[(static_cast<size_t>(b) * maxT + t) * Upad + u] = c > kJointFarC ? 0.0f : fast_exp(c);
+    }
 }
 
 // ------------------------------------------------------------------------------------------

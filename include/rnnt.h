@@ -227,6 +227,37 @@ rnntStatus_t compute_rnnt_loss_add(const float* const trans_acts,
                                    void* workspace,
                                    rnntOptions options);
 
+/* Two-phase form of compute_rnnt_loss_add for autograd frameworks, as compute_rnnt_loss_fwd / _bwd
+ * above: the forward call writes the costs and (with prepare_backward != 0) leaves the weight matrix
+ * and the correction table in the workspace; the backward call, with the SAME activations, labels,
+ * lengths, workspace and options, enqueues only the two gradient GEMMs and the corrections, with
+ * sample b's gradients multiplied by grad_scale_device[b] (NULL = 1) -- no pass over d(trans_acts) /
+ * d(pred_acts) is left for the framework.  Enqueue only, no synchronisation. */
+rnntStatus_t compute_rnnt_loss_add_fwd(const float* const trans_acts,
+                                       const float* const pred_acts,
+                                       const int* const flat_labels,
+                                       const int* const label_lengths,
+                                       const int* const input_lengths,
+                                       int alphabet_size,
+                                       int minibatch,
+                                       float* costs_device,
+                                       void* workspace,
+                                       rnntOptions options,
+                                       int prepare_backward);
+
+rnntStatus_t compute_rnnt_loss_add_bwd(const float* const trans_acts,
+                                       const float* const pred_acts,
+                                       float* trans_grads,
+                                       float* pred_grads,
+                                       const float* grad_scale_device,
+                                       const int* const flat_labels,
+                                       const int* const label_lengths,
+                                       const int* const input_lengths,
+                                       int alphabet_size,
+                                       int minibatch,
+                                       void* workspace,
+                                       rnntOptions options);
+
 /* Stage timing for benchmarks.  rnnt_profile_enable(1) makes every following
  * GPU call record HIP events around its kernels on options.stream (no extra
  * synchronisation); rnnt_profile_read() fills `ms` with the accumulated

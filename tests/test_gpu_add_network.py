@@ -111,6 +111,58 @@ def test_large_logit_range_is_safe(oracle):
     assert np.allclose(dg, ref_gz.sum(axis=1), rtol=1e-4, atol=5e-4)
 
 
+def test_per_sample_grad_output_is_folded_in(oracle):
+    """reduction='none' with a non-uniform grad_output: the two-phase backward multiplies sample b's
+    gradients by grad_output[b] inside the gradient kernels."""
+    from warprnnt_pytorch.add_network import RNNTLossAdd
+    f, g, labels, tl, ll, blank = problem((3, 21, 7, 130), 11)
+    z = f[:, :, None, :].astype(np.float64) + g[:, None, :, :].astype(np.float64)
+    ref_c, ref_gz = oracle.rnnt_logits(z, labels, tl, ll, blank)
+    dev = torch.device("cuda:0")
+    tf = torch.tensor(f, device=dev, requires_grad=True)
+    tg = torch.tensor(g, device=dev, requires_grad=True)
+    w = np.array([0.5, -2.0, 3.25], dtype=np.float32)
+    loss = RNNTLossAdd(blank=blank, reduction="none")(tf, tg, torch.tensor(labels, device=dev),
+                                                     torch.tensor(tl, device=dev), torch.tensor(ll, device=dev))
+    loss.backward(torch.tensor(w, device=dev))
+    assert np.allclose(loss.detach().cpu().numpy(), ref_c, rtol=1e-5)
+    assert np.allclose(tf.grad.cpu().numpy(), ref_gz.sum(axis=2) * w[:, None, None], rtol=1e-4, atol=2e-4)
+    assert np.allclose(tg.grad.cpu().numpy(), ref_gz.sum(axis=1) * w[:, None, None], rtol=1e-4, atol=5e-4)
+
+
+def test_single_call_entry_equals_two_phase():
+    """compute_rnnt_loss_add (one call, through ctypes) against the module's fwd / bwd route."""
+    from warprnnt_pytorch import _lib
+    f, g, labels, tl, ll, blank = problem((2, 40, 9, 260), 3)
+    costs2, df2, dg2 = run_add(f, g, labels, tl, ll, blank)
+    dev = torch.device("cuda:0")
+    tf, tg = torch.tensor(f, device=dev), torch.tensor(g, device=dev)
+    tlab, ttl, tll = (torch.tensor(a, device=dev) for a in (labels, tl, ll))
+    N, T, A = f.shape
+    U = g.shape[1]
+    df, dg = torch.full_like(tf, 7.0), torch.full_like(tg, 7.0)      # every element must be overwritten
+    costs = torch.empty(N, device=dev)
+    ws = torch.empty(_lib.workspace_bytes(T, U, N, True, 4), dtype=torch.uint8, device=dev)
+    opt = _lib.rnntOptions(loc=1, num_threads=0, stream=torch.cuda.current_stream().cuda_stream, blank_label=blank,
+                           maxT=T, maxU=U, batch_first=True)
+    lib = _lib.lib()
+    st = lib.compute_rnnt_loss_add(tf.data_ptr(), tg.data_ptr(), df.data_ptr(), dg.data_ptr(), tlab.data_ptr(),
+                                   tll.data_ptr(), ttl.data_ptr(), A, N, costs.data_ptr(), ws.data_ptr(), opt)
+    assert st == 0
+    torch.cuda.synchronize()
+    assert np.array_equal(costs.cpu().numpy().astype(np.float64), costs2)
+    assert np.array_equal(df.cpu().numpy(), df2) and np.array_equal(dg.cpu().numpy(), dg2)
+    # score only: NULL gradients, and one NULL gradient is rejected
+    st = lib.compute_rnnt_loss_add(tf.data_ptr(), tg.data_ptr(), None, None, tlab.data_ptr(), tll.data_ptr(),
+                                   ttl.data_ptr(), A, N, costs.data_ptr(), ws.data_ptr(), opt)
+    assert st == 0
+    torch.cuda.synchronize()
+    assert np.array_equal(costs.cpu().numpy().astype(np.float64), costs2)
+    st = lib.compute_rnnt_loss_add(tf.data_ptr(), tg.data_ptr(), df.data_ptr(), None, tlab.data_ptr(), tll.data_ptr(),
+                                   ttl.data_ptr(), A, N, costs.data_ptr(), ws.data_ptr(), opt)
+    assert st == 2
+
+
 def test_validation_errors():
     from warprnnt_pytorch.add_network import rnnt_loss_add
     dev = torch.device("cuda:0")

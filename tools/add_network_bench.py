@@ -3,6 +3,8 @@
   fused        : compute_rnnt_loss_add(f, g) -> costs, df, dg
   materialised : joint = f[:, :, None] + g[:, None]  (torch)  -> compute_rnnt_loss_async -> grads
                  -> df = grads.sum(2), dg = grads.sum(1)  (torch)   [what a user of the reference does]
+  step         : RNNTLossAdd(reduction='mean') forward + backward through autograd (two-phase entry,
+                 1/N and grad_output folded into the gradient kernels)
 Usage: python tools/add_network_bench.py [c2 c3 c4]"""
 import ctypes as C
 import os
@@ -60,8 +62,24 @@ for name in sys.argv[1:] or ["c3"]:
         lib.rnnt_profile_enable(0)
         st = (C.c_double * 5)(); n = lib.rnnt_profile_read(st, 5)
         out[label] = (ms, [round(st[i] / max(n, 1), 4) for i in range(5)])
+    from warprnnt_pytorch.add_network import RNNTLossAdd
+    crit = RNNTLossAdd(blank=0, reduction="mean")
+    fr, gr = f.clone().requires_grad_(True), g.clone().requires_grad_(True)
+
+    def step():
+        fr.grad = None; gr.grad = None
+        crit(fr, gr, labels, tl, ll).backward()
+
+    for _ in range(3):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(10):
+        step()
+    torch.cuda.synchronize()
+    step_ms = (time.perf_counter() - t0) * 1e2
     c_f = costs.clone(); fused(); torch.cuda.synchronize()
     print("%s N=%d T=%d U=%d A=%d: fused %.3f ms (stages stats/lattice/coef/grad/span %s) | materialised %.3f ms "
-          "(library stages %s) | speed-up x%.1f" % (name, N, T, U, A, out["fused"][0], out["fused"][1],
-                                                    out["materialised"][0], out["materialised"][1],
-                                                    out["materialised"][0] / out["fused"][0]))
+          "(library stages %s) | speed-up x%.1f | autograd step (mean) %.3f ms"
+          % (name, N, T, U, A, out["fused"][0], out["fused"][1], out["materialised"][0], out["materialised"][1],
+             out["materialised"][0] / out["fused"][0], step_ms))

@@ -340,14 +340,18 @@ static rnntStatus_t run_gpu(const typename Tag::store* acts, typename Tag::store
 // f (N,maxT,A) + g (N,maxU,A) -> costs, df, dg without the (N,T,U,A) tensor (rnnt_joint_kernels.h):
 // the two streaming stages are replaced, lattice and coefficients are the same launches as above.
 // Enqueue only: device costs, no host copy, no synchronisation.  fp32.
+// phases: 1 = forward (row maxima, Z, lattice, and with want_grad the coefficient table + W),
+// 2 = backward (DF, DG, corrections from the workspace a forward call left), 3 = both.
 static rnntStatus_t run_gpu_joint(const float* f, const float* g, float* df, float* dg, const int* labels,
                                   const int* label_lengths, const int* input_lengths, int A, int N,
-                                  float* costs_device, void* workspace, const rnntOptions& opt) {
+                                  float* costs_device, const float* grad_scale, void* workspace,
+                                  const rnntOptions& opt, int phases, bool want_grad) {
     Plan<float> p;
     if (!make_plan(p, A, N, opt, workspace, labels, label_lengths, input_lengths, costs_device))
         return RNNT_STATUS_INVALID_VALUE;
-    if ((df == nullptr) != (dg == nullptr)) return RNNT_STATUS_INVALID_VALUE;
-    const bool training = df != nullptr;
+    const bool do_fwd = (phases & 1) != 0, do_bwd = (phases & 2) != 0;
+    if (do_bwd && (df == nullptr || dg == nullptr)) return RNNT_STATUS_INVALID_VALUE;
+    const bool training = want_grad;
     const bool prof = prof_prepare();
     auto mark = [&](int i) { if (prof) (void)hipEventRecord(g_prof.ev[i], p.stream); };
 
@@ -355,7 +359,7 @@ static rnntStatus_t run_gpu_joint(const float* f, const float* g, float* df, flo
     const bool vec = (A % 4 == 0) && ((reinterpret_cast<uintptr_t>(f) | reinterpret_cast<uintptr_t>(g)) & 15u) == 0;
     const int tilesT = (maxT + 31) / 32, tilesU = (maxU + 31) / 32, tiles = tilesT * tilesU;
     mark(0);
-    {   // row maxima, then the partition-function GEMM with the log-prob epilogue
+    if (do_fwd) {   // row maxima, then the partition-function GEMM with the log-prob epilogue
         const long long rows = static_cast<long long>(N) * (maxT + maxU);
         const dim3 rgrid(static_cast<unsigned>((rows + 3) / 4));
         if (vec)
@@ -380,11 +384,11 @@ static rnntStatus_t run_gpu_joint(const float* f, const float* g, float* df, flo
         p.check();
     }
     mark(1);
-    launch_lattice(p, training);
+    if (do_fwd) launch_lattice(p, training);
     mark(2);
-    if (training) {
-        launch_coef(p, /*joint=*/true);
-        mark(3);
+    if (do_fwd && training) launch_coef(p, /*joint=*/true);
+    mark(3);
+    if (do_bwd) {
         // gradient GEMMs (plain stores of every element, padding included), then the corrections.
         // NK adjacent columns per lane = the widest vector the vocabulary size and alignment allow.
         const int Upad = (maxU + 3) / 4 * 4;
@@ -397,10 +401,10 @@ static rnntStatus_t run_gpu_joint(const float* f, const float* g, float* df, flo
         const int NKf = pick(tn.jfnk), NKg = pick(tn.jgnk);
 #define RNNT_JDF(NN, PP)                                                                                         \
     hipLaunchKernelGGL((joint_df_kernel<NN, PP>), dim3((A + 128 * NN - 1) / (128 * NN), tilesT, N), dim3(256), 0, \
-                       p.stream, f, g, p.rowmax, p.wmat, input_lengths, label_lengths, df, maxT, maxU, Upad, A, N)
+                       p.stream, f, g, p.rowmax, p.wmat, grad_scale, input_lengths, label_lengths, df, maxT, maxU, Upad, A, N)
 #define RNNT_JDG(NN, PP)                                                                                         \
     hipLaunchKernelGGL((joint_dg_kernel<NN, PP>), dim3((A + 128 * NN - 1) / (128 * NN), tilesU, N), dim3(256), 0, \
-                       p.stream, f, g, p.rowmax, p.wmat, input_lengths, label_lengths, dg, maxT, maxU, Upad, A, N)
+                       p.stream, f, g, p.rowmax, p.wmat, grad_scale, input_lengths, label_lengths, dg, maxT, maxU, Upad, A, N)
         if (tn.jfpf) { if (NKf == 4) RNNT_JDF(4, true); else if (NKf == 2) RNNT_JDF(2, true); else RNNT_JDF(1, true); }
         else         { if (NKf == 4) RNNT_JDF(4, false); else if (NKf == 2) RNNT_JDF(2, false); else RNNT_JDF(1, false); }
         if (tn.jgpf) { if (NKg == 4) RNNT_JDG(4, true); else if (NKg == 2) RNNT_JDG(2, true); else RNNT_JDG(1, true); }
@@ -409,11 +413,9 @@ static rnntStatus_t run_gpu_joint(const float* f, const float* g, float* df, flo
 #undef RNNT_JDG
         p.check();
         hipLaunchKernelGGL(joint_fix_kernel, dim3((maxU + 63) / 64, (maxT + kJointFixT - 1) / kJointFixT, N),
-                           dim3(256), 0, p.stream, f, g, p.rowmax, p.rowtab, labels, input_lengths, label_lengths,
-                           df, dg, maxT, maxU, A, p.blank, N);
+                           dim3(256), 0, p.stream, f, g, p.rowmax, p.rowtab, labels, grad_scale, input_lengths,
+                           label_lengths, df, dg, maxT, maxU, A, p.blank, N);
         p.check();
-    } else {
-        mark(3);
     }
     mark(4);
     if (prof) g_prof.pending = true;
@@ -579,8 +581,38 @@ rnntStatus_t compute_rnnt_loss_add(const float* const trans_acts, const float* c
     if (bad_args(trans_acts, flat_labels, label_lengths, input_lengths, costs_device, workspace, alphabet_size,
                  minibatch, options) || pred_acts == nullptr || options.loc != RNNT_GPU)
         return RNNT_STATUS_INVALID_VALUE;
+    if ((trans_grads == nullptr) != (pred_grads == nullptr)) return RNNT_STATUS_INVALID_VALUE;
+    const bool training = trans_grads != nullptr;
     return run_gpu_joint(trans_acts, pred_acts, trans_grads, pred_grads, flat_labels, label_lengths,
-                         input_lengths, alphabet_size, minibatch, costs_device, workspace, options);
+                         input_lengths, alphabet_size, minibatch, costs_device, nullptr, workspace, options,
+                         training ? 3 : 1, training);
+}
+
+rnntStatus_t compute_rnnt_loss_add_fwd(const float* const trans_acts, const float* const pred_acts,
+                                       const int* const flat_labels, const int* const label_lengths,
+                                       const int* const input_lengths, int alphabet_size, int minibatch,
+                                       float* costs_device, void* workspace, rnntOptions options,
+                                       int prepare_backward) {
+    if (bad_args(trans_acts, flat_labels, label_lengths, input_lengths, costs_device, workspace, alphabet_size,
+                 minibatch, options) || pred_acts == nullptr || options.loc != RNNT_GPU)
+        return RNNT_STATUS_INVALID_VALUE;
+    return run_gpu_joint(trans_acts, pred_acts, nullptr, nullptr, flat_labels, label_lengths, input_lengths,
+                         alphabet_size, minibatch, costs_device, nullptr, workspace, options, 1,
+                         prepare_backward != 0);
+}
+
+rnntStatus_t compute_rnnt_loss_add_bwd(const float* const trans_acts, const float* const pred_acts,
+                                       float* trans_grads, float* pred_grads, const float* grad_scale_device,
+                                       const int* const flat_labels, const int* const label_lengths,
+                                       const int* const input_lengths, int alphabet_size, int minibatch,
+                                       void* workspace, rnntOptions options) {
+    if (trans_acts == nullptr || pred_acts == nullptr || trans_grads == nullptr || pred_grads == nullptr ||
+        flat_labels == nullptr || label_lengths == nullptr || input_lengths == nullptr || workspace == nullptr ||
+        alphabet_size <= 0 || minibatch <= 0 || options.maxT <= 0 || options.maxU <= 0 || options.loc != RNNT_GPU)
+        return RNNT_STATUS_INVALID_VALUE;
+    return run_gpu_joint(trans_acts, pred_acts, trans_grads, pred_grads, flat_labels, label_lengths,
+                         input_lengths, alphabet_size, minibatch, nullptr, grad_scale_device, workspace, options, 2,
+                         true);
 }
 
 void rnnt_profile_enable(int on) { g_prof.on = on != 0; }

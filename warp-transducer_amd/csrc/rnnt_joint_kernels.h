@@ -332,8 +332,8 @@ __device__ __forceinline__ void joint_mma(const JointOperands<NK>& s, f32x16 (&a
 template <int NK, bool PF>   // PF: operand ping-pong + epilogue values requested before the loop (more registers)
 __global__ __launch_bounds__(256) void joint_df_kernel(
         const float* __restrict__ f, const float* __restrict__ g, const float* __restrict__ rowmax,
-        const float* __restrict__ wmat, const int* __restrict__ xlen, const int* __restrict__ ylen,
-        float* __restrict__ df, int maxT, int maxU, int Upad, int A, int N) {
+        const float* __restrict__ wmat, const float* __restrict__ scale, const int* __restrict__ xlen,
+        const int* __restrict__ ylen, float* __restrict__ df, int maxT, int maxU, int Upad, int A, int N) {
     const int b = blockIdx.z;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5, col = lane & 31;
     const int k0 = (static_cast<int>(blockIdx.x) * 4 + wave) * (32 * NK);
@@ -366,13 +366,14 @@ __global__ __launch_bounds__(256) void joint_df_kernel(
     }
 
     const bool tin = t0 + col < Tb;
+    const float sc = scale != nullptr ? scale[b] : 1.0f;   // per-sample factor (grad_output / N), folded into W
     const float* wrow = wmat + (static_cast<size_t>(b) * maxT + (tin ? t0 + col : Tb - 1)) * Upad;
     const float* gb = g + static_cast<size_t>(b) * maxU * A + kc;
     auto load = [&](JointOperands<NK>& s, int u2) {
         const int ub = u2 + 4 * half;
         float4 w4 = {0.0f, 0.0f, 0.0f, 0.0f};
         if (tin && ub < Ub) w4 = *reinterpret_cast<const float4*>(wrow + ub);   // ub + 3 < Upad
-        s.w[0] = w4.x; s.w[1] = w4.y; s.w[2] = w4.z; s.w[3] = w4.w;
+        s.w[0] = w4.x * sc; s.w[1] = w4.y * sc; s.w[2] = w4.z * sc; s.w[3] = w4.w * sc;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int u = ub + i;
@@ -451,8 +452,8 @@ __global__ __launch_bounds__(256) void joint_df_kernel(
 template <int NK, bool PF>
 __global__ __launch_bounds__(256) void joint_dg_kernel(
         const float* __restrict__ f, const float* __restrict__ g, const float* __restrict__ rowmax,
-        const float* __restrict__ wmat, const int* __restrict__ xlen, const int* __restrict__ ylen,
-        float* __restrict__ dg, int maxT, int maxU, int Upad, int A, int N) {
+        const float* __restrict__ wmat, const float* __restrict__ scale, const int* __restrict__ xlen,
+        const int* __restrict__ ylen, float* __restrict__ dg, int maxT, int maxU, int Upad, int A, int N) {
     const int b = blockIdx.z;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5, col = lane & 31;
     const int k0 = (static_cast<int>(blockIdx.x) * 4 + wave) * (32 * NK);
@@ -471,6 +472,7 @@ __global__ __launch_bounds__(256) void joint_dg_kernel(
 
     if (u0 < Ub) {
         const bool uin = u0 + col < Ub;
+        const float sc = scale != nullptr ? scale[b] : 1.0f;
         const float* wcol = wmat + static_cast<size_t>(b) * maxT * Upad + (uin ? u0 + col : 0);
         const float* fb = f + static_cast<size_t>(b) * maxT * A + kc;
         auto load = [&](JointOperands<NK>& s, int t2) {
@@ -479,7 +481,7 @@ __global__ __launch_bounds__(256) void joint_dg_kernel(
                 const int t = t2 + 4 * half + i;
                 const bool tin = t < Tb;
                 const int ts = tin ? t : Tb - 1;
-                s.w[i] = (tin && uin) ? wcol[static_cast<size_t>(ts) * Upad] : 0.0f;
+                s.w[i] = (tin && uin) ? wcol[static_cast<size_t>(ts) * Upad] * sc : 0.0f;
                 s.m[i] = mf[ts];
                 if (tin && kin) {
                     joint_loadv<NK>(fb + static_cast<size_t>(ts) * A, s.x[i]);
@@ -548,8 +550,8 @@ constexpr int kJointFixT = 32;
 __global__ __launch_bounds__(256) void joint_fix_kernel(
         const float* __restrict__ f, const float* __restrict__ g, const float* __restrict__ rowmax,
         const Cell<float>* __restrict__ rowtab, const int* __restrict__ labels,
-        const int* __restrict__ xlen, const int* __restrict__ ylen, float* __restrict__ df,
-        float* __restrict__ dg, int maxT, int maxU, int A, int blank, int N) {
+        const float* __restrict__ scale, const int* __restrict__ xlen, const int* __restrict__ ylen,
+        float* __restrict__ df, float* __restrict__ dg, int maxT, int maxU, int A, int blank, int N) {
     __shared__ float red[2][4][64];
     const int b = blockIdx.z;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -565,12 +567,15 @@ __global__ __launch_bounds__(256) void joint_fix_kernel(
     }
     const float* mf = rowmax + static_cast<size_t>(b) * maxT;
     const float* mg = rowmax + static_cast<size_t>(N) * maxT + static_cast<size_t>(b) * maxU;
+    const float sc = scale != nullptr ? scale[b] : 1.0f;
     const int tend = tb0 + kJointFixT < Tb ? tb0 + kJointFixT : Tb;
     float dgb = 0.0f, dgl = 0.0f;
     for (int t = tb0 + wave; t < tend; t += 4) {
         Cell<float> rec;
         rec.x = log_zero<float>(); rec.y = 0.0f; rec.z = 0.0f; rec.w = 0.0f;
         if (uin) rec = rowtab[(static_cast<size_t>(b) * maxT + t) * maxU + u];
+        rec.y *= sc;
+        rec.z *= sc;
         dgb += rec.y;
         dgl += rec.z;
         float* dfrow = df + (static_cast<size_t>(b) * maxT + t) * A;
@@ -587,7 +592,7 @@ __global__ __launch_bounds__(256) void joint_fix_kernel(
             const float* gr = g + (static_cast<size_t>(b) * maxU + uu) * A;
             float* dgrow = dg + (static_cast<size_t>(b) * maxU + uu) * A;
             for (int k = lane; k < A; k += 64) {
-                const float p = fast_exp(fr[k] + gr[k] + shift);
+                const float p = fast_exp(fr[k] + gr[k] + shift) * sc;
                 unsafeAtomicAdd(dfrow + k, p);
                 unsafeAtomicAdd(dgrow + k, p);
             }

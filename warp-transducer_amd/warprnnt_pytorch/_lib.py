@@ -44,6 +44,10 @@ EXPORTS = {
     "compute_rnnt_loss_bwd": (C.c_int, [_PTR, _PTR, _PTR, C.c_int, C.c_int, _PTR, rnntOptions, C.c_int]),
     "compute_rnnt_loss_add": (C.c_int, [_PTR, _PTR, _PTR, _PTR, _PTR, _PTR, _PTR, C.c_int, C.c_int, _PTR, _PTR,
                                         rnntOptions]),
+    "compute_rnnt_loss_add_fwd": (C.c_int, [_PTR, _PTR, _PTR, _PTR, _PTR, C.c_int, C.c_int, _PTR, _PTR, rnntOptions,
+                                            C.c_int]),
+    "compute_rnnt_loss_add_bwd": (C.c_int, [_PTR, _PTR, _PTR, _PTR, _PTR, _PTR, _PTR, _PTR, C.c_int, C.c_int, _PTR,
+                                            rnntOptions]),
     "rnnt_profile_enable": (None, [C.c_int]),
     "rnnt_profile_reset": (None, []),
     "rnnt_profile_collect": (None, []),

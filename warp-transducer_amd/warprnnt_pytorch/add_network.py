@@ -8,9 +8,9 @@ transducer, whose joint logits are ``trans_acts[:, :, None] + pred_acts[:, None]
 
     RNNTLoss(...)(trans_acts.unsqueeze(2) + pred_acts.unsqueeze(1), labels, act_lens, label_lens)
 
-but it binds ``compute_rnnt_loss_add`` of include/rnnt.h, whose kernels form f+g on the fly and
-reduce the gradient into d(trans_acts) = sum_u and d(pred_acts) = sum_t in-kernel
-(docs/rnnt_notes.tex:147-153).  GPU, float32.
+but it binds ``compute_rnnt_loss_add`` of include/rnnt.h: exp(f+g) = exp(f) exp(g), so the partition
+function and d(trans_acts) = sum_u, d(pred_acts) = sum_t (docs/rnnt_notes.tex:147-153) are three
+small GEMMs per sample on the fp32 matrix cores (csrc/rnnt_joint_kernels.h).  GPU, float32.
 """
 import torch
 from torch.autograd import Function
@@ -49,6 +49,10 @@ def _certify(trans_acts, pred_acts, labels, act_lens, label_lens):
 
 
 class _RNNTAdd(Function):
+    """Two-phase (compute_rnnt_loss_add_fwd / _bwd): forward leaves only the workspace behind, backward
+    runs the gradient kernels once with grad_output (and 1/B for 'mean') folded in -- no extra torch
+    pass over d(trans_acts) / d(pred_acts), as in `warprnnt_pytorch._RNNT`."""
+
     @staticmethod
     def forward(ctx, trans_acts, pred_acts, labels, act_lens, label_lens, blank, reduction):
         _certify(trans_acts, pred_acts, labels, act_lens, label_lens)
@@ -58,36 +62,48 @@ class _RNNTAdd(Function):
         need_grad = trans_acts.requires_grad or pred_acts.requires_grad
         dev = trans_acts.device
         with torch.cuda.device(dev):
-            df = torch.empty_like(trans_acts) if need_grad else None
-            dg = torch.empty_like(pred_acts) if need_grad else None
             costs = torch.empty(B, dtype=torch.float32, device=dev)
             ws = torch.empty(_lib.workspace_bytes(T, U, B, True, 4), dtype=torch.uint8, device=dev)
             opt = _lib.rnntOptions(loc=_lib.RNNT_GPU, num_threads=0,
                                    stream=torch.cuda.current_stream(dev).cuda_stream, blank_label=int(blank),
                                    maxT=T, maxU=U, batch_first=True)
             lab_ptr = labels.data_ptr() if labels.numel() else costs.data_ptr()   # maxU == 1: never read
-            st = lib.compute_rnnt_loss_add(trans_acts.data_ptr(), pred_acts.data_ptr(),
-                                           df.data_ptr() if need_grad else None,
-                                           dg.data_ptr() if need_grad else None, lab_ptr,
-                                           label_lens.data_ptr(), act_lens.data_ptr(), V, B, costs.data_ptr(),
-                                           ws.data_ptr(), opt)
-            _lib.check(st, "compute_rnnt_loss_add")
+            st = lib.compute_rnnt_loss_add_fwd(trans_acts.data_ptr(), pred_acts.data_ptr(), lab_ptr,
+                                               label_lens.data_ptr(), act_lens.data_ptr(), V, B, costs.data_ptr(),
+                                               ws.data_ptr(), opt, 1 if need_grad else 0)
+            _lib.check(st, "compute_rnnt_loss_add_fwd")
             ws.record_stream(torch.cuda.current_stream(dev))
+        ctx.save_for_backward(trans_acts, pred_acts, labels, act_lens, label_lens)
+        ctx.workspace = ws if need_grad else None
+        ctx.blank = int(blank)
+        ctx.mean_scale = 1.0 / B if reduction == "mean" else 1.0
         if reduction in ("sum", "mean"):
             costs = costs.sum().unsqueeze_(-1)
             if reduction == "mean":
                 costs /= B
-                if need_grad:
-                    df /= B
-                    dg /= B
-        ctx.grads = (df, dg)
         return costs
 
     @staticmethod
     def backward(ctx, grad_output):
-        df, dg = ctx.grads
-        go = grad_output.view(-1, 1, 1).to(df)
-        return df.mul_(go), dg.mul_(go), None, None, None, None, None
+        trans_acts, pred_acts, labels, act_lens, label_lens = ctx.saved_tensors
+        lib = _lib.lib()
+        B, T, V = trans_acts.shape
+        U = pred_acts.shape[1]
+        dev = trans_acts.device
+        with torch.cuda.device(dev):
+            scale = (grad_output.reshape(-1).to(device=dev, dtype=torch.float32) * ctx.mean_scale).expand(B).contiguous()
+            df = torch.empty_like(trans_acts)
+            dg = torch.empty_like(pred_acts)
+            opt = _lib.rnntOptions(loc=_lib.RNNT_GPU, num_threads=0,
+                                   stream=torch.cuda.current_stream(dev).cuda_stream, blank_label=ctx.blank,
+                                   maxT=T, maxU=U, batch_first=True)
+            lab_ptr = labels.data_ptr() if labels.numel() else scale.data_ptr()
+            st = lib.compute_rnnt_loss_add_bwd(trans_acts.data_ptr(), pred_acts.data_ptr(), df.data_ptr(),
+                                               dg.data_ptr(), scale.data_ptr(), lab_ptr, label_lens.data_ptr(),
+                                               act_lens.data_ptr(), V, B, ctx.workspace.data_ptr(), opt)
+            _lib.check(st, "compute_rnnt_loss_add_bwd")
+            ctx.workspace.record_stream(torch.cuda.current_stream(dev))
+        return df, dg, None, None, None, None, None
 
 
 def rnnt_loss_add(trans_acts, pred_acts, labels, act_lens, label_lens, blank=0, reduction="mean"):

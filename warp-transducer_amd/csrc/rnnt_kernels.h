@@ -1,6 +1,7 @@
 // rnnt_kernels.h -- the gfx950 kernels of the RNN-T loss hot path (four stages).
 //
-//   1 row_stats_kernel       rows > 2 KB: one wavefront per (b,t,u) row, ONE read of the logits,
+//   1 row_stats_block_kernel rows >= 12 KB: one 256-thread block per (b,t,u) row,
+//     row_stats_kernel       rows > 2 KB: one wavefront per row, ONE read of the logits,
 //     row_stats_tile_kernel  rows <= 2 KB: a block stages a contiguous tile of rows in LDS;
 //                            online log-sum-exp per row + gather of the blank / label logits
 //                                                                      [HBM-bound, E*s read]
@@ -154,6 +155,90 @@ __global__ __launch_bounds__(WAVES * 64) void row_stats_kernel(
     const C logZ = shift + acc_log(S_);
 
     if (lane == 0) {
+        LogPair<C> rec;                                // lattice log-probs are kept in base 2
+        rec.x = vmax((xb - logZ) * C(kLog2e), log_zero<C>());
+        rec.y = has_lab ? vmax((xl - logZ) * C(kLog2e), log_zero<C>()) : log_zero<C>();
+        const size_t idx = lat_index(b, t + u, u, maxT, maxU, Up);
+        lp2[idx] = rec;
+        logz[idx] = logZ;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Pass A, BLOCK form for long rows: the 256 threads of a block share ONE row (thread i takes packets
+// i, i + 256, ...), so a row is consumed in one or two load rounds and the rows being read at any
+// moment form one contiguous window of the tensor -- the access pattern of a flat copy -- instead of
+// thousands of 1 KB pieces 20 KB apart.  Partial (max, sum) pairs meet in LDS.
+// grid = (maxT*maxU, N), block = 256.
+template <typename Tag, bool NT, int K>   // K = packets in flight per thread
+__global__ __launch_bounds__(256) void row_stats_block_kernel(
+        const typename Tag::store* __restrict__ acts, const int* __restrict__ labels,
+        const int* __restrict__ xlen, const int* __restrict__ ylen,
+        LogPair<typename Tag::comp>* __restrict__ lp2, typename Tag::comp* __restrict__ logz,
+        int maxT, int maxU, int Up, int A, int blank, int vec_ok) {
+    using S = typename Tag::store;
+    using C = typename Tag::comp;
+    constexpr int V = Vec<Tag>::N;
+    __shared__ C red_m[4], red_s[4];
+    const int b = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int q = blockIdx.x;
+    const int t = q / maxU, u = q - t * maxU;
+    const int Tb = xlen[b], Ub = ylen[b] + 1;
+    if (t >= Tb || u >= Ub) return;   // padded cell: never read (block-uniform)
+
+    const S* row = acts + (static_cast<size_t>(b) * maxT * maxU + q) * A;
+    int head, nvec, tail0;
+    row_split<S>(reinterpret_cast<uintptr_t>(row), A, vec_ok != 0, head, nvec, tail0);
+
+    C m = neg_inf<C>(), s = 0;
+    for (int e = tid; e < head; e += 256) {
+        C v[1] = {load1<Tag>(row + e)};
+        absorb<C, 1>(v, m, s);
+    }
+    const u32x4* vp = reinterpret_cast<const u32x4*>(row + head);
+    for (int i = tid; i < nvec; i += 256 * K) {
+        uint4 r[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k)
+            if (i + 256 * k < nvec) r[k] = load_packet<NT>(vp + i + 256 * k);
+        C v[K * V];
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            if (i + 256 * k < nvec) {
+                unpack<Tag>(r[k], v + k * V);
+            } else {
+#pragma unroll
+                for (int j = 0; j < V; ++j) v[k * V + j] = neg_inf<C>();
+            }
+        }
+        absorb<C, K * V>(v, m, s);
+    }
+    for (int e = tail0 + tid; e < A; e += 256) {
+        C v[1] = {load1<Tag>(row + e)};
+        absorb<C, 1>(v, m, s);
+    }
+
+    const C Mw = wave_max(m);
+    const C shw = (Mw == neg_inf<C>()) ? C(0) : Mw;
+    const C Sw = wave_sum(s * fast_exp(m - shw));
+    if (lane == 0) { red_m[wave] = Mw; red_s[wave] = Sw; }
+    __syncthreads();
+    if (tid == 0) {
+        const C M = vmax(vmax(red_m[0], red_m[1]), vmax(red_m[2], red_m[3]));
+        const C shift = (M == neg_inf<C>()) ? C(0) : M;
+        C S_ = 0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) S_ += red_s[w] * fast_exp(((red_m[w] == neg_inf<C>()) ? shift : red_m[w]) - shift);
+        const C logZ = shift + acc_log(S_);
+        const bool has_lab = u < Ub - 1;
+        int lab = blank;
+        if (has_lab) {
+            lab = labels[static_cast<size_t>(b) * (maxU - 1) + u];
+            lab = lab < 0 ? 0 : (lab >= A ? A - 1 : lab);
+        }
+        const C xb = load1<Tag>(row + blank);
+        const C xl = load1<Tag>(row + lab);
         LogPair<C> rec;                                // lattice log-probs are kept in base 2
         rec.x = vmax((xb - logZ) * C(kLog2e), log_zero<C>());
         rec.y = has_lab ? vmax((xl - logZ) * C(kLog2e), log_zero<C>()) : log_zero<C>();

@@ -48,7 +48,7 @@ static Layout make_layout(int maxT, int maxU, int N, size_t lat) {
     l.llb = o;   o = align_up(o + N * sizeof(double));
     l.costs = o; o = align_up(o + N * sizeof(double));
     // additive joint only: row maxima of f and g, dense weight matrix W (row stride = maxU rounded up to 4)
-    l.rowmax = o; o = align_up(o + (static_cast<size_t>(maxT) + maxU) * N * sizeof(float));
+    l.rowmax = o; o = align_up(o + ((static_cast<size_t>(maxT) + maxU) * N + 1) * sizeof(float));   // + the +inf sentinel
     l.wmat = o;   o = align_up(o + static_cast<size_t>(maxT) * ((maxU + 3) / 4 * 4) * N * sizeof(float));
     l.total = o + kAlign;                       // slack to align the caller's base pointer
     return l;
@@ -94,9 +94,9 @@ static void prof_accumulate() {
 // ppt = packets per thread of the flat gradient kernel, skew = 0/1 forces the natural-order +
 // skew_kernel route of the tile path off/on (-1: heuristic).  Additive joint: jfnk / jgnk = columns
 // per lane of the DF / DG kernels (0: widest the alignment allows), jfpf / jgpf = operand ping-pong;
-// blk = block-per-row statistics kernel for rows >= 12 KB on/off.
+// blk = block-per-row statistics kernel for rows >= 12 KB on/off, jzs = vocabulary split of the Z kernel (1|4|8).
 struct Tune { int sw = 4, nta = 1, gmax = 4194304, rows = 0, tile = 1, tilekb = 48, ppt = 2, skew = -1;
-              int jfnk = 0, jfpf = 0, jgnk = 0, jgpf = 1, blk = 1; };
+              int jfnk = 0, jfpf = 1, jgnk = 0, jgpf = 1, blk = 1, jzs = 0; };
 static Tune g_tune;
 static bool g_tune_read = false;
 static const Tune& tune() {
@@ -111,7 +111,7 @@ static const Tune& tune() {
             get("gmax", g_tune.gmax); get("rows", g_tune.rows); get("tile", g_tune.tile);
             get("tilekb", g_tune.tilekb); get("ppt", g_tune.ppt); get("skew", g_tune.skew);
             get("jfnk", g_tune.jfnk); get("jfpf", g_tune.jfpf); get("jgnk", g_tune.jgnk); get("jgpf", g_tune.jgpf);
-            get("blk", g_tune.blk);
+            get("blk", g_tune.blk); get("jzs", g_tune.jzs);
         }
     }
     return g_tune;
@@ -367,6 +367,8 @@ static rnntStatus_t run_gpu_joint(const float* f, const float* g, float* df, flo
         return RNNT_STATUS_INVALID_VALUE;
     const bool do_fwd = (phases & 1) != 0, do_bwd = (phases & 2) != 0;
     if (do_bwd && (df == nullptr || dg == nullptr)) return RNNT_STATUS_INVALID_VALUE;
+    // the gradient GEMMs address one sample's rows with 32-bit element offsets
+    if (static_cast<long long>(p.maxT > p.maxU ? p.maxT : p.maxU) * A >= (1LL << 31)) return RNNT_STATUS_INVALID_VALUE;
     const bool training = want_grad;
     const bool prof = prof_prepare();
     auto mark = [&](int i) { if (prof) (void)hipEventRecord(g_prof.ev[i], p.stream); };
@@ -377,18 +379,20 @@ static rnntStatus_t run_gpu_joint(const float* f, const float* g, float* df, flo
     mark(0);
     if (do_fwd) {   // row maxima, then the partition-function GEMM with the log-prob epilogue
         const long long rows = static_cast<long long>(N) * (maxT + maxU);
-        const dim3 rgrid(static_cast<unsigned>((rows + 3) / 4));
-        if (vec)
-            hipLaunchKernelGGL(joint_rowmax_kernel<true>, rgrid, dim3(256), 0, p.stream, f, g, input_lengths,
-                               label_lengths, p.rowmax, maxT, maxU, A, N);
-        else
-            hipLaunchKernelGGL(joint_rowmax_kernel<false>, rgrid, dim3(256), 0, p.stream, f, g, input_lengths,
-                               label_lengths, p.rowmax, maxT, maxU, A, N);
+        const bool per_block = static_cast<size_t>(A) * sizeof(float) >= 12288;   // long rows: a block per row
+        const dim3 rgrid(static_cast<unsigned>(per_block ? rows : (rows + 3) / 4));
+#define RNNT_JMAX(VV, WW)                                                                                      \
+    hipLaunchKernelGGL((joint_rowmax_kernel<VV, WW>), rgrid, dim3(256), 0, p.stream, f, g, input_lengths,       \
+                       label_lengths, p.rowmax, maxT, maxU, A, N)
+        if (per_block) { if (vec) RNNT_JMAX(true, 4); else RNNT_JMAX(false, 4); }
+        else { if (vec) RNNT_JMAX(true, 1); else RNNT_JMAX(false, 1); }
+#undef RNNT_JMAX
         p.check();
         // vocabulary slices per tile: few tiles and a long contraction -> split it over 4 or 8 wavefronts
         const long long all_tiles = static_cast<long long>(N) * tiles;
         const int nchunk = (A + 31) / 32;
-        const int S = (all_tiles >= 4096 || nchunk < 16) ? 1 : ((all_tiles < 1024 && nchunk >= 32) ? 8 : 4);
+        int S = (all_tiles >= 4096 || nchunk < 16) ? 1 : ((all_tiles < 1024 && nchunk >= 32) ? 8 : 4);
+        if (tune().jzs == 1 || tune().jzs == 4 || tune().jzs == 8) S = tune().jzs;
 #define RNNT_JZ(SS, VV)                                                                                          \
     hipLaunchKernelGGL((joint_z_kernel<SS, VV>), dim3(SS == 1 ? (tiles + 3) / 4 : tiles, N),                      \
                        dim3(SS == 1 ? 256 : SS * 64), 0, p.stream, f, g, p.rowmax, labels, input_lengths,        \

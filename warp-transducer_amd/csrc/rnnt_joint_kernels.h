@@ -53,20 +53,30 @@ __device__ __forceinline__ float joint_exp(float x, float m2) {
 }
 
 // ------------------------------------------------------------------------------------------
-// Row maxima, stored TIMES log2(e).  rowmax[0, N*maxT) = mf, rowmax[N*maxT, N*(maxT+maxU)) = mg.  One wavefront per row;
-// rows of the padding (t >= T_b, u > U_b) are skipped.  grid = ceil(rows/4), block = 256.
-template <bool VEC>
+// Row maxima, stored TIMES log2(e).  rowmax[0, N*maxT) = mf, rowmax[N*maxT, N*(maxT+maxU)) = mg,
+// rowmax[N*(maxT+maxU)] = +inf (sentinel).
+// WPR wavefronts share a row (1: wavefront per row; 4: the whole block, for rows >= 12 KB, so that the
+// rows in flight form one contiguous window -- see row_stats_block_kernel); rows of the padding
+// (t >= T_b, u > U_b) are skipped.  grid = ceil(rows * WPR / 4), block = 256.
+template <bool VEC, int WPR>
 __global__ __launch_bounds__(256) void joint_rowmax_kernel(
         const float* __restrict__ f, const float* __restrict__ g, const int* __restrict__ xlen,
         const int* __restrict__ ylen, float* __restrict__ rowmax, int maxT, int maxU, int A, int N) {
-    const long long row = static_cast<long long>(blockIdx.x) * 4 + (threadIdx.x >> 6);
+    __shared__ float red[4];
+    // one extra entry after the maxima holds +inf: operand loads of the gradient GEMMs point masked
+    // rows at it, which makes their exp() exactly 0 without a select on loaded data
+    if (blockIdx.x == 0 && threadIdx.x == 0) rowmax[static_cast<size_t>(N) * (maxT + maxU)] = -neg_inf<float>();
+    constexpr int TPR = 64 * WPR;                          // threads per row
+    const int wave = threadIdx.x >> 6;
+    const long long row = WPR == 4 ? static_cast<long long>(blockIdx.x)
+                                   : static_cast<long long>(blockIdx.x) * 4 + wave;
     const long long rows_f = static_cast<long long>(N) * maxT;
     if (row >= rows_f + static_cast<long long>(N) * maxU) return;
-    const int lane = threadIdx.x & 63;
+    const int tid = WPR == 4 ? static_cast<int>(threadIdx.x) : static_cast<int>(threadIdx.x & 63);
     const float* p;
     if (row < rows_f) {
         const int b = static_cast<int>(row / maxT);
-        if (static_cast<int>(row - static_cast<long long>(b) * maxT) >= xlen[b]) return;
+        if (static_cast<int>(row - static_cast<long long>(b) * maxT) >= xlen[b]) return;   // uniform per row
         p = f + row * A;
     } else {
         const long long r = row - rows_f;
@@ -76,16 +86,22 @@ __global__ __launch_bounds__(256) void joint_rowmax_kernel(
     }
     float m = neg_inf<float>();
     if constexpr (VEC) {
-        const float4* p4 = reinterpret_cast<const float4*>(p);
-        for (int i = lane; i < (A >> 2); i += 64) {
-            const float4 v = p4[i];
-            m = fmaxf(fmaxf(m, fmaxf(v.x, v.y)), fmaxf(v.z, v.w));
+        const u32x4* p4 = reinterpret_cast<const u32x4*>(p);
+        for (int i = tid; i < (A >> 2); i += TPR) {
+            float v[4];
+            unpack<F32>(load_packet<true>(p4 + i), v);
+            m = fmaxf(fmaxf(m, fmaxf(v[0], v[1])), fmaxf(v[2], v[3]));
         }
     } else {
-        for (int i = lane; i < A; i += 64) m = fmaxf(m, p[i]);
+        for (int i = tid; i < A; i += TPR) m = fmaxf(m, p[i]);
     }
     m = wave_max(m);
-    if (lane == 0) rowmax[row] = fmaxf(m, kJointMinMax) * static_cast<float>(kLog2e);
+    if constexpr (WPR == 4) {
+        if ((threadIdx.x & 63) == 0) red[wave] = m;
+        __syncthreads();
+        m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    }
+    if (tid == 0) rowmax[row] = fmaxf(m, kJointMinMax) * static_cast<float>(kLog2e);
 }
 
 // Up to four consecutive floats as one 4/8/16-byte access (the address is NK*4-byte aligned).
@@ -343,8 +359,7 @@ __global__ __launch_bounds__(256) void joint_df_kernel(
     const int t0 = blockIdx.y * 32;
     const int Tb = xlen[b], Ub = ylen[b] + 1;
     const float* mf = rowmax + static_cast<size_t>(b) * maxT;
-    const float* mg = rowmax + static_cast<size_t>(N) * maxT + static_cast<size_t>(b) * maxU;
-    const float* fb = f + static_cast<size_t>(b) * maxT * A + kc;
+    const float* fb = f + static_cast<size_t>(b) * maxT * A + (kin ? kc : A - NK);   // lanes past the vocabulary read a valid column
     float* dfb = df + static_cast<size_t>(b) * maxT * A + kc;
     f32x16 acc[NK];
 #pragma unroll
@@ -366,27 +381,29 @@ __global__ __launch_bounds__(256) void joint_df_kernel(
     }
 
     const bool tin = t0 + col < Tb;
-    const float sc = scale != nullptr ? scale[b] : 1.0f;   // per-sample factor (grad_output / N), folded into W
+    // per-sample factor (grad_output / N): applied in the epilogue -- a multiply on the W operand inside
+    // the contraction loop sits in front of every MFMA group and cost 25 % of the kernel
+    const float sc = scale != nullptr ? scale[b] : 1.0f;
+    // Operand loads are UNCONDITIONAL and nothing selects on a loaded value (a select lets the compiler
+    // turn the load into a branch with a full vmcnt(0) drain inside the prefetch phase): label rows past
+    // the sample read the +inf sentinel as their maximum, so their B operand is exactly 0 (W is finite:
+    // zero in the padding, zero in the pad columns, <= e^40 elsewhere); time rows past the sample and
+    // lanes past the vocabulary compute on a valid neighbour and store nothing.
     const float* wrow = wmat + (static_cast<size_t>(b) * maxT + (tin ? t0 + col : Tb - 1)) * Upad;
-    const float* gb = g + static_cast<size_t>(b) * maxU * A + kc;
+    const float* gb = g + static_cast<size_t>(b) * maxU * A + (kin ? kc : A - NK);
+    const unsigned Au = static_cast<unsigned>(A);          // maxU * A < 2^31 (host check): 32-bit offsets
+    const unsigned mg0 = static_cast<unsigned>(N) * maxT + static_cast<unsigned>(b) * maxU;
+    const unsigned sentinel = static_cast<unsigned>(N) * (maxT + maxU);
     auto load = [&](JointOperands<NK>& s, int u2) {
         const int ub = u2 + 4 * half;
-        float4 w4 = {0.0f, 0.0f, 0.0f, 0.0f};
-        if (tin && ub < Ub) w4 = *reinterpret_cast<const float4*>(wrow + ub);   // ub + 3 < Upad
-        s.w[0] = w4.x * sc; s.w[1] = w4.y * sc; s.w[2] = w4.z * sc; s.w[3] = w4.w * sc;
+        const float4 w4 = *reinterpret_cast<const float4*>(wrow + (ub < Upad - 4 ? ub : Upad - 4));
+        s.w[0] = w4.x; s.w[1] = w4.y; s.w[2] = w4.z; s.w[3] = w4.w;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int u = ub + i;
             const bool uin = u < Ub;
-            const int us = uin ? u : Ub - 1;
-            if (!uin) s.w[i] = 0.0f;                       // columns past the sample: zero / never written
-            s.m[i] = mg[us];
-            if (uin && kin) {
-                joint_loadv<NK>(gb + static_cast<size_t>(us) * A, s.x[i]);
-            } else {
-#pragma unroll
-                for (int n = 0; n < NK; ++n) s.x[i][n] = neg_inf<float>();
-            }
+            s.m[i] = rowmax[uin ? mg0 + u : sentinel];
+            joint_loadv<NK>(gb + static_cast<unsigned>(uin ? u : Ub - 1) * Au, s.x[i]);
         }
     };
 
@@ -397,12 +414,7 @@ __global__ __launch_bounds__(256) void joint_df_kernel(
             const int t = t0 + mfma_row(r, lane);
             const int ts = t < Tb ? t : Tb - 1;
             mt[r] = mf[ts];
-            if (kin) {
-                joint_loadv<NK>(fb + static_cast<size_t>(ts) * A, fv[r]);
-            } else {
-#pragma unroll
-                for (int n = 0; n < NK; ++n) fv[r][n] = 0.0f;
-            }
+            joint_loadv<NK>(fb + static_cast<unsigned>(ts) * Au, fv[r]);
         }
     };
     if constexpr (PF) {
@@ -427,7 +439,9 @@ __global__ __launch_bounds__(256) void joint_df_kernel(
         for (int u2 = 0; u2 < Ub; u2 += 8) {
             JointOperands<NK> s0;
             load(s0, u2);
+            __builtin_amdgcn_sched_barrier(0);             // all loads of the step first, then its MFMAs
             joint_mma<NK>(s0, acc);
+            __builtin_amdgcn_sched_barrier(0);
         }
         load_f();
     }
@@ -439,7 +453,7 @@ __global__ __launch_bounds__(256) void joint_df_kernel(
         if (t >= maxT) continue;
         float o[NK];
 #pragma unroll
-        for (int n = 0; n < NK; ++n) o[n] = t < Tb ? joint_exp(fv[r][n], mt[r]) * acc[n][r] : 0.0f;
+        for (int n = 0; n < NK; ++n) o[n] = t < Tb ? joint_exp(fv[r][n], mt[r]) * (acc[n][r] * sc) : 0.0f;
         joint_storev<NK>(dfb + static_cast<size_t>(t) * A, o);
     }
 }
@@ -462,7 +476,6 @@ __global__ __launch_bounds__(256) void joint_dg_kernel(
     const bool kin = kc < A;
     const int u0 = blockIdx.y * 32;
     const int Tb = xlen[b], Ub = ylen[b] + 1;
-    const float* mf = rowmax + static_cast<size_t>(b) * maxT;
     const float* mg = rowmax + static_cast<size_t>(N) * maxT + static_cast<size_t>(b) * maxU;
     f32x16 acc[NK];
 #pragma unroll
@@ -471,24 +484,22 @@ __global__ __launch_bounds__(256) void joint_dg_kernel(
         for (int r = 0; r < 16; ++r) acc[n][r] = 0.0f;
 
     if (u0 < Ub) {
-        const bool uin = u0 + col < Ub;
-        const float sc = scale != nullptr ? scale[b] : 1.0f;
-        const float* wcol = wmat + static_cast<size_t>(b) * maxT * Upad + (uin ? u0 + col : 0);
-        const float* fb = f + static_cast<size_t>(b) * maxT * A + kc;
+        // unconditional operand loads, masking through the +inf sentinel (see joint_df_kernel); label
+        // rows past the sample read column 0 and produce accumulator rows nobody stores
+        const float* wcol = wmat + static_cast<size_t>(b) * maxT * Upad + (u0 + col < Ub ? u0 + col : 0);
+        const float* fb = f + static_cast<size_t>(b) * maxT * A + (kin ? kc : A - NK);
+        const unsigned Au = static_cast<unsigned>(A), Upu = static_cast<unsigned>(Upad);   // 32-bit offsets (host check)
+        const unsigned mf0 = static_cast<unsigned>(b) * maxT;
+        const unsigned sentinel = static_cast<unsigned>(N) * (maxT + maxU);
         auto load = [&](JointOperands<NK>& s, int t2) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int t = t2 + 4 * half + i;
                 const bool tin = t < Tb;
-                const int ts = tin ? t : Tb - 1;
-                s.w[i] = (tin && uin) ? wcol[static_cast<size_t>(ts) * Upad] * sc : 0.0f;
-                s.m[i] = mf[ts];
-                if (tin && kin) {
-                    joint_loadv<NK>(fb + static_cast<size_t>(ts) * A, s.x[i]);
-                } else {
-#pragma unroll
-                    for (int n = 0; n < NK; ++n) s.x[i][n] = neg_inf<float>();
-                }
+                const unsigned ts = static_cast<unsigned>(tin ? t : Tb - 1);
+                s.w[i] = wcol[ts * Upu];
+                s.m[i] = rowmax[tin ? mf0 + t : sentinel];
+                joint_loadv<NK>(fb + ts * Au, s.x[i]);
             }
         };
         if constexpr (PF) {
@@ -518,6 +529,7 @@ __global__ __launch_bounds__(256) void joint_dg_kernel(
         }
     }
     if (!kin) return;
+    const float sc = scale != nullptr ? scale[b] : 1.0f;   // per-sample factor, applied once per output
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int u = u0 + mfma_row(r, lane);
@@ -528,7 +540,7 @@ __global__ __launch_bounds__(256) void joint_dg_kernel(
             const float mu = mg[u];
             joint_loadv<NK>(g + at, o);
 #pragma unroll
-            for (int n = 0; n < NK; ++n) o[n] = joint_exp(o[n], mu) * acc[n][r];
+            for (int n = 0; n < NK; ++n) o[n] = joint_exp(o[n], mu) * (acc[n][r] * sc);
         } else {
 #pragma unroll
             for (int n = 0; n < NK; ++n) o[n] = 0.0f;

@@ -770,6 +770,8 @@ __global__ __launch_bounds__(256) void coef_kernel(
     const int n = uniform(static_cast<int>(i0 / Up));
     const int u = static_cast<int>(i0 - static_cast<long long>(n) * Up) + (threadIdx.x & 63);
     const int t = n - u;
+    if (wmat != nullptr && u >= maxU && u < Upad && t >= 0 && t < maxT)   // additive joint: W's pad columns are zero
+        wmat[(static_cast<size_t>(b) * maxT + t) * Upad + u] = 0.0f;
     if (u >= maxU || t < 0 || t >= maxT) return;              // not a row of the tensor
     const int Tb = xlen[b], Ub = ylen[b] + 1;
     Cell<L> o;      // padded row: c = "log zero" (exp(x + c) = 0 for any x), no corrections, flagged

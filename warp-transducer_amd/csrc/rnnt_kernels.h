@@ -256,6 +256,67 @@ __global__ __launch_bounds__(256) void row_stats_block_kernel(
 // reduce it out of LDS: pass 1 max, pass 2 sum-exp.  Lane-to-element order is rotated by the
 // row number when A is even so that the RT rows fall into different LDS banks.
 // grid = ceil(R / RT), dynamic LDS = RT*A*s + 32 bytes.
+// Reduce phase of the tile kernel for rows made of whole LDS words (W = uint4: 16-byte packets,
+// uint2: 8-byte words; NE elements each).  Lane j of the row's G lanes owns words j, j+G, ...  When a
+// lane owns at most kTileRegWords of them it reads them ONCE, back to back, into registers and runs
+// both passes (max, then sum of exp2) from there; counters on c4 showed the two rolled passes over LDS
+// at 12.8 VALU instructions per element (loop control + addressing per 8-byte read, twice).  A word
+// index past the row is clamped to the last word (harmless for the max) and its sum is dropped.
+constexpr int kTileRegWords = 16;   // 8 for 16-bit storage (the unpacked values stay live between the passes)
+
+template <typename Tag, typename W, int NE, typename Unpack>
+__device__ __forceinline__ void tile_reduce_words(const W* __restrict__ words, int nw, int j, int G,
+                                                  typename Tag::comp& m_out, typename Tag::comp& shift_out,
+                                                  typename Tag::comp& sum_out, Unpack unpack_word) {
+    using C = typename Tag::comp;
+    constexpr int KW = sizeof(typename Tag::store) == 2 ? kTileRegWords / 2 : kTileRegWords;
+    C m = neg_inf<C>(), sum = 0, shift = 0;
+    if (nw <= KW * G) {
+        W r[KW];
+#pragma unroll
+        for (int i = 0; i < KW; ++i) {
+            const int p = j + i * G;
+            r[i] = words[p < nw ? p : nw - 1];
+        }
+#pragma unroll
+        for (int i = 0; i < KW; ++i) {
+            C v[NE];
+            unpack_word(r[i], v);
+#pragma unroll
+            for (int e = 0; e < NE; ++e) m = vmax(m, v[e]);
+        }
+        for (int off = G / 2; off > 0; off >>= 1) m = vmax(m, __shfl_xor(m, off, kWave));
+        shift = (m == neg_inf<C>()) ? C(0) : m;
+        const C sh2 = -shift * C(kLog2e);
+#pragma unroll
+        for (int i = 0; i < KW; ++i) {
+            C v[NE];
+            unpack_word(r[i], v);
+            C ps = 0;
+#pragma unroll
+            for (int e = 0; e < NE; ++e) ps += fast_exp2(v[e] * C(kLog2e) + sh2);
+            sum += (j + i * G < nw) ? ps : C(0);
+        }
+    } else {
+        for (int p = j; p < nw; p += G) {
+            C v[NE];
+            unpack_word(words[p], v);
+#pragma unroll
+            for (int e = 0; e < NE; ++e) m = vmax(m, v[e]);
+        }
+        for (int off = G / 2; off > 0; off >>= 1) m = vmax(m, __shfl_xor(m, off, kWave));
+        shift = (m == neg_inf<C>()) ? C(0) : m;
+        const C sh2 = -shift * C(kLog2e);
+        for (int p = j; p < nw; p += G) {
+            C v[NE];
+            unpack_word(words[p], v);
+#pragma unroll
+            for (int e = 0; e < NE; ++e) sum += fast_exp2(v[e] * C(kLog2e) + sh2);
+        }
+    }
+    m_out = m; shift_out = shift; sum_out = sum;
+}
+
 constexpr int kTileMaxRowBytes = 2048;
 #ifndef RNNT_TILE_ABLATE
 #define RNNT_TILE_ABLATE 0     // development only: bit0 skips the LDS reduce phase, bit1 the global loads
@@ -317,44 +378,13 @@ __global__ __launch_bounds__(256) void row_stats_tile_kernel(
     // row allows it and forms exp(x - shift) as exp2(x*log2e - shift*log2e): one fma + one v_exp_f32.
     if (phase == 0 && A % V == 0) {
         // rows are whole 16-byte packets: ds_read_b128
-        const uint4* rowpk = tile_raw + rl * (A / V);
-        const int npk = A / V;
-        for (int p = j; p < npk; p += G) {
-            C v[V];
-            unpack<Tag>(rowpk[p], v);
-#pragma unroll
-            for (int i = 0; i < V; ++i) m = vmax(m, v[i]);
-        }
-#pragma unroll
-        for (int off = G / 2; off > 0; off >>= 1) m = vmax(m, __shfl_xor(m, off, kWave));
-        shift = (m == neg_inf<C>()) ? C(0) : m;
-        const C sh2 = -shift * C(kLog2e);
-        for (int p = j; p < npk; p += G) {
-            C v[V];
-            unpack<Tag>(rowpk[p], v);
-#pragma unroll
-            for (int i = 0; i < V; ++i) sum += fast_exp2(v[i] * C(kLog2e) + sh2);
-        }
+        tile_reduce_words<Tag, uint4, V>(tile_raw + rl * (A / V), A / V, j, G, m, shift, sum,
+                                         [](const uint4& w, C* v) { unpack<Tag>(w, v); });
     } else if (H > 1 && (phase % H) == 0 && A % H == 0) {
         // rows are whole 8-byte words: ds_read_b64
-        const uint2* rowh = reinterpret_cast<const uint2*>(tile_raw) + (phase + rl * A) / H;
-        const int nh = A / H;
-        for (int p = j; p < nh; p += G) {
-            C v[H > 1 ? H : 1];
-            unpack_half<Tag>(rowh[p], v);
-#pragma unroll
-            for (int i = 0; i < H; ++i) m = vmax(m, v[i]);
-        }
-#pragma unroll
-        for (int off = G / 2; off > 0; off >>= 1) m = vmax(m, __shfl_xor(m, off, kWave));
-        shift = (m == neg_inf<C>()) ? C(0) : m;
-        const C sh2 = -shift * C(kLog2e);
-        for (int p = j; p < nh; p += G) {
-            C v[H > 1 ? H : 1];
-            unpack_half<Tag>(rowh[p], v);
-#pragma unroll
-            for (int i = 0; i < H; ++i) sum += fast_exp2(v[i] * C(kLog2e) + sh2);
-        }
+        tile_reduce_words<Tag, uint2, (H > 1 ? H : 1)>(reinterpret_cast<const uint2*>(tile_raw) + (phase + rl * A) / H,
+                                                       A / H, j, G, m, shift, sum,
+                                                       [](const uint2& w, C* v) { unpack_half<Tag>(w, v); });
     } else {
         const int rot = (A & 1) ? 0 : (rl % A);
         for (int e = j; e < A; e += G) {

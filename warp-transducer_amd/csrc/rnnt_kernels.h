@@ -262,14 +262,13 @@ __global__ __launch_bounds__(256) void row_stats_block_kernel(
 // both passes (max, then sum of exp2) from there; counters on c4 showed the two rolled passes over LDS
 // at 12.8 VALU instructions per element (loop control + addressing per 8-byte read, twice).  A word
 // index past the row is clamped to the last word (harmless for the max) and its sum is dropped.
-constexpr int kTileRegWords = 16;   // 8 for 16-bit storage (the unpacked values stay live between the passes)
+constexpr int kTileRegWords = 16;   // one-shot kernel; halved for 16-bit storage (the unpacked values stay live)
 
-template <typename Tag, typename W, int NE, typename Unpack>
+template <typename Tag, typename W, int NE, int KW, typename Unpack>
 __device__ __forceinline__ void tile_reduce_words(const W* __restrict__ words, int nw, int j, int G,
                                                   typename Tag::comp& m_out, typename Tag::comp& shift_out,
                                                   typename Tag::comp& sum_out, Unpack unpack_word) {
     using C = typename Tag::comp;
-    constexpr int KW = sizeof(typename Tag::store) == 2 ? kTileRegWords / 2 : kTileRegWords;
     C m = neg_inf<C>(), sum = 0, shift = 0;
     if (nw <= KW * G) {
         W r[KW];
@@ -378,11 +377,13 @@ __global__ __launch_bounds__(256) void row_stats_tile_kernel(
     // row allows it and forms exp(x - shift) as exp2(x*log2e - shift*log2e): one fma + one v_exp_f32.
     if (phase == 0 && A % V == 0) {
         // rows are whole 16-byte packets: ds_read_b128
-        tile_reduce_words<Tag, uint4, V>(tile_raw + rl * (A / V), A / V, j, G, m, shift, sum,
-                                         [](const uint4& w, C* v) { unpack<Tag>(w, v); });
+        constexpr int KW = sizeof(S) == 2 ? kTileRegWords / 2 : kTileRegWords;
+        tile_reduce_words<Tag, uint4, V, KW>(tile_raw + rl * (A / V), A / V, j, G, m, shift, sum,
+                                             [](const uint4& w, C* v) { unpack<Tag>(w, v); });
     } else if (H > 1 && (phase % H) == 0 && A % H == 0) {
         // rows are whole 8-byte words: ds_read_b64
-        tile_reduce_words<Tag, uint2, (H > 1 ? H : 1)>(reinterpret_cast<const uint2*>(tile_raw) + (phase + rl * A) / H,
+        constexpr int KW = sizeof(S) == 2 ? kTileRegWords / 2 : kTileRegWords;
+        tile_reduce_words<Tag, uint2, (H > 1 ? H : 1), KW>(reinterpret_cast<const uint2*>(tile_raw) + (phase + rl * A) / H,
                                                        A / H, j, G, m, shift, sum,
                                                        [](const uint2& w, C* v) { unpack_half<Tag>(w, v); });
     } else {

@@ -22,6 +22,7 @@ struct F16 { using store = uint16_t; using comp = float;  };
 
 // 16-byte packet as a native vector (lowers to global_load/store_dwordx4).
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 
 template <bool NT> __device__ __forceinline__ uint4 load_packet(const u32x4* p) {
     u32x4 v;

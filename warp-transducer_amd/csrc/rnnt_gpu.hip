@@ -95,7 +95,7 @@ static void prof_accumulate() {
 // skew_kernel route of the tile path off/on (-1: heuristic).  Additive joint: jfnk / jgnk = columns
 // per lane of the DF / DG kernels (0: widest the alignment allows), jfpf / jgpf = operand ping-pong;
 // blk = block-per-row statistics kernel for rows >= 12 KB on/off, jzs = vocabulary split of the Z kernel (1|4|8).
-struct Tune { int sw = 4, nta = 1, gmax = 4194304, rows = 0, tile = 1, tilekb = 48, ppt = 2, skew = -1;
+struct Tune { int sw = 4, nta = 1, gmax = 4194304, rows = 0, tile = 1, tilekb = 52, ppt = 2, skew = -1;
               int jfnk = 0, jfpf = 1, jgnk = 0, jgpf = 1, blk = 1, jzs = 0; };
 static Tune g_tune;
 static bool g_tune_read = false;

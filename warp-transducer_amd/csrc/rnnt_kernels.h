@@ -318,7 +318,7 @@ __device__ __forceinline__ void tile_reduce_words(const W* __restrict__ words, i
 
 constexpr int kTileMaxRowBytes = 2048;
 #ifndef RNNT_TILE_ABLATE
-#define RNNT_TILE_ABLATE 0     // development only: bit0 skips the LDS reduce phase, bit1 the global loads
+#define RNNT_TILE_ABLATE 0     // development only: bit0 skips the LDS reduce phase, bit1 the global loads, bit2 the result stores
 #endif
 
 template <typename Tag, int G>
@@ -349,24 +349,51 @@ __global__ __launch_bounds__(256) void row_stats_tile_kernel(
     const int nbody = (n_el - head) / V;
     const int tail0 = head + nbody * V;
 
-    // ---- global -> LDS, the tile keeps the 16-byte phase of its global address
+    // ---- global -> LDS, the tile keeps the 16-byte phase of its global address.  ALL packets of the
+    // tile are requested before the first one is stored (one memory round trip per block, not one per
+    // four packets), then the row metadata, then everything drains into LDS.
     for (int e = threadIdx.x; e < head; e += 256) tile[phase + e] = base[e];
+    constexpr int kTilePk = 12;                            // packets per thread: tiles up to 48 KB
+    uint4 pk[kTilePk];
+    const u32x4* src = reinterpret_cast<const u32x4*>(base + head);
     if (!(RNNT_TILE_ABLATE & 2)) {
-        const u32x4* src = reinterpret_cast<const u32x4*>(base + head);
+#pragma unroll
+        for (int i = 0; i < kTilePk; ++i)
+            if (i * 256 < nbody) {                         // block-uniform
+                const int pi = i * 256 + static_cast<int>(threadIdx.x);
+                pk[i] = load_packet<true>(src + (pi < nbody ? pi : nbody - 1));
+            }
+    }
+    __builtin_amdgcn_sched_barrier(0);                     // the packets go out before the index arithmetic below
+    // The row's position, lengths and label: requested right behind the tile's packets, by every lane,
+    // as three independent loads (the label index is clamped instead of depending on the lengths), so
+    // they have long arrived when the epilogue needs them.  Done at the end, as two dependent global
+    // latencies, they held the block's LDS tile for 2.6 us of its 8.7 us life (c4).
+    const int rl = threadIdx.x / G, j = threadIdx.x % G;
+    const unsigned TU = static_cast<unsigned>(maxT) * maxU;
+    const unsigned long long b0 = r0 / TU;                 // block-uniform
+    unsigned q = static_cast<unsigned>(r0 - b0 * TU) + static_cast<unsigned>(rl);
+    int b = static_cast<int>(b0);
+    while (q >= TU) { q -= TU; ++b; }
+    const int nb = static_cast<int>(R / TU);
+    b = b < nb ? b : nb - 1;                               // lanes past the last row: any valid sample
+    const int t = static_cast<int>(q / static_cast<unsigned>(maxU));
+    const int u = static_cast<int>(q) - t * maxU;
+    const int Tb = xlen[b], Ub = ylen[b] + 1;
+    int lab = labels[maxU > 1 ? static_cast<size_t>(b) * (maxU - 1) + (u < maxU - 1 ? u : maxU - 2) : 0];
+    if (!(RNNT_TILE_ABLATE & 2)) {
         uint4* dst = tile_raw + (phase + head) / V;
-        int p = threadIdx.x;
-        for (; p + 768 < nbody; p += 1024) {
-            const uint4 a0 = load_packet<true>(src + p), a1 = load_packet<true>(src + p + 256),
-                        a2 = load_packet<true>(src + p + 512), a3 = load_packet<true>(src + p + 768);
-            dst[p] = a0; dst[p + 256] = a1; dst[p + 512] = a2; dst[p + 768] = a3;
+#pragma unroll
+        for (int i = 0; i < kTilePk; ++i) {
+            const int pi = i * 256 + static_cast<int>(threadIdx.x);
+            if (i * 256 < nbody && pi < nbody) dst[pi] = pk[i];
         }
-        for (; p < nbody; p += 256) dst[p] = load_packet<true>(src + p);
+        for (int pi = kTilePk * 256 + threadIdx.x; pi < nbody; pi += 256) dst[pi] = load_packet<true>(src + pi);   // > 48 KB tiles
     }
     for (int e = tail0 + threadIdx.x; e < n_el; e += 256) tile[phase + e] = base[e];
     __syncthreads();
 
     // ---- G lanes per row
-    const int rl = threadIdx.x / G, j = threadIdx.x % G;
     if (rl >= nrows) return;                                   // whole lane groups leave together
     if ((RNNT_TILE_ABLATE & 1) && threadIdx.x != 9999) { if (tile[phase + threadIdx.x] == S(12345)) logz[0] = 1; return; }
     const S* rowp = tile + phase + rl * A;
@@ -406,37 +433,23 @@ __global__ __launch_bounds__(256) void row_stats_tile_kernel(
 #pragma unroll
     for (int off = G / 2; off > 0; off >>= 1) sum += __shfl_xor(sum, off, kWave);
 
-    if (j == 0) {
-        // (b, t, u) of the row: the 64-bit division is done for the block's first row only,
-        // per row 32-bit arithmetic remains
-        const unsigned TU = static_cast<unsigned>(maxT) * maxU;
-        const unsigned long long b0 = r0 / TU;
-        unsigned q = static_cast<unsigned>(r0 - b0 * TU) + static_cast<unsigned>(rl);
-        int b = static_cast<int>(b0);
-        while (q >= TU) { q -= TU; ++b; }
-        const int t = static_cast<int>(q / static_cast<unsigned>(maxU));
-        const int u = static_cast<int>(q) - t * maxU;
-        const int Tb = xlen[b], Ub = ylen[b] + 1;
-        if (t < Tb && u < Ub) {
-            const C logZ = shift + fast_log(sum);
-            const bool has_lab = u < Ub - 1;
-            int lab = blank;
-            if (has_lab) {
-                lab = labels[static_cast<size_t>(b) * (maxU - 1) + u];
-                lab = lab < 0 ? 0 : (lab >= A ? A - 1 : lab);
-            }
-            LogPair<C> rec;                            // lattice log-probs are kept in base 2
-            rec.x = vmax((load1<Tag>(rowp + blank) - logZ) * C(kLog2e), log_zero<C>());
-            rec.y = has_lab ? vmax((load1<Tag>(rowp + lab) - logZ) * C(kLog2e), log_zero<C>()) : log_zero<C>();
-            if (natural) {
-                Cell<C> nrec;
-                nrec.x = rec.x; nrec.y = rec.y; nrec.z = logZ; nrec.w = 0;
-                natural[r0 + rl] = nrec;
-            } else {
-                const size_t idx = lat_index(b, t + u, u, maxT, maxU, Up);
-                lp2[idx] = rec;
-                logz[idx] = logZ;
-            }
+    if (j == 0 && t < Tb && u < Ub) {
+        const C logZ = shift + fast_log(sum);
+        const bool has_lab = u < Ub - 1;
+        lab = has_lab ? (lab < 0 ? 0 : (lab >= A ? A - 1 : lab)) : blank;
+        LogPair<C> rec;                            // lattice log-probs are kept in base 2
+        rec.x = vmax((load1<Tag>(rowp + blank) - logZ) * C(kLog2e), log_zero<C>());
+        rec.y = has_lab ? vmax((load1<Tag>(rowp + lab) - logZ) * C(kLog2e), log_zero<C>()) : log_zero<C>();
+        if ((RNNT_TILE_ABLATE & 4) && rec.x != C(12345)) {
+            // development only: results computed, not stored
+        } else if (natural) {
+            Cell<C> nrec;
+            nrec.x = rec.x; nrec.y = rec.y; nrec.z = logZ; nrec.w = 0;
+            natural[r0 + rl] = nrec;
+        } else {
+            const size_t idx = lat_index(b, t + u, u, maxT, maxU, Up);
+            lp2[idx] = rec;
+            logz[idx] = logZ;
         }
     }
 }

@@ -91,12 +91,12 @@ static void prof_accumulate() {
 // measured best; see profiles/).  sw = waves per block of the row-stats kernel (2|4|8),
 // nta = non-temporal stats loads, gmax = grid cap of the flat gradient kernel, rows = 1 forces
 // the row-form gradient kernel, tile / tilekb = LDS-tile stats kernel on/off and its LDS budget,
-// ppt = packets per thread of the flat gradient kernel, skew = 0/1 forces the natural-order +
-// skew_kernel route of the tile path off/on (-1: heuristic).  Additive joint: jfnk / jgnk = columns
+// ppt = packets per thread of the flat gradient kernel.  Additive joint: jfnk / jgnk = columns
 // per lane of the DF / DG kernels (0: widest the alignment allows), jfpf / jgpf = operand ping-pong;
-// blk = block-per-row statistics kernel for rows >= 12 KB on/off, jzs = vocabulary split of the Z kernel (1|4|8).
-struct Tune { int sw = 4, nta = 1, gmax = 4194304, rows = 0, tile = 1, tilekb = 52, ppt = 2, skew = -1;
-              int jfnk = 0, jfpf = 1, jgnk = 0, jgpf = 1, blk = 1, jzs = 0; };
+// blk = block-per-row statistics kernel for rows >= 12 KB on/off, jzs = vocabulary split of the Z kernel (1|4|8),
+// xcd = XCD-aware tile order of the short-row statistics kernel on/off.
+struct Tune { int sw = 4, nta = 1, gmax = 4194304, rows = 0, tile = 1, tilekb = 52, ppt = 2;
+              int jfnk = 0, jfpf = 1, jgnk = 0, jgpf = 1, blk = 1, jzs = 0, xcd = 1; };
 static Tune g_tune;
 static bool g_tune_read = false;
 static const Tune& tune() {
@@ -109,9 +109,9 @@ static const Tune& tune() {
             };
             get("sw", g_tune.sw); get("nta", g_tune.nta);
             get("gmax", g_tune.gmax); get("rows", g_tune.rows); get("tile", g_tune.tile);
-            get("tilekb", g_tune.tilekb); get("ppt", g_tune.ppt); get("skew", g_tune.skew);
+            get("tilekb", g_tune.tilekb); get("ppt", g_tune.ppt);
             get("jfnk", g_tune.jfnk); get("jfpf", g_tune.jfpf); get("jgnk", g_tune.jgnk); get("jgpf", g_tune.jgpf);
-            get("blk", g_tune.blk); get("jzs", g_tune.jzs);
+            get("blk", g_tune.blk); get("jzs", g_tune.jzs); get("xcd", g_tune.xcd);
         }
     }
     return g_tune;
@@ -165,7 +165,6 @@ static bool make_plan(Plan<C>& p, int A, int N, const rnntOptions& opt, void* wo
 template <typename Tag>
 static void launch_row_stats(Plan<typename Tag::comp>& p, const typename Tag::store* acts, int vec_ok) {
     using S = typename Tag::store;
-    using C = typename Tag::comp;
     const Tune& tn = tune();
     const size_t row_bytes = static_cast<size_t>(p.A) * sizeof(S);
     if (tn.tile && vec_ok && row_bytes <= static_cast<size_t>(kTileMaxRowBytes)) {
@@ -178,16 +177,11 @@ static void launch_row_stats(Plan<typename Tag::comp>& p, const typename Tag::st
         const unsigned long long Rall = static_cast<unsigned long long>(p.N) * p.cells_per_sample;
         const unsigned tgrid = static_cast<unsigned>((Rall + RT - 1) / RT);
         if (lds <= 64 * 1024) {
-            // large lattices of not-too-short rows: coalesced natural-order records (parked in the
-            // not-yet-used row table) + an LDS-tiled natural->skewed pass instead of two scattered
-            // stores per row (measured: +10 % on this stage for 2 KB rows, neutral to slightly
-            // negative for 200-byte rows)
-            const bool via_natural = tn.skew >= 0 ? tn.skew != 0 : (Rall >= (1ull << 20) && row_bytes >= 512);
-            Cell<C>* natural = via_natural ? p.rowtab : nullptr;
+            const unsigned xgrid = tn.xcd ? (tgrid + 7u) / 8u * 8u : tgrid;   // XCD remap wants a multiple of 8
 #define RNNT_TILE(GG)                                                                                       \
-    hipLaunchKernelGGL((row_stats_tile_kernel<Tag, GG>), dim3(tgrid), dim3(256), lds, p.stream, acts, p.labels, \
-                       p.input_lengths, p.label_lengths, p.lp2, p.logz, natural, Rall, p.maxT, p.maxU, p.Up,  \
-                       p.A, p.blank)
+    hipLaunchKernelGGL((row_stats_tile_kernel<Tag, GG>), dim3(xgrid), dim3(256), lds, p.stream, acts, p.labels, \
+                       p.input_lengths, p.label_lengths, p.lp2, p.logz, Rall, p.maxT, p.maxU, p.Up,           \
+                       p.A, p.blank, tn.xcd)
             switch (G) {
                 case 1: RNNT_TILE(1); break;
                 case 2: RNNT_TILE(2); break;
@@ -199,12 +193,6 @@ static void launch_row_stats(Plan<typename Tag::comp>& p, const typename Tag::st
             }
 #undef RNNT_TILE
             p.check();
-            if (via_natural) {
-                const dim3 sgrid((p.maxU + kSkewU - 1) / kSkewU, (p.maxT + kSkewT - 1) / kSkewT, p.N);
-                hipLaunchKernelGGL((skew_kernel<C>), sgrid, dim3(256), 0, p.stream, p.rowtab, p.lp2, p.logz, p.maxT,
-                                   p.maxU, p.Up);
-                p.check();
-            }
             return;
         }
     }

@@ -326,12 +326,7 @@ __global__ __launch_bounds__(256) void row_stats_tile_kernel(
         const typename Tag::store* __restrict__ acts, const int* __restrict__ labels,
         const int* __restrict__ xlen, const int* __restrict__ ylen,
         LogPair<typename Tag::comp>* __restrict__ lp2, typename Tag::comp* __restrict__ logz,
-        Cell<typename Tag::comp>* __restrict__ natural, unsigned long long R, int maxT, int maxU, int Up,
-        int A, int blank) {
-    // `natural` != nullptr: write ONE coalesced 16-byte record {lp_blank, lp_label, logZ, -} per row in
-    // natural row order (skew_kernel then builds the diagonal-skewed arrays with coalesced accesses on
-    // both sides); nullptr: store straight into the skewed arrays (two scattered stores per row --
-    // fine for small lattices, measured to dominate this kernel at 29 M rows).
+        unsigned long long R, int maxT, int maxU, int Up, int A, int blank, int xcd_remap) {
     using S = typename Tag::store;
     using C = typename Tag::comp;
     constexpr int V = Vec<Tag>::N;
@@ -339,7 +334,16 @@ __global__ __launch_bounds__(256) void row_stats_tile_kernel(
     extern __shared__ uint4 tile_raw[];
     S* tile = reinterpret_cast<S*>(tile_raw);
 
-    const unsigned long long r0 = static_cast<unsigned long long>(blockIdx.x) * RT;
+    // XCD-aware tile order (workgroup i runs on XCD i % 8, each XCD has its own L2): every XCD walks
+    // ONE contiguous range of tiles.  Neighbouring cells of a skewed row come from tensor rows maxU-1
+    // apart, i.e. from tiles a few positions apart that run at the same time; in launch order they sit
+    // on different XCDs and each L2 writes its partial line back, with this order they meet in one L2
+    // and leave as full lines (the scattered result stores are what bounds this kernel on c4).
+    const unsigned ntile = static_cast<unsigned>((R + RT - 1) / RT);
+    const unsigned per = (ntile + 7u) >> 3;
+    const unsigned tile_id = xcd_remap ? (blockIdx.x & 7u) * per + (blockIdx.x >> 3) : blockIdx.x;
+    if (tile_id >= ntile) return;                          // grid is rounded up to a multiple of 8
+    const unsigned long long r0 = static_cast<unsigned long long>(tile_id) * RT;
     const int nrows = static_cast<int>(R - r0 < static_cast<unsigned long long>(RT) ? R - r0 : RT);
     const S* base = acts + r0 * static_cast<unsigned>(A);
     const int n_el = nrows * A;
@@ -442,61 +446,12 @@ __global__ __launch_bounds__(256) void row_stats_tile_kernel(
         rec.y = has_lab ? vmax((load1<Tag>(rowp + lab) - logZ) * C(kLog2e), log_zero<C>()) : log_zero<C>();
         if ((RNNT_TILE_ABLATE & 4) && rec.x != C(12345)) {
             // development only: results computed, not stored
-        } else if (natural) {
-            Cell<C> nrec;
-            nrec.x = rec.x; nrec.y = rec.y; nrec.z = logZ; nrec.w = 0;
-            natural[r0 + rl] = nrec;
         } else {
+            // two scattered stores per row: they combine into full lines in the XCD's L2 (tile order above)
             const size_t idx = lat_index(b, t + u, u, maxT, maxU, Up);
             lp2[idx] = rec;
             logz[idx] = logZ;
         }
-    }
-}
-
-// ------------------------------------------------------------------------------------------
-// Natural -> skewed transposition of the row-stats records for large lattices.  A block owns a
-// 32 (time) x 64 (label) tile of one sample: it reads the tile's natural rows (64 consecutive
-// 16-byte records each: coalesced), parks them in LDS and writes them out along the tile's
-// anti-diagonals -- on a diagonal consecutive u are consecutive addresses of the skewed arrays, so
-// the writes are contiguous runs of up to 32 cells.  LDS row stride 64 words per field keeps the
-// diagonal reads (stride 63) conflict-free.  Cells outside the sample's T_b x U_b lattice are
-// copied as they are (the lattice kernel never lets them matter).
-// grid = (ceil(maxU/64), ceil(maxT/32), N), block = 256.
-constexpr int kSkewT = 32, kSkewU = 64;
-
-template <typename L>
-__global__ __launch_bounds__(256) void skew_kernel(const Cell<L>* __restrict__ natural,
-                                                   LogPair<L>* __restrict__ lp2, L* __restrict__ logz,
-                                                   int maxT, int maxU, int Up) {
-    __shared__ L tx[kSkewT][kSkewU], ty[kSkewT][kSkewU], tz[kSkewT][kSkewU];
-    const int b = blockIdx.z;
-    const int t0 = blockIdx.y * kSkewT, u0 = blockIdx.x * kSkewU;
-    const Cell<L>* nat = natural + static_cast<size_t>(b) * maxT * maxU;
-    // load: thread -> (row i, column j), consecutive threads consecutive columns
-    for (int e = threadIdx.x; e < kSkewT * kSkewU; e += 256) {
-        const int i = e / kSkewU, j = e - i * kSkewU;
-        const int t = t0 + i, u = u0 + j;
-        Cell<L> r;
-        r.x = 0; r.y = 0; r.z = 0; r.w = 0;
-        if (t < maxT && u < maxU) r = nat[static_cast<size_t>(t) * maxU + u];
-        tx[i][j] = r.x; ty[i][j] = r.y; tz[i][j] = r.z;
-    }
-    __syncthreads();
-    // store: diagonal d = i + j of the tile (0 .. 94); positions along it indexed by the row i
-    // (so consecutive threads walk DOWN in i = UP in u... use j ascending for ascending addresses)
-    for (int e = threadIdx.x; e < (kSkewT + kSkewU - 1) * kSkewT; e += 256) {
-        const int d = e / kSkewT, k = e - d * kSkewT;        // k-th cell of diagonal d
-        const int jlo = d - (kSkewT - 1) > 0 ? d - (kSkewT - 1) : 0;
-        const int j = jlo + k, i = d - j;
-        if (j >= kSkewU || i < 0) continue;
-        const int t = t0 + i, u = u0 + j;
-        if (t >= maxT || u >= maxU) continue;
-        const size_t idx = lat_index(b, t + u, u, maxT, maxU, Up);
-        LogPair<L> p;
-        p.x = tx[i][j]; p.y = ty[i][j];
-        lp2[idx] = p;
-        logz[idx] = tz[i][j];
     }
 }
 

@@ -382,7 +382,7 @@ static rnntStatus_t run_gpu_joint(const float* f, const float* g, float* df, flo
         int S = (all_tiles >= 4096 || nchunk < 16) ? 1 : ((all_tiles < 1024 && nchunk >= 32) ? 8 : 4);
         if (tune().jzs == 1 || tune().jzs == 4 || tune().jzs == 8) S = tune().jzs;
 #define RNNT_JZ(SS, VV)                                                                                          \
-    hipLaunchKernelGGL((joint_z_kernel<SS, VV>), dim3(SS == 1 ? (tiles + 3) / 4 : tiles, N),                      \
+    hipLaunchKernelGGL((joint_z_kernel<SS, VV>), dim3(SS == 1 ? ((tiles + 3) / 4 + 7) / 8 * 8 : tiles, N),                      \
                        dim3(SS == 1 ? 256 : SS * 64), 0, p.stream, f, g, p.rowmax, labels, input_lengths,        \
                        label_lengths, p.lp2, p.logz, maxT, maxU, p.Up, A, p.blank, tilesU, tiles, N)
         if (S == 8) { if (vec) RNNT_JZ(8, true); else RNNT_JZ(8, false); }

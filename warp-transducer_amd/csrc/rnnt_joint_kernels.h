@@ -167,7 +167,12 @@ __global__ __launch_bounds__(S == 1 ? 256 : S * 64) void joint_z_kernel(
     float* stage = reinterpret_cast<float*>(stage4);
     const int b = blockIdx.y;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5, col = lane & 31;
-    const int tile = S == 1 ? static_cast<int>(blockIdx.x) * 4 + wave : static_cast<int>(blockIdx.x);
+    // S == 1 (many tiles): XCD-aware order -- workgroup i runs on XCD i % 8, so every XCD is given one
+    // contiguous range of tile groups and the partial lines of the skewed arrays that neighbouring tiles
+    // write meet in one L2 (gridDim.x is a multiple of 8 then; see row_stats_tile_kernel)
+    const int group = S == 1 ? static_cast<int>((blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3))
+                             : static_cast<int>(blockIdx.x);
+    const int tile = S == 1 ? group * 4 + wave : group;
     if (tile >= tiles) return;                             // S == 1 only: a whole wavefront leaves
     const int Tb = xlen[b], Ub = ylen[b] + 1;
     const int t0 = (tile / tilesU) * 32, u0 = (tile % tilesU) * 32;

@@ -163,6 +163,66 @@ def test_single_call_entry_equals_two_phase():
     assert st == 2
 
 
+def test_graph_capture_and_replay(oracle):
+    """compute_rnnt_loss_add only enqueues (no allocation, no host sync): capture it in a hipGraph and
+    replay it on changed inputs."""
+    from warprnnt_pytorch import _lib
+    f, g, labels, tl, ll, blank = problem((3, 25, 8, 96), 21)
+    dev = torch.device("cuda:0")
+    N, T, A = f.shape
+    U = g.shape[1]
+    tf, tg = torch.tensor(f, device=dev), torch.tensor(g, device=dev)
+    tlab, ttl, tll = (torch.tensor(a, device=dev) for a in (labels, tl, ll))
+    df, dg, costs = torch.empty_like(tf), torch.empty_like(tg), torch.empty(N, device=dev)
+    ws = torch.empty(_lib.workspace_bytes(T, U, N, True, 4), dtype=torch.uint8, device=dev)
+    lib = _lib.lib()
+
+    def call():
+        opt = _lib.rnntOptions(loc=1, num_threads=0, stream=torch.cuda.current_stream().cuda_stream,
+                               blank_label=blank, maxT=T, maxU=U, batch_first=True)
+        assert lib.compute_rnnt_loss_add(tf.data_ptr(), tg.data_ptr(), df.data_ptr(), dg.data_ptr(), tlab.data_ptr(),
+                                         tll.data_ptr(), ttl.data_ptr(), A, N, costs.data_ptr(), ws.data_ptr(), opt) == 0
+
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):                       # warm-up outside capture
+        call()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        call()
+    for scale in (1.0, 0.5):
+        tf.copy_(torch.tensor(f * scale)); tg.copy_(torch.tensor(g * scale))
+        costs.zero_(); df.zero_(); dg.zero_()
+        graph.replay()
+        torch.cuda.synchronize()
+        z = (f * scale)[:, :, None, :].astype(np.float64) + (g * scale)[:, None, :, :].astype(np.float64)
+        ref_c, ref_gz = oracle.rnnt_logits(z, labels, tl, ll, blank)
+        assert np.abs(costs.cpu().numpy() - ref_c).max() <= 1e-4 * np.abs(ref_c).max()
+        assert np.allclose(df.cpu().numpy(), ref_gz.sum(axis=2), rtol=1e-4, atol=2e-4)
+        assert np.allclose(dg.cpu().numpy(), ref_gz.sum(axis=1), rtol=1e-4, atol=5e-4)
+
+
+def test_masked_vocabulary_entries(oracle):
+    """-inf in trans_acts / pred_acts columns that are neither the blank nor a label: probability zero,
+    gradient exactly zero there, no NaN anywhere."""
+    f, g, labels, tl, ll, blank = problem((2, 19, 6, 64), 8)
+    labels = (labels % 20).astype(np.int32)
+    blank = 25
+    f[..., 40:50] = -np.inf
+    g[:, :, 52:60] = -np.inf
+    z = f[:, :, None, :].astype(np.float64) + g[:, None, :, :].astype(np.float64)
+    ref_c, ref_gz = oracle.rnnt_logits(z, labels, tl, ll, blank)
+    costs, df, dg = run_add(f, g, labels, tl, ll, blank)
+    assert np.isfinite(costs).all() and np.abs(costs - ref_c).max() <= 1e-4 * np.abs(ref_c).max()
+    assert not np.isnan(df).any() and not np.isnan(dg).any()
+    for sl in (slice(40, 50), slice(52, 60)):
+        assert not df[..., sl].any() and not dg[..., sl].any()
+    assert np.allclose(df, ref_gz.sum(axis=2), rtol=1e-4, atol=2e-4)
+    assert np.allclose(dg, ref_gz.sum(axis=1), rtol=1e-4, atol=5e-4)
+
+
 def test_validation_errors():
     from warprnnt_pytorch.add_network import rnnt_loss_add
     dev = torch.device("cuda:0")

@@ -858,7 +858,7 @@ __global__ __launch_bounds__(256) void grad_flat_kernel(
     for (; c < nchunks; c += gridDim.x) {
         const unsigned long long pk0 = c * kChunkPackets;
         uint4 raw[PPT];
-        Cell<C> rec[PPT];
+        Cell<C> rec[PPT], rec2[PPT];                        // rec2: the NEXT row's record, for packets that straddle
         int v0[PPT];
         unsigned long long row[PPT];
         bool live[PPT];
@@ -875,6 +875,10 @@ __global__ __launch_bounds__(256) void grad_flat_kernel(
             if (live[k]) {
                 rec[k] = rowtab[row[k]];
                 if constexpr (!PADSKIP) raw[k] = load_packet<true>(in + pk0 + p);
+                // a packet that crosses into the next row (A % V != 0) needs that row's record too: asked
+                // for here, with the other loads -- fetched inside the compute phase it was a dependent
+                // global latency that nearly every wavefront paid on c4 (A = 50: 5.9 -> 6.4 TB/s)
+                if (rr + V > A) rec2[k] = rowtab[row[k] + 1 < R ? row[k] + 1 : R - 1];
             }
         }
         if constexpr (PADSKIP) {
@@ -923,20 +927,32 @@ __global__ __launch_bounds__(256) void grad_flat_kernel(
                 }
             } else {
                 // packet crosses a row boundary (A not a multiple of the packet, or A < packet)
-                unsigned long long rw = row[k];
-                int pos = v0[k];
-                Cell<C> cur = rec[k];
-                C gs = scale_of(rw);
+                if (A >= V) {
+                    // two rows at most: elements j < split belong to row[k], the rest to the next row
+                    const int split = A - v0[k];
+                    const unsigned long long rw2 = row[k] + 1 < R ? row[k] + 1 : R - 1;
+                    const C gs1 = scale_of(row[k]), gs2 = scale_of(rw2);
 #pragma unroll
-                for (int j = 0; j < V; ++j) {
-                    while (pos >= A) {
-                        pos -= A;
-                        ++rw;
-                        if (rw < R) cur = rowtab[rw];
-                        gs = scale_of(rw < R ? rw : R - 1);
+                    for (int j = 0; j < V; ++j) {
+                        const bool first = j < split;
+                        v[j] = elem(first ? rec[k] : rec2[k], first ? v0[k] + j : j - split, v[j], first ? gs1 : gs2);
                     }
-                    v[j] = elem(cur, pos, v[j], gs);
-                    ++pos;
+                } else {
+                    unsigned long long rw = row[k];
+                    int pos = v0[k];
+                    Cell<C> cur = rec[k];
+                    C gs = scale_of(rw);
+#pragma unroll
+                    for (int j = 0; j < V; ++j) {
+                        while (pos >= A) {
+                            pos -= A;
+                            ++rw;
+                            if (rw < R) cur = rowtab[rw];
+                            gs = scale_of(rw < R ? rw : R - 1);
+                        }
+                        v[j] = elem(cur, pos, v[j], gs);
+                        ++pos;
+                    }
                 }
             }
             store_packet<true>(out + pk0 + p, pack<Tag>(v));

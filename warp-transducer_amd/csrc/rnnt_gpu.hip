@@ -94,9 +94,9 @@ static void prof_accumulate() {
 // ppt = packets per thread of the flat gradient kernel.  Additive joint: jfnk / jgnk = columns
 // per lane of the DF / DG kernels (0: widest the alignment allows), jfpf / jgpf = operand ping-pong;
 // blk = block-per-row statistics kernel for rows >= 12 KB on/off, jzs = vocabulary split of the Z kernel (1|4|8),
-// xcd = XCD-aware tile order of the short-row statistics kernel on/off.
+// xcd = XCD-aware tile order of the short-row statistics kernel on/off, ctile = tiled coefficient kernel on/off.
 struct Tune { int sw = 4, nta = 1, gmax = 4194304, rows = 0, tile = 1, tilekb = 52, ppt = 2;
-              int jfnk = 0, jfpf = 1, jgnk = 0, jgpf = 1, blk = 1, jzs = 0, xcd = 1; };
+              int jfnk = 0, jfpf = 1, jgnk = 0, jgpf = 1, blk = 1, jzs = 0, xcd = 1, ctile = 1; };
 static Tune g_tune;
 static bool g_tune_read = false;
 static const Tune& tune() {
@@ -111,7 +111,7 @@ static const Tune& tune() {
             get("gmax", g_tune.gmax); get("rows", g_tune.rows); get("tile", g_tune.tile);
             get("tilekb", g_tune.tilekb); get("ppt", g_tune.ppt);
             get("jfnk", g_tune.jfnk); get("jfpf", g_tune.jfpf); get("jgnk", g_tune.jgnk); get("jgpf", g_tune.jgpf);
-            get("blk", g_tune.blk); get("jzs", g_tune.jzs); get("xcd", g_tune.xcd);
+            get("blk", g_tune.blk); get("jzs", g_tune.jzs); get("xcd", g_tune.xcd); get("ctile", g_tune.ctile);
         }
     }
     return g_tune;
@@ -237,11 +237,23 @@ template <typename C> static void launch_lattice(Plan<C>& p, bool with_beta) {
 
 // Stage 3: gradient coefficients per row into the natural-order row table.
 template <typename C> static void launch_coef(Plan<C>& p, bool joint = false) {
-    const long long skew_cells = static_cast<long long>(p.maxT + p.maxU - 1) * p.Up;
-    const dim3 cgrid(static_cast<unsigned>(((skew_cells + 255) / 256 + 7) / 8 * 8), p.N);   // multiple of 8: XCD-aware remap
-    hipLaunchKernelGGL((coef_kernel<C>), cgrid, dim3(256), 0, p.stream, p.lp2, p.logz, p.alpha, p.beta, p.offa, p.offb,
-                       p.llf, p.labels, p.input_lengths, p.label_lengths, p.rowtab, p.maxT, p.maxU, p.Up,
-                       joint ? p.wmat : nullptr, (p.maxU + 3) / 4 * 4);
+    float* wmat = joint ? p.wmat : nullptr;
+    const int Upad = (p.maxU + 3) / 4 * 4;
+    if (p.maxU <= 48 || !tune().ctile) {
+        // small lattices: one thread per skewed cell, scattered record store
+        const long long skew_cells = static_cast<long long>(p.maxT + p.maxU - 1) * p.Up;
+        const dim3 cgrid(static_cast<unsigned>(((skew_cells + 255) / 256 + 7) / 8 * 8), p.N);   // multiple of 8: XCD-aware remap
+        hipLaunchKernelGGL((coef_cell_kernel<C>), cgrid, dim3(256), 0, p.stream, p.lp2, p.logz, p.alpha, p.beta, p.offa,
+                           p.offb, p.llf, p.labels, p.input_lengths, p.label_lengths, p.rowtab, p.maxT, p.maxU, p.Up,
+                           wmat, Upad);
+    } else {
+        const int DN = sizeof(C) == 4 ? 32 : 16;           // diagonals per tile (coef_kernel)
+        const int tilesU = (p.maxU + 63) / 64, tilesN = (p.maxT + p.maxU - 1 + DN - 1) / DN;
+        const dim3 cgrid(static_cast<unsigned>(tilesU * tilesN), p.N);
+        hipLaunchKernelGGL((coef_kernel<C>), cgrid, dim3(256), 0, p.stream, p.lp2, p.logz, p.alpha, p.beta, p.offa,
+                           p.offb, p.llf, p.labels, p.input_lengths, p.label_lengths, p.rowtab, p.maxT, p.maxU, p.Up,
+                           wmat, Upad, tilesU);
+    }
     p.check();
 }
 

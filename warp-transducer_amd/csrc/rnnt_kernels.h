@@ -746,34 +746,15 @@ __global__ __launch_bounds__(MAXW * 64) void lattice_kernel(
 // formed in fp64 from the scaled fp32 lattice values and their fp64 offsets.
 constexpr int kPadded = -2;
 
+// The record of one lattice cell (b, t, u) on diagonal n = t + u (the caller guarantees that the cell is a
+// row of the tensor).  Padded cells: c = "log zero" (exp(x + c) = 0 for any x), no corrections, flagged.
 template <typename L>
-__global__ __launch_bounds__(256) void coef_kernel(
+__device__ __forceinline__ Cell<L> coef_cell(
         const LogPair<L>* __restrict__ lp2, const L* __restrict__ logz, const L* __restrict__ alpha_arr,
-        const L* __restrict__ beta, const double* __restrict__ offa,
-        const double* __restrict__ offb, const double* __restrict__ ll_fwd,
-        const int* __restrict__ labels, const int* __restrict__ xlen, const int* __restrict__ ylen,
-        Cell<L>* __restrict__ rowtab, int maxT, int maxU, int Up, float* __restrict__ wmat, int Upad) {
-    // Threads run over the SKEWED index space (diagonal n, column u): a wavefront covers 64
-    // consecutive columns of one diagonal, so every read of the lattice arrays is one coalesced
-    // row segment and the per-diagonal offsets are wave-uniform; the only scattered access is the
-    // single 16-byte store of the record into the natural-order row table.
-    // XCD-aware block order (workgroup i runs on XCD i % 8, each XCD has its own L2): blocks are
-    // remapped so that every XCD owns one contiguous range of diagonals and the partial lines of
-    // the row table are combined in ONE L2.  gridDim.x is a multiple of 8.  Speed only.
-    const int b = blockIdx.y;
-    const unsigned per = gridDim.x >> 3;
-    const unsigned blk = (blockIdx.x & 7u) * per + (blockIdx.x >> 3);
-    const int D = maxT + maxU - 1;
-    const long long i0 = (static_cast<long long>(blk) * 4 + (threadIdx.x >> 6)) * 64;   // this wavefront's first cell
-    if (i0 >= static_cast<long long>(D) * Up) return;
-    const int n = uniform(static_cast<int>(i0 / Up));
-    const int u = static_cast<int>(i0 - static_cast<long long>(n) * Up) + (threadIdx.x & 63);
-    const int t = n - u;
-    if (wmat != nullptr && u >= maxU && u < Upad && t >= 0 && t < maxT)   // additive joint: W's pad columns are zero
-        wmat[(static_cast<size_t>(b) * maxT + t) * Upad + u] = 0.0f;
-    if (u >= maxU || t < 0 || t >= maxT) return;              // not a row of the tensor
-    const int Tb = xlen[b], Ub = ylen[b] + 1;
-    Cell<L> o;      // padded row: c = "log zero" (exp(x + c) = 0 for any x), no corrections, flagged
+        const L* __restrict__ beta, const double* __restrict__ offa, const double* __restrict__ offb,
+        const double* __restrict__ ll_fwd, const int* __restrict__ labels, int b, int n, int t, int u, int Tb,
+        int Ub, int maxT, int maxU, int Up) {
+    Cell<L> o;
     o.x = log_zero<L>(); o.y = 0; o.z = 0; o.w = static_cast<L>(kPadded);
     if (t < Tb && u < Ub) {
         const size_t Dp = lat_rows(maxT, maxU);
@@ -804,10 +785,109 @@ __global__ __launch_bounds__(256) void coef_kernel(
         }
         o.w = static_cast<L>(lab);
     }
+    return o;
+}
+
+// Gradient coefficients, one thread per cell of the SKEWED index space (diagonal n, column u): a wavefront
+// covers 64 consecutive columns of one diagonal, so every read of the lattice arrays is one coalesced row
+// segment; the record goes out as one scattered 16-byte store into the natural-order row table.  Used for
+// small lattices (the tiled form below wastes most of its 64-column tiles when U is a few dozen).
+// XCD-aware block order (workgroup i runs on XCD i % 8, each XCD has its own L2): every XCD owns one
+// contiguous range of diagonals, so the partial lines of the row table combine in ONE L2.  gridDim.x is a
+// multiple of 8.  grid = (8 * ceil(D*Up/2048), N), block = 256.
+template <typename L>
+__global__ __launch_bounds__(256) void coef_cell_kernel(
+        const LogPair<L>* __restrict__ lp2, const L* __restrict__ logz, const L* __restrict__ alpha_arr,
+        const L* __restrict__ beta, const double* __restrict__ offa,
+        const double* __restrict__ offb, const double* __restrict__ ll_fwd,
+        const int* __restrict__ labels, const int* __restrict__ xlen, const int* __restrict__ ylen,
+        Cell<L>* __restrict__ rowtab, int maxT, int maxU, int Up, float* __restrict__ wmat, int Upad) {
+    const int b = blockIdx.y;
+    const unsigned per = gridDim.x >> 3;
+    const unsigned blk = (blockIdx.x & 7u) * per + (blockIdx.x >> 3);
+    const int D = maxT + maxU - 1;
+    const long long i0 = (static_cast<long long>(blk) * 4 + (threadIdx.x >> 6)) * 64;   // this wavefront's first cell
+    if (i0 >= static_cast<long long>(D) * Up) return;
+    const int n = uniform(static_cast<int>(i0 / Up));
+    const int u = static_cast<int>(i0 - static_cast<long long>(n) * Up) + (threadIdx.x & 63);
+    const int t = n - u;
+    if (wmat != nullptr && u >= maxU && u < Upad && t >= 0 && t < maxT)   // additive joint: W's pad columns are zero
+        wmat[(static_cast<size_t>(b) * maxT + t) * Upad + u] = 0.0f;
+    if (u >= maxU || t < 0 || t >= maxT) return;              // not a row of the tensor
+    const Cell<L> o = coef_cell<L>(lp2, logz, alpha_arr, beta, offa, offb, ll_fwd, labels, b, n, t, u, xlen[b],
+                                   ylen[b] + 1, maxT, maxU, Up);
     rowtab[(static_cast<size_t>(b) * maxT + t) * maxU + u] = o;
     if (wmat != nullptr) {                                    // additive joint only: W = exp(c), row stride Upad
         const float c = static_cast<float>(o.x);
         wmat[(static_cast<size_t>(b) * maxT + t) * Upad + u] = c > kJointFarC ? 0.0f : fast_exp(c);
+    }
+}
+
+// Gradient coefficients over 2-D tiles of the skewed index space: DN diagonals x 64 columns per block.
+//   compute: wavefront w takes the diagonals w, w+4, ... of the tile, lane = column -- every read of the
+//            lattice arrays is a coalesced 256-byte row segment and the per-diagonal offsets are
+//            wave-uniform, exactly as in the cell-per-thread form;
+//   store:   the records meet in LDS and leave along NATURAL rows: for a time row t the tile holds the
+//            columns u with n0 <= t + u < n0 + DN, a run of up to DN consecutive 16-byte records, written by
+//            DN consecutive lanes (512-byte runs for fp32) -- instead of one scattered 16-byte store per
+//            cell, which cost 0.225 of this kernel's 0.42 ms on c4 even with the partial lines meeting in
+//            one L2.  The dense weight matrix of the additive-joint path leaves the same way.
+// grid = (ceil(D/DN) * ceil(maxU/64), N), block = 256.
+template <typename L>
+__global__ __launch_bounds__(256) void coef_kernel(
+        const LogPair<L>* __restrict__ lp2, const L* __restrict__ logz, const L* __restrict__ alpha_arr,
+        const L* __restrict__ beta, const double* __restrict__ offa,
+        const double* __restrict__ offb, const double* __restrict__ ll_fwd,
+        const int* __restrict__ labels, const int* __restrict__ xlen, const int* __restrict__ ylen,
+        Cell<L>* __restrict__ rowtab, int maxT, int maxU, int Up, float* __restrict__ wmat, int Upad, int tilesU) {
+    constexpr int DN = sizeof(L) == 4 ? 32 : 16;           // diagonals per tile (LDS: DN * 64 records)
+    __shared__ Cell<L> recs[DN][64];
+    const int b = blockIdx.y;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int tu = static_cast<int>(blockIdx.x) % tilesU, tn = static_cast<int>(blockIdx.x) / tilesU;
+    const int n0 = tn * DN, u0 = tu * 64;
+    const int D = maxT + maxU - 1;
+    const int Tb = xlen[b], Ub = ylen[b] + 1;
+
+    // ---- compute, skewed order
+    {
+        const int u = u0 + lane;
+#pragma unroll 2
+        for (int dn = wave; dn < DN; dn += 4) {
+            const int n = n0 + dn, t = n - u;
+            Cell<L> o;
+            o.x = log_zero<L>(); o.y = 0; o.z = 0; o.w = static_cast<L>(kPadded);
+            if (n < D && u < maxU && t >= 0 && t < maxT)
+                o = coef_cell<L>(lp2, logz, alpha_arr, beta, offa, offb, ll_fwd, labels, b, n, t, u, Tb, Ub, maxT, maxU, Up);
+            recs[dn][lane] = o;
+        }
+    }
+    __syncthreads();
+    // ---- store, natural order: groups of DN lanes take one time row each
+    constexpr int GROUPS = 256 / DN;
+    const int grp = threadIdx.x / DN, c = threadIdx.x % DN;
+    const int t_lo = n0 - (u0 + 63);                       // first time row that meets the tile
+    for (int r = grp; r < DN + 63; r += GROUPS) {
+        const int t = t_lo + r;
+        if (t < 0 || t >= maxT) continue;
+        const int ulo = n0 - t > u0 ? n0 - t : u0;         // columns of row t inside the tile
+        const int u = ulo + c;
+        if (u > u0 + 63 || u >= maxU || t + u >= n0 + DN || t + u >= D) continue;
+        const Cell<L> o = recs[t + u - n0][u - u0];
+        rowtab[(static_cast<size_t>(b) * maxT + t) * maxU + u] = o;
+        if (wmat != nullptr) {                             // additive joint only: W = exp(c), row stride Upad
+            const float cc = static_cast<float>(o.x);
+            wmat[(static_cast<size_t>(b) * maxT + t) * Upad + u] = cc > kJointFarC ? 0.0f : fast_exp(cc);
+        }
+    }
+    // additive joint: W's pad columns [maxU, Upad) are zero (tiles of the last column group only)
+    if (wmat != nullptr && u0 + 64 >= maxU) {
+        for (int r = grp; r < DN + 63; r += GROUPS) {
+            const int t = t_lo + r;
+            if (t < 0 || t >= maxT || c >= Upad - maxU) continue;
+            // each (t, pad column) is written by the tiles of every diagonal range that meets row t: same value
+            wmat[(static_cast<size_t>(b) * maxT + t) * Upad + maxU + c] = 0.0f;
+        }
     }
 }
 

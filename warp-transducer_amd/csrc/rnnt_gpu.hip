@@ -94,9 +94,10 @@ static void prof_accumulate() {
 // ppt = packets per thread of the flat gradient kernel.  Additive joint: jfnk / jgnk = columns
 // per lane of the DF / DG kernels (0: widest the alignment allows), jfpf / jgpf = operand ping-pong;
 // blk = block-per-row statistics kernel for rows >= 12 KB on/off, jzs = vocabulary split of the Z kernel (1|4|8),
-// xcd = XCD-aware tile order of the short-row statistics kernel on/off, ctile = tiled coefficient kernel on/off.
+// xcd = XCD-aware tile order of the short-row statistics kernel on/off, ctile = tiled coefficient kernel on/off,
+// pskip = the gradient kernel's skip-padded-rows form for rows >= 8 KB on/off.
 struct Tune { int sw = 4, nta = 1, gmax = 4194304, rows = 0, tile = 1, tilekb = 52, ppt = 2;
-              int jfnk = 0, jfpf = 1, jgnk = 0, jgpf = 1, blk = 1, jzs = 0, xcd = 1, ctile = 1; };
+              int jfnk = 0, jfpf = 1, jgnk = 0, jgpf = 1, blk = 1, jzs = 0, xcd = 1, ctile = 1, pskip = 1; };
 static Tune g_tune;
 static bool g_tune_read = false;
 static const Tune& tune() {
@@ -111,7 +112,7 @@ static const Tune& tune() {
             get("gmax", g_tune.gmax); get("rows", g_tune.rows); get("tile", g_tune.tile);
             get("tilekb", g_tune.tilekb); get("ppt", g_tune.ppt);
             get("jfnk", g_tune.jfnk); get("jfpf", g_tune.jfpf); get("jgnk", g_tune.jgnk); get("jgpf", g_tune.jgpf);
-            get("blk", g_tune.blk); get("jzs", g_tune.jzs); get("xcd", g_tune.xcd); get("ctile", g_tune.ctile);
+            get("blk", g_tune.blk); get("jzs", g_tune.jzs); get("xcd", g_tune.xcd); get("ctile", g_tune.ctile); get("pskip", g_tune.pskip);
         }
     }
     return g_tune;
@@ -283,7 +284,7 @@ static void launch_grad(Plan<typename Tag::comp>& p, const typename Tag::store* 
 #define RNNT_FLAT(SC, PP, PS)                                                                                       \
     hipLaunchKernelGGL((grad_flat_kernel<Tag, SC, PP, PS>), dim3(grid), dim3(256), 0, p.stream, acts, grads, p.rowtab, \
                        grad_scale, E, R, p.A, p.blank, p.cells_per_sample, invA, dq, drem)
-        const bool padskip = row_bytes >= 8192;     // skip reading padded rows only where rows are long
+        const bool padskip = tn.pskip && row_bytes >= 8192;     // skip reading padded rows only where rows are long
         if (grad_scale) { if (padskip) RNNT_FLAT(true, 2, true); else RNNT_FLAT(true, 2, false); }
         else if (ppt == 1) RNNT_FLAT(false, 1, false);
         else if (ppt == 4) RNNT_FLAT(false, 4, false);

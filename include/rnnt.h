@@ -206,6 +206,39 @@ rnntStatus_t compute_rnnt_loss_bwd(const void* activations,
                                    rnntOptions options,
                                    int dtype_code);
 
+/* FastEmit regularisation (Yu et al., "FastEmit", ICASSP 2021, in the form NVIDIA
+ * NeMo's RNN-T loss uses): the gradient of every LABEL transition's log-probability is scaled by
+ * (1 + fastemit_lambda), which pushes the model to emit earlier; the returned costs are the plain
+ * negative log-likelihoods.  fastemit_lambda = 0 is exactly compute_rnnt_loss_async /
+ * compute_rnnt_loss_fwd; negative or NaN -> INVALID_VALUE.  compute_rnnt_loss_fwd_fastemit pairs with
+ * the unchanged compute_rnnt_loss_bwd (the factor lives in the coefficient table).  GPU only. */
+rnntStatus_t compute_rnnt_loss_fastemit(const void* activations,
+                                        void* gradients,
+                                        const int* const flat_labels,
+                                        const int* const label_lengths,
+                                        const int* const input_lengths,
+                                        int alphabet_size,
+                                        int minibatch,
+                                        void* costs_device,
+                                        const void* grad_scale_device,
+                                        void* workspace,
+                                        rnntOptions options,
+                                        int dtype_code,
+                                        float fastemit_lambda);
+
+rnntStatus_t compute_rnnt_loss_fwd_fastemit(const void* activations,
+                                            const int* const flat_labels,
+                                            const int* const label_lengths,
+                                            const int* const input_lengths,
+                                            int alphabet_size,
+                                            int minibatch,
+                                            void* costs_device,
+                                            void* workspace,
+                                            rnntOptions options,
+                                            int dtype_code,
+                                            int prepare_backward,
+                                            float fastemit_lambda);
+
 /* Additive joint ("add network", the reference's add_network branch: README.md:4,
  * docs/rnnt_notes.tex:56-59,147-153, pytorch_binding/test/test_time.py:51-77).  The joint logits
  * are h(k,t,u) = trans_acts[b,t,k] + pred_acts[b,u,k]; the (B,T,U,V) tensor is never formed.

@@ -402,6 +402,73 @@ def test_async_entry_is_graph_capturable(oracle):
         assert np.abs(grads.cpu().numpy() - ref_g).max() < 1e-4
 
 
+def _fastemit_expectation(oracle, acts, labels, tl, ll, blank, lam):
+    """FastEmit through the oracle: the sparse log-prob gradient's LABEL entries times (1 + lambda), then
+    the chain rule through log_softmax (include/rnnt.h, compute_rnnt_loss_fastemit)."""
+    lp = oracle.log_softmax(acts.astype(np.float64))
+    costs, g_lp = oracle.rnnt_logprobs(lp, labels, tl, ll, blank)
+    for b in range(acts.shape[0]):
+        for u in range(ll[b]):
+            g_lp[b, :tl[b], u, labels[b, u]] *= 1.0 + lam
+    return costs, oracle.chain_rule_to_logits(lp, g_lp)
+
+
+@pytest.mark.parametrize("shape,lam", [((3, 12, 6, 20), 0.01), ((2, 40, 70, 33), 0.5), ((2, 9, 5, 5000), 0.05)])
+def test_fastemit_entry(oracle, shape, lam):
+    from warprnnt_pytorch import warp_rnnt
+    N, T, U, A = shape
+    rng = np.random.default_rng(A + T)
+    acts = rng.standard_normal(shape).astype(np.float32)
+    blank = A - 1
+    labels = rng.integers(0, A - 1, size=(N, U - 1)).astype(np.int32)
+    tl = np.array([T] + list(rng.integers(max(1, T // 2), T + 1, size=N - 1)), dtype=np.int32)
+    ll = np.array(list(rng.integers(U // 2, U, size=N - 1)) + [U - 1], dtype=np.int32)
+    ref_c, ref_g = _fastemit_expectation(oracle, acts, labels, tl, ll, blank, lam)
+    dev = torch.device("cuda:0")
+    x = torch.tensor(acts, device=dev)
+    args = [torch.tensor(a, device=dev) for a in (labels, tl, ll)]
+    costs = torch.empty(N, device=dev)
+    grads = torch.empty_like(x)
+    ws = warp_rnnt.gpu_rnnt_async(x, args[0], args[1], args[2], costs, grads, blank, fastemit_lambda=lam)
+    torch.cuda.synchronize()
+    assert np.abs(costs.cpu().numpy() - ref_c).max() <= 1e-4 * np.abs(ref_c).max()      # the plain likelihood
+    assert np.abs(grads.cpu().numpy() - ref_g).max() < 2e-4
+    # lambda = 0 through the same entry is the plain loss, bit for bit
+    g0, g1, c1 = torch.empty_like(x), torch.empty_like(x), torch.empty(N, device=dev)
+    warp_rnnt.gpu_rnnt_async(x, args[0], args[1], args[2], c1, g0, blank, workspace=ws)
+    lib = __import__("warprnnt_pytorch")._lib
+    opt = lib.rnntOptions(loc=1, num_threads=0, stream=torch.cuda.current_stream().cuda_stream, blank_label=blank,
+                          maxT=T, maxU=U, batch_first=True)
+    call = lambda lam_: lib.lib().compute_rnnt_loss_fastemit(
+        x.data_ptr(), g1.data_ptr(), args[0].data_ptr(), args[2].data_ptr(), args[1].data_ptr(), A, N, c1.data_ptr(),
+        None, ws.data_ptr(), opt, 0, lam_)
+    assert call(0.0) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(g0, g1)
+    assert call(-0.5) == 2 and call(float("nan")) == 2
+
+
+def test_fastemit_in_the_module(oracle):
+    from warprnnt_pytorch import RNNTLoss
+    shape, lam = (4, 15, 7, 50), 0.02
+    N, T, U, A = shape
+    rng = np.random.default_rng(5)
+    acts = rng.standard_normal(shape).astype(np.float32)
+    labels = rng.integers(1, A, size=(N, U - 1)).astype(np.int32)
+    tl = np.full(N, T, dtype=np.int32); tl[1] = T - 4
+    ll = np.full(N, U - 1, dtype=np.int32); ll[2] = 2
+    ref_c, ref_g = _fastemit_expectation(oracle, acts, labels, tl, ll, 0, lam)
+    dev = torch.device("cuda:0")
+    x = torch.tensor(acts, device=dev, requires_grad=True)
+    loss = RNNTLoss(blank=0, reduction="mean", fastemit_lambda=lam)(
+        x, *(torch.tensor(a, device=dev) for a in (labels, tl, ll)))
+    loss.backward()
+    assert abs(loss.item() - ref_c.mean()) <= 1e-4 * abs(ref_c.mean())
+    assert np.abs(x.grad.cpu().numpy() - ref_g / N).max() < 1e-4
+    with pytest.raises(NotImplementedError):            # CPU location: not offered
+        RNNTLoss(fastemit_lambda=lam)(torch.tensor(acts), *(torch.tensor(a) for a in (labels, tl, ll)))
+
+
 def test_minus_inf_logits(oracle):
     """Masked vocabulary entries (-inf logits) that are neither the blank nor a label: probability
     zero, gradient exactly zero there, everything else as the oracle says."""

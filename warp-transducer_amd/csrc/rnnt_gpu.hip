@@ -128,6 +128,7 @@ template <typename C> struct Plan {
     LogPair<C>* lp2; C *logz, *alpha, *beta; Cell<C>* rowtab;
     double *offa, *offb, *llf, *llb;
     float *rowmax, *wmat;
+    float fastemit = 0.0f;         // FastEmit lambda (extension entries only)
     C* costs_dev;
     bool failed = false;
     void check() { if (hipGetLastError() != hipSuccess) failed = true; }
@@ -246,14 +247,14 @@ template <typename C> static void launch_coef(Plan<C>& p, bool joint = false) {
         const dim3 cgrid(static_cast<unsigned>(((skew_cells + 255) / 256 + 7) / 8 * 8), p.N);   // multiple of 8: XCD-aware remap
         hipLaunchKernelGGL((coef_cell_kernel<C>), cgrid, dim3(256), 0, p.stream, p.lp2, p.logz, p.alpha, p.beta, p.offa,
                            p.offb, p.llf, p.labels, p.input_lengths, p.label_lengths, p.rowtab, p.maxT, p.maxU, p.Up,
-                           wmat, Upad);
+                           wmat, Upad, p.fastemit);
     } else {
         const int DN = sizeof(C) == 4 ? 32 : 16;           // diagonals per tile (coef_kernel)
         const int tilesU = (p.maxU + 63) / 64, tilesN = (p.maxT + p.maxU - 1 + DN - 1) / DN;
         const dim3 cgrid(static_cast<unsigned>(tilesU * tilesN), p.N);
         hipLaunchKernelGGL((coef_kernel<C>), cgrid, dim3(256), 0, p.stream, p.lp2, p.logz, p.alpha, p.beta, p.offa,
                            p.offb, p.llf, p.labels, p.input_lengths, p.label_lengths, p.rowtab, p.maxT, p.maxU, p.Up,
-                           wmat, Upad, tilesU);
+                           wmat, Upad, tilesU, p.fastemit);
     }
     p.check();
 }
@@ -312,12 +313,15 @@ static rnntStatus_t run_gpu(const typename Tag::store* acts, typename Tag::store
                             const int* labels, const int* label_lengths, const int* input_lengths,
                             int A, int N, typename Tag::comp* costs_host,
                             typename Tag::comp* costs_device_out, const typename Tag::comp* grad_scale,
-                            void* workspace, const rnntOptions& opt, int phases = 3, int want_grad = -1) {
+                            void* workspace, const rnntOptions& opt, int phases = 3, int want_grad = -1,
+                            float fastemit = 0.0f) {
     using S = typename Tag::store;
     using C = typename Tag::comp;
     Plan<C> p;
     if (!make_plan(p, A, N, opt, workspace, labels, label_lengths, input_lengths, costs_device_out))
         return RNNT_STATUS_INVALID_VALUE;
+    if (!(fastemit >= 0.0f)) return RNNT_STATUS_INVALID_VALUE;
+    p.fastemit = fastemit;
     const bool training = want_grad < 0 ? grads != nullptr : want_grad != 0;
     const bool do_fwd = (phases & 1) != 0, do_bwd = (phases & 2) != 0 && training;
     if (do_bwd && grads == nullptr) return RNNT_STATUS_INVALID_VALUE;
@@ -539,24 +543,25 @@ rnntStatus_t compute_rnnt_loss_fp16(const uint16_t* const activations, uint16_t*
 // Dispatch of the enqueue-only forms on the dtype code (0 fp32, 1 fp64, 2 bf16, 3 fp16).
 static rnntStatus_t run_async(const void* acts, void* grads, const int* labels, const int* label_lengths,
                               const int* input_lengths, int A, int N, void* costs_device, const void* scale,
-                              void* workspace, const rnntOptions& o, int dtype_code, int phases, int want_grad) {
+                              void* workspace, const rnntOptions& o, int dtype_code, int phases, int want_grad,
+                              float fastemit = 0.0f) {
     switch (dtype_code) {
         case 0:
             return run_gpu<F32>(static_cast<const float*>(acts), static_cast<float*>(grads), labels, label_lengths,
                                 input_lengths, A, N, nullptr, static_cast<float*>(costs_device),
-                                static_cast<const float*>(scale), workspace, o, phases, want_grad);
+                                static_cast<const float*>(scale), workspace, o, phases, want_grad, fastemit);
         case 1:
             return run_gpu<F64>(static_cast<const double*>(acts), static_cast<double*>(grads), labels, label_lengths,
                                 input_lengths, A, N, nullptr, static_cast<double*>(costs_device),
-                                static_cast<const double*>(scale), workspace, o, phases, want_grad);
+                                static_cast<const double*>(scale), workspace, o, phases, want_grad, fastemit);
         case 2:
             return run_gpu<BF16>(static_cast<const uint16_t*>(acts), static_cast<uint16_t*>(grads), labels,
                                  label_lengths, input_lengths, A, N, nullptr, static_cast<float*>(costs_device),
-                                 static_cast<const float*>(scale), workspace, o, phases, want_grad);
+                                 static_cast<const float*>(scale), workspace, o, phases, want_grad, fastemit);
         case 3:
             return run_gpu<F16>(static_cast<const uint16_t*>(acts), static_cast<uint16_t*>(grads), labels,
                                 label_lengths, input_lengths, A, N, nullptr, static_cast<float*>(costs_device),
-                                static_cast<const float*>(scale), workspace, o, phases, want_grad);
+                                static_cast<const float*>(scale), workspace, o, phases, want_grad, fastemit);
         default: return RNNT_STATUS_INVALID_VALUE;
     }
 }
@@ -592,6 +597,31 @@ rnntStatus_t compute_rnnt_loss_bwd(const void* activations, void* gradients, con
         return RNNT_STATUS_INVALID_VALUE;
     return run_async(activations, gradients, nullptr, nullptr, nullptr, alphabet_size, minibatch, nullptr,
                      grad_scale_device, workspace, options, dtype_code, 2, 1);
+}
+
+rnntStatus_t compute_rnnt_loss_fastemit(const void* activations, void* gradients, const int* const flat_labels,
+                                        const int* const label_lengths, const int* const input_lengths,
+                                        int alphabet_size, int minibatch, void* costs_device,
+                                        const void* grad_scale_device, void* workspace, rnntOptions options,
+                                        int dtype_code, float fastemit_lambda) {
+    if (bad_args(activations, flat_labels, label_lengths, input_lengths, costs_device, workspace,
+                 alphabet_size, minibatch, options) || options.loc != RNNT_GPU)
+        return RNNT_STATUS_INVALID_VALUE;
+    return run_async(activations, gradients, flat_labels, label_lengths, input_lengths, alphabet_size, minibatch,
+                     costs_device, grad_scale_device, workspace, options, dtype_code, 3, -1, fastemit_lambda);
+}
+
+rnntStatus_t compute_rnnt_loss_fwd_fastemit(const void* activations, const int* const flat_labels,
+                                            const int* const label_lengths, const int* const input_lengths,
+                                            int alphabet_size, int minibatch, void* costs_device, void* workspace,
+                                            rnntOptions options, int dtype_code, int prepare_backward,
+                                            float fastemit_lambda) {
+    if (bad_args(activations, flat_labels, label_lengths, input_lengths, costs_device, workspace,
+                 alphabet_size, minibatch, options) || options.loc != RNNT_GPU)
+        return RNNT_STATUS_INVALID_VALUE;
+    return run_async(activations, nullptr, flat_labels, label_lengths, input_lengths, alphabet_size, minibatch,
+                     costs_device, nullptr, workspace, options, dtype_code, 1, prepare_backward != 0 ? 1 : 0,
+                     fastemit_lambda);
 }
 
 rnntStatus_t compute_rnnt_loss_add(const float* const trans_acts, const float* const pred_acts,

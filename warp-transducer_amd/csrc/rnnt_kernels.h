@@ -753,7 +753,7 @@ __device__ __forceinline__ Cell<L> coef_cell(
         const LogPair<L>* __restrict__ lp2, const L* __restrict__ logz, const L* __restrict__ alpha_arr,
         const L* __restrict__ beta, const double* __restrict__ offa, const double* __restrict__ offb,
         const double* __restrict__ ll_fwd, const int* __restrict__ labels, int b, int n, int t, int u, int Tb,
-        int Ub, int maxT, int maxU, int Up) {
+        int Ub, int maxT, int maxU, int Up, float fastemit) {
     Cell<L> o;
     o.x = log_zero<L>(); o.y = 0; o.z = 0; o.w = static_cast<L>(kPadded);
     if (t < Tb && u < Ub) {
@@ -780,8 +780,19 @@ __device__ __forceinline__ Cell<L> coef_cell(
             o.y = fast_exp2(static_cast<L>(alpha + static_cast<double>(r.x)));
         int lab = -1;
         if (!last_u) {
-            o.z = fast_exp2(static_cast<L>(alpha + static_cast<double>(r.y) + static_cast<double>(bp[Up + 1]) + ob_r[n + 1]));
+            const double arg_l = alpha + static_cast<double>(r.y) + static_cast<double>(bp[Up + 1]) + ob_r[n + 1];
+            o.z = fast_exp2(static_cast<L>(arg_l));
             lab = labels[static_cast<size_t>(b) * (maxU - 1) + u];
+            if (fastemit != 0.0f) {
+                // FastEmit (Yu et al. 2021, the form NVIDIA NeMo's RNN-T loss uses): the label
+                // transition's log-prob gradient is scaled by (1 + lambda).  In the record form
+                //   g_v = p_v (gamma + lambda cl) - [v=blank] cb - [v=label] (1 + lambda) cl,   gamma = exp(alpha+beta-ll)
+                // so c grows by log(1 + lambda cl/gamma) (cl/gamma <= 1, formed from the two exponents) and cl
+                // by the factor (1 + lambda); the gradient kernel is unchanged.
+                const double ratio = exp2(arg_l - (alpha + static_cast<double>(bp[0]) + ob[n]));
+                o.x += static_cast<L>(log1p(static_cast<double>(fastemit) * (ratio < 1.0 ? ratio : 1.0)));
+                o.z *= static_cast<L>(1.0f + fastemit);
+            }
         }
         o.w = static_cast<L>(lab);
     }
@@ -801,7 +812,7 @@ __global__ __launch_bounds__(256) void coef_cell_kernel(
         const L* __restrict__ beta, const double* __restrict__ offa,
         const double* __restrict__ offb, const double* __restrict__ ll_fwd,
         const int* __restrict__ labels, const int* __restrict__ xlen, const int* __restrict__ ylen,
-        Cell<L>* __restrict__ rowtab, int maxT, int maxU, int Up, float* __restrict__ wmat, int Upad) {
+        Cell<L>* __restrict__ rowtab, int maxT, int maxU, int Up, float* __restrict__ wmat, int Upad, float fastemit) {
     const int b = blockIdx.y;
     const unsigned per = gridDim.x >> 3;
     const unsigned blk = (blockIdx.x & 7u) * per + (blockIdx.x >> 3);
@@ -815,7 +826,7 @@ __global__ __launch_bounds__(256) void coef_cell_kernel(
         wmat[(static_cast<size_t>(b) * maxT + t) * Upad + u] = 0.0f;
     if (u >= maxU || t < 0 || t >= maxT) return;              // not a row of the tensor
     const Cell<L> o = coef_cell<L>(lp2, logz, alpha_arr, beta, offa, offb, ll_fwd, labels, b, n, t, u, xlen[b],
-                                   ylen[b] + 1, maxT, maxU, Up);
+                                   ylen[b] + 1, maxT, maxU, Up, fastemit);
     rowtab[(static_cast<size_t>(b) * maxT + t) * maxU + u] = o;
     if (wmat != nullptr) {                                    // additive joint only: W = exp(c), row stride Upad
         const float c = static_cast<float>(o.x);
@@ -839,7 +850,8 @@ __global__ __launch_bounds__(256) void coef_kernel(
         const L* __restrict__ beta, const double* __restrict__ offa,
         const double* __restrict__ offb, const double* __restrict__ ll_fwd,
         const int* __restrict__ labels, const int* __restrict__ xlen, const int* __restrict__ ylen,
-        Cell<L>* __restrict__ rowtab, int maxT, int maxU, int Up, float* __restrict__ wmat, int Upad, int tilesU) {
+        Cell<L>* __restrict__ rowtab, int maxT, int maxU, int Up, float* __restrict__ wmat, int Upad, int tilesU,
+        float fastemit) {
     constexpr int DN = sizeof(L) == 4 ? 32 : 16;           // diagonals per tile (LDS: DN * 64 records)
     __shared__ Cell<L> recs[DN][64];
     const int b = blockIdx.y;
@@ -858,7 +870,7 @@ __global__ __launch_bounds__(256) void coef_kernel(
             Cell<L> o;
             o.x = log_zero<L>(); o.y = 0; o.z = 0; o.w = static_cast<L>(kPadded);
             if (n < D && u < maxU && t >= 0 && t < maxT)
-                o = coef_cell<L>(lp2, logz, alpha_arr, beta, offa, offb, ll_fwd, labels, b, n, t, u, Tb, Ub, maxT, maxU, Up);
+                o = coef_cell<L>(lp2, logz, alpha_arr, beta, offa, offb, ll_fwd, labels, b, n, t, u, Tb, Ub, maxT, maxU, Up, fastemit);
             recs[dn][lane] = o;
         }
     }

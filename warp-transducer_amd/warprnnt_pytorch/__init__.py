@@ -23,7 +23,7 @@ _ASYNC_GPU = _os.environ.get("WARPRNNT_SYNC_API", "0") != "1"
 
 class _RNNT(Function):
     @staticmethod
-    def forward(ctx, acts, labels, act_lens, label_lens, blank, reduction):
+    def forward(ctx, acts, labels, act_lens, label_lens, blank, reduction, fastemit_lambda=0.0):
         """
         acts:       (batch, T, U, vocab) joint-network output; raw logits on the GPU,
                     log-probabilities on the CPU (the wrappers below apply log_softmax there)
@@ -37,6 +37,8 @@ class _RNNT(Function):
         minibatch_size = acts.size(0)
         cost_dtype = acts.dtype if acts.dtype in (torch.float32, torch.float64) else torch.float32
         ctx.two_phase = bool(is_cuda and _ASYNC_GPU)
+        if fastemit_lambda and not ctx.two_phase:
+            raise NotImplementedError("fastemit_lambda is an extension of the GPU two-phase route")
         if ctx.two_phase:
             # Two-phase route (compute_rnnt_loss_fwd / _bwd).  The reference computes the full gradient
             # tensor here, keeps it in ctx, divides it by N for 'mean' and multiplies it by grad_output
@@ -45,7 +47,8 @@ class _RNNT(Function):
             # the workspace (lattice + coefficient table) behind; backward runs the gradient kernel
             # once with the 1/N and grad_output factors folded in.  Same values, costs stay on device.
             costs = torch.empty(minibatch_size, dtype=cost_dtype, device=acts.device)
-            ws = warp_rnnt.gpu_rnnt_fwd(acts, labels, act_lens, label_lens, costs, blank, acts.requires_grad)
+            ws = warp_rnnt.gpu_rnnt_fwd(acts, labels, act_lens, label_lens, costs, blank, acts.requires_grad,
+                                        fastemit_lambda)
             ws.record_stream(torch.cuda.current_stream(acts.device))
             ctx.save_for_backward(acts)
             ctx.workspace = ws if acts.requires_grad else None
@@ -81,12 +84,12 @@ class _RNNT(Function):
             scale = (grad_output.reshape(-1).to(device=acts.device, dtype=sdt) * ctx.mean_scale).expand(n).contiguous()
             grads = torch.empty_like(acts)
             warp_rnnt.gpu_rnnt_bwd(acts, grads, scale, ctx.workspace, ctx.blank)
-            return grads, None, None, None, None, None
+            return grads, None, None, None, None, None, None
         grad_output = grad_output.view(-1, 1, 1, 1).to(ctx.grads)
-        return ctx.grads.mul_(grad_output), None, None, None, None, None
+        return ctx.grads.mul_(grad_output), None, None, None, None, None, None
 
 
-def rnnt_loss(acts, labels, act_lens, label_lens, blank=0, reduction='mean'):
+def rnnt_loss(acts, labels, act_lens, label_lens, blank=0, reduction='mean', fastemit_lambda=0.0):
     """RNN Transducer loss.
 
     Args:
@@ -98,10 +101,13 @@ def rnnt_loss(acts, labels, act_lens, label_lens, blank=0, reduction='mean'):
         reduction (string, optional): 'none' | 'mean' | 'sum'. 'none': per-sample losses;
             'sum': summed over the batch (shape (1,)); 'mean': the sum divided by the batch
             size. Default: 'mean'
+        fastemit_lambda (float, optional): extension, GPU only -- FastEmit regularisation (Yu et al.
+            2021): the gradient of every label transition is scaled by (1 + fastemit_lambda); the
+            returned loss is the plain negative log-likelihood. Default: 0.0 (the reference's loss)
     """
     if not acts.is_cuda:
         acts = torch.nn.functional.log_softmax(acts, -1)
-    return _RNNT.apply(acts, labels, act_lens, label_lens, blank, reduction)
+    return _RNNT.apply(acts, labels, act_lens, label_lens, blank, reduction, fastemit_lambda)
 
 
 class RNNTLoss(Module):
@@ -109,12 +115,14 @@ class RNNTLoss(Module):
     Parameters:
         blank (int, optional): blank label. Default: 0.
         reduction (string, optional): 'none' | 'mean' | 'sum' (see `rnnt_loss`). Default: 'mean'
+        fastemit_lambda (float, optional): extension, GPU only (see `rnnt_loss`). Default: 0.0
     """
 
-    def __init__(self, blank=0, reduction='mean'):
+    def __init__(self, blank=0, reduction='mean', fastemit_lambda=0.0):
         super(RNNTLoss, self).__init__()
         self.blank = blank
         self.reduction = reduction
+        self.fastemit_lambda = fastemit_lambda
         self.loss = _RNNT.apply
 
     def forward(self, acts, labels, act_lens, label_lens):
@@ -122,7 +130,7 @@ class RNNTLoss(Module):
             # The CPU location of the library takes log-probabilities; log_softmax runs inside
             # the kernels only on the GPU (reference __init__.py:95-98).
             acts = torch.nn.functional.log_softmax(acts, -1)
-        return self.loss(acts, labels, act_lens, label_lens, self.blank, self.reduction)
+        return self.loss(acts, labels, act_lens, label_lens, self.blank, self.reduction, self.fastemit_lambda)
 
 
 def check_type(var, t, name):

@@ -72,10 +72,11 @@ def gpu_rnnt(acts, labels, input_lengths, label_lengths, costs, grads, blank_lab
 
 
 def gpu_rnnt_async(acts, labels, input_lengths, label_lengths, costs_device, grads, blank_label,
-                   grad_scale=None, workspace=None):
+                   grad_scale=None, workspace=None, fastemit_lambda=0.0):
     """Extension: enqueue only (no host copy, no synchronisation).  ``costs_device`` is a device
     tensor (float32, or float64 for float64 acts).  Returns the workspace tensor, which the caller
-    must keep alive until the stream has passed this work."""
+    must keep alive until the stream has passed this work.  ``fastemit_lambda`` != 0 selects
+    compute_rnnt_loss_fastemit."""
     lib = _lib.lib()
     N, T, U, A = acts.shape
     code = {torch.float32: (_lib.DT_F32, 4), torch.float64: (_lib.DT_F64, 8),
@@ -86,10 +87,16 @@ def gpu_rnnt_async(acts, labels, input_lengths, label_lengths, costs_device, gra
                                     device=acts.device)
         stream = torch.cuda.current_stream(acts.device).cuda_stream
         opt = _options(_lib.RNNT_GPU, acts, blank_label, 0, stream)
-        st = lib.compute_rnnt_loss_async(acts.data_ptr(), _ptr(grads), labels.data_ptr(),
-                                         label_lengths.data_ptr(), input_lengths.data_ptr(), A, N,
-                                         costs_device.data_ptr(), _ptr(grad_scale), workspace.data_ptr(),
-                                         opt, code[0])
+        if fastemit_lambda:
+            st = lib.compute_rnnt_loss_fastemit(acts.data_ptr(), _ptr(grads), labels.data_ptr(),
+                                                label_lengths.data_ptr(), input_lengths.data_ptr(), A, N,
+                                                costs_device.data_ptr(), _ptr(grad_scale), workspace.data_ptr(),
+                                                opt, code[0], float(fastemit_lambda))
+        else:
+            st = lib.compute_rnnt_loss_async(acts.data_ptr(), _ptr(grads), labels.data_ptr(),
+                                             label_lengths.data_ptr(), input_lengths.data_ptr(), A, N,
+                                             costs_device.data_ptr(), _ptr(grad_scale), workspace.data_ptr(),
+                                             opt, code[0])
     _lib.check(st, "compute_rnnt_loss_async")
     return workspace
 
@@ -98,10 +105,11 @@ _DT = {torch.float32: (_lib.DT_F32, 4), torch.float64: (_lib.DT_F64, 8),
        torch.bfloat16: (_lib.DT_BF16, 2), torch.float16: (_lib.DT_F16, 2)}
 
 
-def gpu_rnnt_fwd(acts, labels, input_lengths, label_lengths, costs_device, blank_label, prepare_backward):
-    """Extension: forward phase only (compute_rnnt_loss_fwd).  Returns the workspace tensor; with
-    ``prepare_backward`` it holds the gradient-coefficient table `gpu_rnnt_bwd` needs and must be
-    kept (untouched) until then.  Enqueue only."""
+def gpu_rnnt_fwd(acts, labels, input_lengths, label_lengths, costs_device, blank_label, prepare_backward,
+                 fastemit_lambda=0.0):
+    """Extension: forward phase only (compute_rnnt_loss_fwd; compute_rnnt_loss_fwd_fastemit when
+    ``fastemit_lambda`` is not 0).  Returns the workspace tensor; with ``prepare_backward`` it holds the
+    gradient-coefficient table `gpu_rnnt_bwd` needs and must be kept (untouched) until then.  Enqueue only."""
     lib = _lib.lib()
     N, T, U, A = acts.shape
     code, esz = _DT[acts.dtype]
@@ -109,9 +117,15 @@ def gpu_rnnt_fwd(acts, labels, input_lengths, label_lengths, costs_device, blank
         ws = torch.empty(_lib.workspace_bytes(T, U, N, True, esz), dtype=torch.uint8, device=acts.device)
         opt = _options(_lib.RNNT_GPU, acts, blank_label, 0, torch.cuda.current_stream(acts.device).cuda_stream)
         lab_ptr = labels.data_ptr() if labels.numel() else costs_device.data_ptr()   # maxU == 1: never read
-        st = lib.compute_rnnt_loss_fwd(acts.data_ptr(), lab_ptr, label_lengths.data_ptr(),
-                                       input_lengths.data_ptr(), A, N, costs_device.data_ptr(), ws.data_ptr(), opt,
-                                       code, 1 if prepare_backward else 0)
+        if fastemit_lambda:
+            st = lib.compute_rnnt_loss_fwd_fastemit(acts.data_ptr(), lab_ptr, label_lengths.data_ptr(),
+                                                    input_lengths.data_ptr(), A, N, costs_device.data_ptr(),
+                                                    ws.data_ptr(), opt, code, 1 if prepare_backward else 0,
+                                                    float(fastemit_lambda))
+        else:
+            st = lib.compute_rnnt_loss_fwd(acts.data_ptr(), lab_ptr, label_lengths.data_ptr(),
+                                           input_lengths.data_ptr(), A, N, costs_device.data_ptr(), ws.data_ptr(), opt,
+                                           code, 1 if prepare_backward else 0)
     _lib.check(st, "compute_rnnt_loss_fwd")
     return ws
 

@@ -278,6 +278,21 @@ rnntStatus_t compute_rnnt_loss_add_fwd(const float* const trans_acts,
                                        rnntOptions options,
                                        int prepare_backward);
 
+/* compute_rnnt_loss_add_fwd with a FastEmit lambda (see compute_rnnt_loss_fastemit); pairs with the
+ * unchanged compute_rnnt_loss_add_bwd. */
+rnntStatus_t compute_rnnt_loss_add_fwd_fastemit(const float* const trans_acts,
+                                                const float* const pred_acts,
+                                                const int* const flat_labels,
+                                                const int* const label_lengths,
+                                                const int* const input_lengths,
+                                                int alphabet_size,
+                                                int minibatch,
+                                                float* costs_device,
+                                                void* workspace,
+                                                rnntOptions options,
+                                                int prepare_backward,
+                                                float fastemit_lambda);
+
 rnntStatus_t compute_rnnt_loss_add_bwd(const float* const trans_acts,
                                        const float* const pred_acts,
                                        float* trans_grads,

@@ -223,6 +223,30 @@ def test_masked_vocabulary_entries(oracle):
     assert np.allclose(dg, ref_gz.sum(axis=1), rtol=1e-4, atol=5e-4)
 
 
+def test_fastemit_on_the_additive_joint(oracle):
+    """fastemit_lambda on RNNTLossAdd: the oracle's label log-prob gradients times (1 + lambda), chain rule,
+    then the sums over u / t."""
+    from warprnnt_pytorch.add_network import RNNTLossAdd
+    lam = 0.05
+    f, g, labels, tl, ll, blank = problem((3, 23, 9, 130), 14)
+    z = f[:, :, None, :].astype(np.float64) + g[:, None, :, :].astype(np.float64)
+    lp = oracle.log_softmax(z)
+    ref_c, g_lp = oracle.rnnt_logprobs(lp, labels, tl, ll, blank)
+    for b in range(f.shape[0]):
+        for u in range(ll[b]):
+            g_lp[b, :tl[b], u, labels[b, u]] *= 1.0 + lam
+    ref_gz = oracle.chain_rule_to_logits(lp, g_lp)
+    dev = torch.device("cuda:0")
+    tf = torch.tensor(f, device=dev, requires_grad=True)
+    tg = torch.tensor(g, device=dev, requires_grad=True)
+    loss = RNNTLossAdd(blank=blank, reduction="none", fastemit_lambda=lam)(
+        tf, tg, *(torch.tensor(a, device=dev) for a in (labels, tl, ll)))
+    loss.sum().backward()
+    assert np.allclose(loss.detach().cpu().numpy(), ref_c, rtol=1e-5)
+    assert np.allclose(tf.grad.cpu().numpy(), ref_gz.sum(axis=2), rtol=1e-4, atol=2e-4)
+    assert np.allclose(tg.grad.cpu().numpy(), ref_gz.sum(axis=1), rtol=1e-4, atol=5e-4)
+
+
 def test_validation_errors():
     from warprnnt_pytorch.add_network import rnnt_loss_add
     dev = torch.device("cuda:0")

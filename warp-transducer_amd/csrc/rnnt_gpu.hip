@@ -366,10 +366,12 @@ static rnntStatus_t run_gpu(const typename Tag::store* acts, typename Tag::store
 static rnntStatus_t run_gpu_joint(const float* f, const float* g, float* df, float* dg, const int* labels,
                                   const int* label_lengths, const int* input_lengths, int A, int N,
                                   float* costs_device, const float* grad_scale, void* workspace,
-                                  const rnntOptions& opt, int phases, bool want_grad) {
+                                  const rnntOptions& opt, int phases, bool want_grad, float fastemit = 0.0f) {
     Plan<float> p;
     if (!make_plan(p, A, N, opt, workspace, labels, label_lengths, input_lengths, costs_device))
         return RNNT_STATUS_INVALID_VALUE;
+    if (!(fastemit >= 0.0f)) return RNNT_STATUS_INVALID_VALUE;
+    p.fastemit = fastemit;
     const bool do_fwd = (phases & 1) != 0, do_bwd = (phases & 2) != 0;
     if (do_bwd && (df == nullptr || dg == nullptr)) return RNNT_STATUS_INVALID_VALUE;
     // the gradient GEMMs address one sample's rows with 32-bit element offsets
@@ -650,6 +652,19 @@ rnntStatus_t compute_rnnt_loss_add_fwd(const float* const trans_acts, const floa
     return run_gpu_joint(trans_acts, pred_acts, nullptr, nullptr, flat_labels, label_lengths, input_lengths,
                          alphabet_size, minibatch, costs_device, nullptr, workspace, options, 1,
                          prepare_backward != 0);
+}
+
+rnntStatus_t compute_rnnt_loss_add_fwd_fastemit(const float* const trans_acts, const float* const pred_acts,
+                                                const int* const flat_labels, const int* const label_lengths,
+                                                const int* const input_lengths, int alphabet_size, int minibatch,
+                                                float* costs_device, void* workspace, rnntOptions options,
+                                                int prepare_backward, float fastemit_lambda) {
+    if (bad_args(trans_acts, flat_labels, label_lengths, input_lengths, costs_device, workspace, alphabet_size,
+                 minibatch, options) || pred_acts == nullptr || options.loc != RNNT_GPU)
+        return RNNT_STATUS_INVALID_VALUE;
+    return run_gpu_joint(trans_acts, pred_acts, nullptr, nullptr, flat_labels, label_lengths, input_lengths,
+                         alphabet_size, minibatch, costs_device, nullptr, workspace, options, 1,
+                         prepare_backward != 0, fastemit_lambda);
 }
 
 rnntStatus_t compute_rnnt_loss_add_bwd(const float* const trans_acts, const float* const pred_acts,

@@ -50,6 +50,8 @@ EXPORTS = {
                                         rnntOptions]),
     "compute_rnnt_loss_add_fwd": (C.c_int, [_PTR, _PTR, _PTR, _PTR, _PTR, C.c_int, C.c_int, _PTR, _PTR, rnntOptions,
                                             C.c_int]),
+    "compute_rnnt_loss_add_fwd_fastemit": (C.c_int, [_PTR, _PTR, _PTR, _PTR, _PTR, C.c_int, C.c_int, _PTR, _PTR,
+                                                     rnntOptions, C.c_int, C.c_float]),
     "compute_rnnt_loss_add_bwd": (C.c_int, [_PTR, _PTR, _PTR, _PTR, _PTR, _PTR, _PTR, _PTR, C.c_int, C.c_int, _PTR,
                                             rnntOptions]),
     "rnnt_profile_enable": (None, [C.c_int]),

@@ -54,7 +54,7 @@ class _RNNTAdd(Function):
     pass over d(trans_acts) / d(pred_acts), as in `warprnnt_pytorch._RNNT`."""
 
     @staticmethod
-    def forward(ctx, trans_acts, pred_acts, labels, act_lens, label_lens, blank, reduction):
+    def forward(ctx, trans_acts, pred_acts, labels, act_lens, label_lens, blank, reduction, fastemit_lambda=0.0):
         _certify(trans_acts, pred_acts, labels, act_lens, label_lens)
         lib = _lib.lib()
         B, T, V = trans_acts.shape
@@ -68,9 +68,10 @@ class _RNNTAdd(Function):
                                    stream=torch.cuda.current_stream(dev).cuda_stream, blank_label=int(blank),
                                    maxT=T, maxU=U, batch_first=True)
             lab_ptr = labels.data_ptr() if labels.numel() else costs.data_ptr()   # maxU == 1: never read
-            st = lib.compute_rnnt_loss_add_fwd(trans_acts.data_ptr(), pred_acts.data_ptr(), lab_ptr,
-                                               label_lens.data_ptr(), act_lens.data_ptr(), V, B, costs.data_ptr(),
-                                               ws.data_ptr(), opt, 1 if need_grad else 0)
+            st = lib.compute_rnnt_loss_add_fwd_fastemit(trans_acts.data_ptr(), pred_acts.data_ptr(), lab_ptr,
+                                                        label_lens.data_ptr(), act_lens.data_ptr(), V, B,
+                                                        costs.data_ptr(), ws.data_ptr(), opt, 1 if need_grad else 0,
+                                                        float(fastemit_lambda))
             _lib.check(st, "compute_rnnt_loss_add_fwd")
             ws.record_stream(torch.cuda.current_stream(dev))
         ctx.save_for_backward(trans_acts, pred_acts, labels, act_lens, label_lens)
@@ -103,19 +104,21 @@ class _RNNTAdd(Function):
                                                act_lens.data_ptr(), V, B, ctx.workspace.data_ptr(), opt)
             _lib.check(st, "compute_rnnt_loss_add_bwd")
             ctx.workspace.record_stream(torch.cuda.current_stream(dev))
-        return df, dg, None, None, None, None, None
+        return df, dg, None, None, None, None, None, None
 
 
-def rnnt_loss_add(trans_acts, pred_acts, labels, act_lens, label_lens, blank=0, reduction="mean"):
+def rnnt_loss_add(trans_acts, pred_acts, labels, act_lens, label_lens, blank=0, reduction="mean",
+                  fastemit_lambda=0.0):
     """RNN-T loss of the additive joint ``trans_acts[:, :, None] + pred_acts[:, None]`` without
     forming it.  Arguments as `rnnt_loss`, with the two activations instead of the joint tensor."""
-    return _RNNTAdd.apply(trans_acts, pred_acts, labels, act_lens, label_lens, blank, reduction)
+    return _RNNTAdd.apply(trans_acts, pred_acts, labels, act_lens, label_lens, blank, reduction, fastemit_lambda)
 
 
 class RNNTLossAdd(Module):
-    def __init__(self, blank=0, reduction="mean"):
+    def __init__(self, blank=0, reduction="mean", fastemit_lambda=0.0):
         super().__init__()
-        self.blank, self.reduction = blank, reduction
+        self.blank, self.reduction, self.fastemit_lambda = blank, reduction, fastemit_lambda
 
     def forward(self, trans_acts, pred_acts, labels, act_lens, label_lens):
-        return rnnt_loss_add(trans_acts, pred_acts, labels, act_lens, label_lens, self.blank, self.reduction)
+        return rnnt_loss_add(trans_acts, pred_acts, labels, act_lens, label_lens, self.blank, self.reduction,
+                             self.fastemit_lambda)

@@ -375,7 +375,9 @@ static rnntStatus_t run_gpu_joint(const float* f, const float* g, float* df, flo
     const bool do_fwd = (phases & 1) != 0, do_bwd = (phases & 2) != 0;
     if (do_bwd && (df == nullptr || dg == nullptr)) return RNNT_STATUS_INVALID_VALUE;
     // the gradient GEMMs address one sample's rows with 32-bit element offsets
-    if (static_cast<long long>(p.maxT > p.maxU ? p.maxT : p.maxU) * A >= (1LL << 31)) return RNNT_STATUS_INVALID_VALUE;
+    if (static_cast<long long>(p.maxT > p.maxU ? p.maxT : p.maxU) * A >= (1LL << 31) ||
+        static_cast<long long>(N) * (p.maxT + p.maxU) >= (1LL << 31))
+        return RNNT_STATUS_INVALID_VALUE;
     const bool training = want_grad;
     const bool prof = prof_prepare();
     auto mark = [&](int i) { if (prof) (void)hipEventRecord(g_prof.ev[i], p.stream); };

@@ -47,9 +47,9 @@ static Layout make_layout(int maxT, int maxU, int N, size_t lat) {
     l.llf = o;   o = align_up(o + N * sizeof(double));
     l.llb = o;   o = align_up(o + N * sizeof(double));
     l.costs = o; o = align_up(o + N * sizeof(double));
-    // additive joint only: row maxima of f and g, dense weight matrix W (row stride = maxU rounded up to 4)
+    // additive joint only: row maxima of f and g, dense matrices W, CB, CL (row stride = maxU rounded up to 8)
     l.rowmax = o; o = align_up(o + ((static_cast<size_t>(maxT) + maxU) * N + 1) * sizeof(float));   // + the +inf sentinel
-    l.wmat = o;   o = align_up(o + static_cast<size_t>(maxT) * ((maxU + 3) / 4 * 4) * N * sizeof(float));
+    l.wmat = o;   o = align_up(o + 3 * static_cast<size_t>(maxT) * joint_upad(maxU) * N * sizeof(float));   // W | CB | CL
     l.total = o + kAlign;                       // slack to align the caller's base pointer
     return l;
 }
@@ -95,9 +95,10 @@ static void prof_accumulate() {
 // per lane of the DF / DG kernels (0: widest the alignment allows), jfpf / jgpf = operand ping-pong;
 // blk = block-per-row statistics kernel for rows >= 12 KB on/off, jzs = vocabulary split of the Z kernel (1|4|8),
 // xcd = XCD-aware tile order of the short-row statistics kernel on/off, ctile = tiled coefficient kernel on/off,
-// pskip = the gradient kernel's skip-padded-rows form for rows >= 8 KB on/off.
+// pskip = the gradient kernel's skip-padded-rows form for rows >= 8 KB on/off, joh = one-hot df corrections in the
+// additive-joint DF kernel (-1: vocabularies <= 256).
 struct Tune { int sw = 4, nta = 1, gmax = 4194304, rows = 0, tile = 1, tilekb = 52, ppt = 2;
-              int jfnk = 0, jfpf = 1, jgnk = 0, jgpf = 1, blk = 1, jzs = 0, xcd = 1, ctile = 1, pskip = 1; };
+              int jfnk = 0, jfpf = 1, jgnk = 0, jgpf = 1, blk = 1, jzs = 0, xcd = 1, ctile = 1, pskip = 1, joh = -1; };
 static Tune g_tune;
 static bool g_tune_read = false;
 static const Tune& tune() {
@@ -112,7 +113,7 @@ static const Tune& tune() {
             get("gmax", g_tune.gmax); get("rows", g_tune.rows); get("tile", g_tune.tile);
             get("tilekb", g_tune.tilekb); get("ppt", g_tune.ppt);
             get("jfnk", g_tune.jfnk); get("jfpf", g_tune.jfpf); get("jgnk", g_tune.jgnk); get("jgpf", g_tune.jgpf);
-            get("blk", g_tune.blk); get("jzs", g_tune.jzs); get("xcd", g_tune.xcd); get("ctile", g_tune.ctile); get("pskip", g_tune.pskip);
+            get("blk", g_tune.blk); get("jzs", g_tune.jzs); get("xcd", g_tune.xcd); get("ctile", g_tune.ctile); get("pskip", g_tune.pskip); get("joh", g_tune.joh);
         }
     }
     return g_tune;
@@ -238,23 +239,23 @@ template <typename C> static void launch_lattice(Plan<C>& p, bool with_beta) {
 }
 
 // Stage 3: gradient coefficients per row into the natural-order row table.
-template <typename C> static void launch_coef(Plan<C>& p, bool joint = false) {
+template <typename C> static void launch_coef(Plan<C>& p, bool joint = false, bool onehot = false) {
     float* wmat = joint ? p.wmat : nullptr;
-    const int Upad = (p.maxU + 3) / 4 * 4;
+    const int Upad = joint_upad(p.maxU);
     if (p.maxU <= 48 || !tune().ctile) {
         // small lattices: one thread per skewed cell, scattered record store
         const long long skew_cells = static_cast<long long>(p.maxT + p.maxU - 1) * p.Up;
         const dim3 cgrid(static_cast<unsigned>(((skew_cells + 255) / 256 + 7) / 8 * 8), p.N);   // multiple of 8: XCD-aware remap
         hipLaunchKernelGGL((coef_cell_kernel<C>), cgrid, dim3(256), 0, p.stream, p.lp2, p.logz, p.alpha, p.beta, p.offa,
                            p.offb, p.llf, p.labels, p.input_lengths, p.label_lengths, p.rowtab, p.maxT, p.maxU, p.Up,
-                           wmat, Upad, p.fastemit);
+                           wmat, Upad, p.fastemit, onehot ? 3 : 1);
     } else {
         const int DN = sizeof(C) == 4 ? 32 : 16;           // diagonals per tile (coef_kernel)
         const int tilesU = (p.maxU + 63) / 64, tilesN = (p.maxT + p.maxU - 1 + DN - 1) / DN;
         const dim3 cgrid(static_cast<unsigned>(tilesU * tilesN), p.N);
         hipLaunchKernelGGL((coef_kernel<C>), cgrid, dim3(256), 0, p.stream, p.lp2, p.logz, p.alpha, p.beta, p.offa,
                            p.offb, p.llf, p.labels, p.input_lengths, p.label_lengths, p.rowtab, p.maxT, p.maxU, p.Up,
-                           wmat, Upad, tilesU, p.fastemit);
+                           wmat, Upad, tilesU, p.fastemit, onehot ? 3 : 1);
     }
     p.check();
 }
@@ -415,12 +416,15 @@ static rnntStatus_t run_gpu_joint(const float* f, const float* g, float* df, flo
     mark(1);
     if (do_fwd) launch_lattice(p, training);
     mark(2);
-    if (do_fwd && training) launch_coef(p, /*joint=*/true);
+    // small vocabularies: the df corrections ride along in the DF GEMM as one-hot operands (3x its
+    // contraction) instead of one global atomic per lattice cell in the fix-up kernel
+    const bool onehot = tune().joh >= 0 ? tune().joh != 0 : A <= 256;
+    if (do_fwd && training) launch_coef(p, /*joint=*/true, onehot);
     mark(3);
     if (do_bwd) {
         // gradient GEMMs (plain stores of every element, padding included), then the corrections.
         // NK adjacent columns per lane = the widest vector the vocabulary size and alignment allow.
-        const int Upad = (maxU + 3) / 4 * 4;
+        const int Upad = joint_upad(maxU);
         const uintptr_t all4 = reinterpret_cast<uintptr_t>(f) | reinterpret_cast<uintptr_t>(g) |
                                reinterpret_cast<uintptr_t>(df) | reinterpret_cast<uintptr_t>(dg);
         const int NKmax = (A % 4 == 0 && (all4 & 15u) == 0 && A >= 96) ? 4
@@ -428,14 +432,17 @@ static rnntStatus_t run_gpu_joint(const float* f, const float* g, float* df, flo
         const Tune& tn = tune();
         auto pick = [&](int want) { int nk = want > 0 ? want : NKmax; while (nk > NKmax) nk >>= 1; return nk; };
         const int NKf = pick(tn.jfnk), NKg = pick(tn.jgnk);
-#define RNNT_JDF(NN, PP)                                                                                         \
-    hipLaunchKernelGGL((joint_df_kernel<NN, PP>), dim3((A + 128 * NN - 1) / (128 * NN), tilesT, N), dim3(256), 0, \
-                       p.stream, f, g, p.rowmax, p.wmat, grad_scale, input_lengths, label_lengths, df, maxT, maxU, Upad, A, N)
+#define RNNT_JDF(NN, PP, OO)                                                                                     \
+    hipLaunchKernelGGL((joint_df_kernel<NN, PP, OO>), dim3((A + 128 * NN - 1) / (128 * NN), tilesT, N), dim3(256), 0, \
+                       p.stream, f, g, p.rowmax, p.wmat, grad_scale, labels, input_lengths, label_lengths, df, maxT,  \
+                       maxU, Upad, A, N, p.blank)
 #define RNNT_JDG(NN, PP)                                                                                         \
     hipLaunchKernelGGL((joint_dg_kernel<NN, PP>), dim3((A + 128 * NN - 1) / (128 * NN), tilesU, N), dim3(256), 0, \
-                       p.stream, f, g, p.rowmax, p.wmat, grad_scale, input_lengths, label_lengths, dg, maxT, maxU, Upad, A, N)
-        if (tn.jfpf) { if (NKf == 4) RNNT_JDF(4, true); else if (NKf == 2) RNNT_JDF(2, true); else RNNT_JDF(1, true); }
-        else         { if (NKf == 4) RNNT_JDF(4, false); else if (NKf == 2) RNNT_JDF(2, false); else RNNT_JDF(1, false); }
+                       p.stream, f, g, p.rowmax, p.wmat, grad_scale, input_lengths, label_lengths, dg, maxT,     \
+                       maxU, Upad, A, N)
+        if (onehot)       { if (NKf == 4) RNNT_JDF(4, true, true); else if (NKf == 2) RNNT_JDF(2, true, true); else RNNT_JDF(1, true, true); }
+        else if (tn.jfpf) { if (NKf == 4) RNNT_JDF(4, true, false); else if (NKf == 2) RNNT_JDF(2, true, false); else RNNT_JDF(1, true, false); }
+        else              { if (NKf == 4) RNNT_JDF(4, false, false); else if (NKf == 2) RNNT_JDF(2, false, false); else RNNT_JDF(1, false, false); }
         if (tn.jgpf) { if (NKg == 4) RNNT_JDG(4, true); else if (NKg == 2) RNNT_JDG(2, true); else RNNT_JDG(1, true); }
         else         { if (NKg == 4) RNNT_JDG(4, false); else if (NKg == 2) RNNT_JDG(2, false); else RNNT_JDG(1, false); }
 #undef RNNT_JDF
@@ -443,7 +450,7 @@ static rnntStatus_t run_gpu_joint(const float* f, const float* g, float* df, flo
         p.check();
         hipLaunchKernelGGL(joint_fix_kernel, dim3((maxU + 63) / 64, (maxT + kJointFixT - 1) / kJointFixT, N),
                            dim3(256), 0, p.stream, f, g, p.rowmax, p.rowtab, labels, grad_scale, input_lengths,
-                           label_lengths, df, dg, maxT, maxU, A, p.blank, N);
+                           label_lengths, df, dg, maxT, maxU, A, p.blank, N, onehot ? 1 : 0);
         p.check();
     }
     mark(4);

@@ -339,7 +339,7 @@ __global__ __launch_bounds__(S == 1 ? 256 : S * 64) void joint_z_kernel(
 // requested before the loop starts.  Epilogue: multiply by ef, store; rows of the padding are
 // written as zeros.  The four wavefronts of a block take adjacent column groups of the same time
 // rows.  grid = (ceil(A / (128 NK)), ceil(maxT/32), N), block = 256.
-template <int NK> struct JointOperands { float w[4], m[4], x[4][NK]; };
+template <int NK> struct JointOperands { float w[4], m[4], x[4][NK], cb[4], cl[4]; int lab[4]; };
 
 template <int NK>
 __device__ __forceinline__ void joint_mma(const JointOperands<NK>& s, f32x16 (&acc)[NK]) {
@@ -350,11 +350,18 @@ __device__ __forceinline__ void joint_mma(const JointOperands<NK>& s, f32x16 (&a
             acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(s.w[i], joint_exp(s.x[i][n], s.m[i]), acc[n], 0, 0, 0);
 }
 
-template <int NK, bool PF>   // PF: operand ping-pong + epilogue values requested before the loop (more registers)
+// OH (small vocabularies): the blank / label corrections of df are accumulated here as well,
+//     acc2 += CB[t][u] * [k == blank] + CL[t][u] * [k == y_u]       (two more MFMAs per step, one-hot B operands),
+// from the dense CB / CL planes the coefficient kernel writes next to W.  It replaces one global atomic per
+// lattice cell in joint_fix_kernel, which all land on the few cache lines of a short df row (c4 shape,
+// A = 50: 340 us of atomics against ~100 us of extra matrix work); above a few hundred symbols the atomics
+// are cheaper than the 3x contraction and the host keeps them.
+template <int NK, bool PF, bool OH>   // PF: operand ping-pong + epilogue values requested before the loop (more registers)
 __global__ __launch_bounds__(256) void joint_df_kernel(
         const float* __restrict__ f, const float* __restrict__ g, const float* __restrict__ rowmax,
-        const float* __restrict__ wmat, const float* __restrict__ scale, const int* __restrict__ xlen,
-        const int* __restrict__ ylen, float* __restrict__ df, int maxT, int maxU, int Upad, int A, int N) {
+        const float* __restrict__ wmat, const float* __restrict__ scale, const int* __restrict__ labels,
+        const int* __restrict__ xlen, const int* __restrict__ ylen, float* __restrict__ df, int maxT, int maxU,
+        int Upad, int A, int N, int blank) {
     const int b = blockIdx.z;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5, col = lane & 31;
     const int k0 = (static_cast<int>(blockIdx.x) * 4 + wave) * (32 * NK);
@@ -371,6 +378,11 @@ __global__ __launch_bounds__(256) void joint_df_kernel(
     for (int n = 0; n < NK; ++n)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[n][r] = 0.0f;
+    f32x16 acc2[OH ? NK : 1];                              // corrections (OH only)
+#pragma unroll
+    for (int n = 0; n < (OH ? NK : 1); ++n)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc2[n][r] = 0.0f;
 
     if (t0 >= Tb) {                                        // time rows of the padding: zeros
         if (!kin) return;
@@ -399,16 +411,38 @@ __global__ __launch_bounds__(256) void joint_df_kernel(
     const unsigned Au = static_cast<unsigned>(A);          // maxU * A < 2^31 (host check): 32-bit offsets
     const unsigned mg0 = static_cast<unsigned>(N) * maxT + static_cast<unsigned>(b) * maxU;
     const unsigned sentinel = static_cast<unsigned>(N) * (maxT + maxU);
+    const size_t plane = static_cast<size_t>(N) * maxT * Upad;              // W | CB | CL
+    const size_t labs0 = static_cast<size_t>(b) * (maxU > 1 ? maxU - 1 : 1);
     auto load = [&](JointOperands<NK>& s, int u2) {
-        const int ub = u2 + 4 * half;
-        const float4 w4 = *reinterpret_cast<const float4*>(wrow + (ub < Upad - 4 ? ub : Upad - 4));
+        const int ub = u2 + 4 * half;                      // ub + 3 < Upad: Upad is a multiple of 8 and u2 < Ub
+        const float4 w4 = *reinterpret_cast<const float4*>(wrow + ub);
         s.w[0] = w4.x; s.w[1] = w4.y; s.w[2] = w4.z; s.w[3] = w4.w;
+        if constexpr (OH) {                                // zero outside the sample (padding, pad columns): no masks
+            const float4 b4 = *reinterpret_cast<const float4*>(wrow + plane + ub);
+            const float4 l4 = *reinterpret_cast<const float4*>(wrow + 2 * plane + ub);
+            s.cb[0] = b4.x; s.cb[1] = b4.y; s.cb[2] = b4.z; s.cb[3] = b4.w;
+            s.cl[0] = l4.x; s.cl[1] = l4.y; s.cl[2] = l4.z; s.cl[3] = l4.w;
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int u = ub + i;
             const bool uin = u < Ub;
             s.m[i] = rowmax[uin ? mg0 + u : sentinel];
             joint_loadv<NK>(gb + static_cast<unsigned>(uin ? u : Ub - 1) * Au, s.x[i]);
+            if constexpr (OH) s.lab[i] = labels[labs0 + (u < maxU - 1 ? u : (maxU > 1 ? maxU - 2 : 0))];
+        }
+    };
+    auto corr = [&](const JointOperands<NK>& s) {          // OH: acc2 += CB [k == blank] + CL [k == y_u]
+        if constexpr (OH) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int lab = s.lab[i] < 0 ? 0 : (s.lab[i] >= A ? A - 1 : s.lab[i]);
+#pragma unroll
+                for (int n = 0; n < NK; ++n) {
+                    acc2[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(s.cb[i], kc + n == blank ? 1.0f : 0.0f, acc2[n], 0, 0, 0);
+                    acc2[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(s.cl[i], kc + n == lab ? 1.0f : 0.0f, acc2[n], 0, 0, 0);
+                }
+            }
         }
     };
 
@@ -431,21 +465,21 @@ __global__ __launch_bounds__(256) void joint_df_kernel(
         while (u2 + 8 < Ub) {                              // two steps per trip, both unconditional (see joint_z_kernel)
             load(s1, u2 + 8);
             __builtin_amdgcn_sched_barrier(0);
-            joint_mma<NK>(s0, acc);
+            joint_mma<NK>(s0, acc); corr(s0);
             __builtin_amdgcn_sched_barrier(0);
             load(s0, u2 + 16);                             // past the sample: no loads, zero weights
             __builtin_amdgcn_sched_barrier(0);
-            joint_mma<NK>(s1, acc);
+            joint_mma<NK>(s1, acc); corr(s1);
             __builtin_amdgcn_sched_barrier(0);
             u2 += 16;
         }
-        if (u2 < Ub) joint_mma<NK>(s0, acc);
+        if (u2 < Ub) { joint_mma<NK>(s0, acc); corr(s0); }
     } else {
         for (int u2 = 0; u2 < Ub; u2 += 8) {
             JointOperands<NK> s0;
             load(s0, u2);
             __builtin_amdgcn_sched_barrier(0);             // all loads of the step first, then its MFMAs
-            joint_mma<NK>(s0, acc);
+            joint_mma<NK>(s0, acc); corr(s0);
             __builtin_amdgcn_sched_barrier(0);
         }
         load_f();
@@ -458,7 +492,10 @@ __global__ __launch_bounds__(256) void joint_df_kernel(
         if (t >= maxT) continue;
         float o[NK];
 #pragma unroll
-        for (int n = 0; n < NK; ++n) o[n] = t < Tb ? joint_exp(fv[r][n], mt[r]) * (acc[n][r] * sc) : 0.0f;
+        for (int n = 0; n < NK; ++n) {
+            o[n] = t < Tb ? joint_exp(fv[r][n], mt[r]) * (acc[n][r] * sc) : 0.0f;
+            if constexpr (OH) o[n] = t < Tb ? o[n] - acc2[n][r] * sc : 0.0f;
+        }
         joint_storev<NK>(dfb + static_cast<size_t>(t) * A, o);
     }
 }
@@ -568,7 +605,7 @@ __global__ __launch_bounds__(256) void joint_fix_kernel(
         const float* __restrict__ f, const float* __restrict__ g, const float* __restrict__ rowmax,
         const Cell<float>* __restrict__ rowtab, const int* __restrict__ labels,
         const float* __restrict__ scale, const int* __restrict__ xlen, const int* __restrict__ ylen,
-        float* __restrict__ df, float* __restrict__ dg, int maxT, int maxU, int A, int blank, int N) {
+        float* __restrict__ df, float* __restrict__ dg, int maxT, int maxU, int A, int blank, int N, int skip_df) {
     __shared__ float red[2][4][64];
     const int b = blockIdx.z;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -597,8 +634,10 @@ __global__ __launch_bounds__(256) void joint_fix_kernel(
         dgl += rec.z;
         float* dfrow = df + (static_cast<size_t>(b) * maxT + t) * A;
         const float rs = wave_sum(rec.y);
-        if (lane == 0) unsafeAtomicAdd(dfrow + blank, -rs);
-        if (has_lab && rec.z != 0.0f) unsafeAtomicAdd(dfrow + lab, -rec.z);
+        if (!skip_df) {                                    // (done inside joint_df_kernel<.., OH> for small vocabularies)
+            if (lane == 0) unsafeAtomicAdd(dfrow + blank, -rs);
+            if (has_lab && rec.z != 0.0f) unsafeAtomicAdd(dfrow + lab, -rec.z);
+        }
         unsigned long long far = __ballot(uin && rec.x > kJointFarC);
         while (far) {                                      // never taken for ordinary logits
             const int src = __ffsll(static_cast<long long>(far)) - 1;

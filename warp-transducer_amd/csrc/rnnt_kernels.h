@@ -51,6 +51,10 @@ constexpr double kLn2 = 0.6931471805599453;
 // W[b][t][u] = exp(c) of the gradient GEMMs; cells with c above kJointFarC ("far" cells, whose two
 // logit rows peak at different symbols) and the padding get 0 and are handled outside the GEMMs.
 constexpr float kJointFarC = 40.0f;
+// Row stride of those dense matrices: maxU rounded up to 8 (the GEMMs read them eight columns at a time;
+// the pad columns are kept zero).  Three planes of N*maxT*Upad floats each: W, CB (blank corrections),
+// CL (label corrections).
+__host__ __device__ inline int joint_upad(int maxU) { return (maxU + 7) & ~7; }
 
 // The skewed arrays carry kLatPad spare rows before diagonal 0 and after diagonal D-1 of every
 // sample, so the last (partial) chunk of a sweep can run its full C steps without bounds checks.
@@ -812,7 +816,8 @@ __global__ __launch_bounds__(256) void coef_cell_kernel(
         const L* __restrict__ beta, const double* __restrict__ offa,
         const double* __restrict__ offb, const double* __restrict__ ll_fwd,
         const int* __restrict__ labels, const int* __restrict__ xlen, const int* __restrict__ ylen,
-        Cell<L>* __restrict__ rowtab, int maxT, int maxU, int Up, float* __restrict__ wmat, int Upad, float fastemit) {
+        Cell<L>* __restrict__ rowtab, int maxT, int maxU, int Up, float* __restrict__ wmat, int Upad, float fastemit,
+        int planes) {                      // planes: 1 = W only, 3 = W, CB, CL (one-hot df corrections)
     const int b = blockIdx.y;
     const unsigned per = gridDim.x >> 3;
     const unsigned blk = (blockIdx.x & 7u) * per + (blockIdx.x >> 3);
@@ -822,15 +827,19 @@ __global__ __launch_bounds__(256) void coef_cell_kernel(
     const int n = uniform(static_cast<int>(i0 / Up));
     const int u = static_cast<int>(i0 - static_cast<long long>(n) * Up) + (threadIdx.x & 63);
     const int t = n - u;
-    if (wmat != nullptr && u >= maxU && u < Upad && t >= 0 && t < maxT)   // additive joint: W's pad columns are zero
-        wmat[(static_cast<size_t>(b) * maxT + t) * Upad + u] = 0.0f;
+    const size_t plane = static_cast<size_t>(gridDim.y) * maxT * Upad;      // gridDim.y = N
     if (u >= maxU || t < 0 || t >= maxT) return;              // not a row of the tensor
     const Cell<L> o = coef_cell<L>(lp2, logz, alpha_arr, beta, offa, offb, ll_fwd, labels, b, n, t, u, xlen[b],
                                    ylen[b] + 1, maxT, maxU, Up, fastemit);
     rowtab[(static_cast<size_t>(b) * maxT + t) * maxU + u] = o;
-    if (wmat != nullptr) {                                    // additive joint only: W = exp(c), row stride Upad
+    if (wmat != nullptr) {                                    // additive joint only: W = exp(c), cb, cl; row stride Upad
         const float c = static_cast<float>(o.x);
-        wmat[(static_cast<size_t>(b) * maxT + t) * Upad + u] = c > kJointFarC ? 0.0f : fast_exp(c);
+        const size_t at = (static_cast<size_t>(b) * maxT + t) * Upad + u;
+        wmat[at] = c > kJointFarC ? 0.0f : fast_exp(c);
+        if (planes == 3) { wmat[plane + at] = static_cast<float>(o.y); wmat[2 * plane + at] = static_cast<float>(o.z); }
+        if (u == maxU - 1)                                    // the row's pad columns [maxU, Upad) are zero
+            for (int k = 1; k <= Upad - maxU; ++k)
+                for (int pl = 0; pl < planes; ++pl) wmat[pl * plane + at + k] = 0.0f;
     }
 }
 
@@ -851,7 +860,7 @@ __global__ __launch_bounds__(256) void coef_kernel(
         const double* __restrict__ offb, const double* __restrict__ ll_fwd,
         const int* __restrict__ labels, const int* __restrict__ xlen, const int* __restrict__ ylen,
         Cell<L>* __restrict__ rowtab, int maxT, int maxU, int Up, float* __restrict__ wmat, int Upad, int tilesU,
-        float fastemit) {
+        float fastemit, int planes) {
     constexpr int DN = sizeof(L) == 4 ? 32 : 16;           // diagonals per tile (LDS: DN * 64 records)
     __shared__ Cell<L> recs[DN][64];
     const int b = blockIdx.y;
@@ -876,6 +885,7 @@ __global__ __launch_bounds__(256) void coef_kernel(
     }
     __syncthreads();
     // ---- store, natural order: groups of DN lanes take one time row each
+    const size_t plane = static_cast<size_t>(gridDim.y) * maxT * Upad;      // gridDim.y = N
     constexpr int GROUPS = 256 / DN;
     const int grp = threadIdx.x / DN, c = threadIdx.x % DN;
     const int t_lo = n0 - (u0 + 63);                       // first time row that meets the tile
@@ -887,18 +897,14 @@ __global__ __launch_bounds__(256) void coef_kernel(
         if (u > u0 + 63 || u >= maxU || t + u >= n0 + DN || t + u >= D) continue;
         const Cell<L> o = recs[t + u - n0][u - u0];
         rowtab[(static_cast<size_t>(b) * maxT + t) * maxU + u] = o;
-        if (wmat != nullptr) {                             // additive joint only: W = exp(c), row stride Upad
+        if (wmat != nullptr) {                             // additive joint only: W = exp(c), cb, cl; row stride Upad
             const float cc = static_cast<float>(o.x);
-            wmat[(static_cast<size_t>(b) * maxT + t) * Upad + u] = cc > kJointFarC ? 0.0f : fast_exp(cc);
-        }
-    }
-    // additive joint: W's pad columns [maxU, Upad) are zero (tiles of the last column group only)
-    if (wmat != nullptr && u0 + 64 >= maxU) {
-        for (int r = grp; r < DN + 63; r += GROUPS) {
-            const int t = t_lo + r;
-            if (t < 0 || t >= maxT || c >= Upad - maxU) continue;
-            // each (t, pad column) is written by the tiles of every diagonal range that meets row t: same value
-            wmat[(static_cast<size_t>(b) * maxT + t) * Upad + maxU + c] = 0.0f;
+            const size_t at = (static_cast<size_t>(b) * maxT + t) * Upad + u;
+            wmat[at] = cc > kJointFarC ? 0.0f : fast_exp(cc);
+            if (planes == 3) { wmat[plane + at] = static_cast<float>(o.y); wmat[2 * plane + at] = static_cast<float>(o.z); }
+            if (u == maxU - 1)                             // the row's pad columns [maxU, Upad) are zero
+                for (int k = 1; k <= Upad - maxU; ++k)
+                    for (int pl = 0; pl < planes; ++pl) wmat[pl * plane + at + k] = 0.0f;
         }
     }
 }

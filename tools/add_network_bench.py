@@ -5,7 +5,7 @@
                  -> df = grads.sum(2), dg = grads.sum(1)  (torch)   [what a user of the reference does]
   step         : RNNTLossAdd(reduction='mean') forward + backward through autograd (two-phase entry,
                  1/N and grad_output folded into the gradient kernels)
-Usage: python tools/add_network_bench.py [c2 c3 c4]"""
+Usage: python tools/add_network_bench.py [--fused-only] [c2 c3 c4 c5f32]   (--fused-only: skip the materialised comparison)"""
 import ctypes as C
 import os
 import sys
@@ -20,7 +20,8 @@ from warprnnt_pytorch import _lib, warp_rnnt
 SHAPES = {"c2": (16, 150, 41, 28), "c3": (128, 150, 21, 5000), "c4": (64, 1500, 301, 50), "c5f32": (128, 200, 41, 1024)}
 dev = torch.device("cuda:0")
 lib = _lib.lib()
-for name in sys.argv[1:] or ["c3"]:
+FUSED_ONLY = "--fused-only" in sys.argv
+for name in [a for a in sys.argv[1:] if not a.startswith("--")] or ["c3"]:
     N, T, U, A = SHAPES[name]
     g0 = torch.Generator(device=dev); g0.manual_seed(1)
     f = torch.rand((N, T, A), generator=g0, device=dev)
@@ -39,7 +40,7 @@ for name in sys.argv[1:] or ["c3"]:
                                        ll.data_ptr(), tl.data_ptr(), A, N, costs.data_ptr(), ws.data_ptr(), opt)
         assert st == 0
 
-    grads = torch.empty((N, T, U, A), device=dev)
+    grads = None if FUSED_ONLY else torch.empty((N, T, U, A), device=dev)
 
     def materialised():
         joint = f.unsqueeze(2) + g.unsqueeze(1)
@@ -47,7 +48,7 @@ for name in sys.argv[1:] or ["c3"]:
         return grads.sum(2), grads.sum(1)
 
     out = {}
-    for label, fn in (("fused", fused), ("materialised", materialised)):
+    for label, fn in (("fused", fused),) + (() if FUSED_ONLY else (("materialised", materialised),)):
         for _ in range(3):
             fn()
         torch.cuda.synchronize()
@@ -79,6 +80,10 @@ for name in sys.argv[1:] or ["c3"]:
     torch.cuda.synchronize()
     step_ms = (time.perf_counter() - t0) * 1e2
     c_f = costs.clone(); fused(); torch.cuda.synchronize()
+    if FUSED_ONLY:
+        print("%s N=%d T=%d U=%d A=%d: fused %.3f ms (stages stats/lattice/coef/grad/span %s) | autograd step (mean) %.3f ms"
+              % (name, N, T, U, A, out["fused"][0], out["fused"][1], step_ms))
+        continue
     print("%s N=%d T=%d U=%d A=%d: fused %.3f ms (stages stats/lattice/coef/grad/span %s) | materialised %.3f ms "
           "(library stages %s) | speed-up x%.1f | autograd step (mean) %.3f ms"
           % (name, N, T, U, A, out["fused"][0], out["fused"][1], out["materialised"][0], out["materialised"][1],

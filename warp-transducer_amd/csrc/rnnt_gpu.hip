@@ -407,7 +407,12 @@ static rnntStatus_t run_gpu_joint(const float* f, const float* g, float* df, flo
     hipLaunchKernelGGL((joint_z_kernel<SS, VV>), dim3(SS == 1 ? ((tiles + 3) / 4 + 7) / 8 * 8 : tiles, N),                      \
                        dim3(SS == 1 ? 256 : SS * 64), 0, p.stream, f, g, p.rowmax, labels, input_lengths,        \
                        label_lengths, p.lp2, p.logz, maxT, maxU, p.Up, A, p.blank, tilesU, tiles, N)
-        if (S == 8) { if (vec) RNNT_JZ(8, true); else RNNT_JZ(8, false); }
+        if (S == 1 && A <= kJointZSmallA && tune().jzs != 1)
+            hipLaunchKernelGGL(joint_z_small_kernel, dim3(((tiles + 3) / 4 + 7) / 8 * 8, N), dim3(256),
+                               4 * kJointZSmallSlice * sizeof(float), p.stream, f, g, p.rowmax, labels,
+                               input_lengths, label_lengths, p.lp2, p.logz, maxT, maxU, p.Up, A, p.blank, tilesU,
+                               tiles, N);
+        else if (S == 8) { if (vec) RNNT_JZ(8, true); else RNNT_JZ(8, false); }
         else if (S == 4) { if (vec) RNNT_JZ(4, true); else RNNT_JZ(4, false); }
         else { if (vec) RNNT_JZ(1, true); else RNNT_JZ(1, false); }
 #undef RNNT_JZ

@@ -122,20 +122,20 @@ template <int NK> __device__ __forceinline__ void joint_storev(float* __restrict
     else p[0] = v[0];
 }
 
-// Four consecutive columns k..k+3 of a row.  VEC (A % 4 == 0, rows 16-byte aligned): a packet past
-// the end is read from the last valid packet instead and the CALLER cancels it (row maximum +inf
-// -> exp(x - inf) = 0); scalar form: columns >= A read as -inf.
+// Four consecutive columns k..k+3 of a row, loaded UNCONDITIONALLY: a column past the end is read from a
+// valid one instead (VEC: the whole 16-byte packet from the last packet, A % 4 == 0 and rows 16-byte
+// aligned; scalar form: each element from column A-1) and the CALLER cancels it (row maximum +inf ->
+// exp(x - inf) = 0).  With guards instead, every scalar load sat in its own exec-masked branch.
 template <bool VEC>
 __device__ __forceinline__ float4 joint_load4(const float* __restrict__ row, int k, int A) {
     if constexpr (VEC) {
         return *reinterpret_cast<const float4*>(row + (k < A ? k : A - 4));
     } else {
-        const float ninf = neg_inf<float>();
-        float4 v = {ninf, ninf, ninf, ninf};
-        if (k < A) v.x = row[k];
-        if (k + 1 < A) v.y = row[k + 1];
-        if (k + 2 < A) v.z = row[k + 2];
-        if (k + 3 < A) v.w = row[k + 3];
+        float4 v;
+        v.x = row[k < A ? k : A - 1];
+        v.y = row[k + 1 < A ? k + 1 : A - 1];
+        v.z = row[k + 2 < A ? k + 2 : A - 1];
+        v.w = row[k + 3 < A ? k + 3 : A - 1];
         return v;
     }
 }
@@ -166,7 +166,7 @@ __global__ __launch_bounds__(S == 1 ? 256 : S * 64) void joint_z_kernel(
     __shared__ float4 stage4[WAVES * kJointZSlice / 4];
     float* stage = reinterpret_cast<float*>(stage4);
     const int b = blockIdx.y;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5, col = lane & 31;
+    const int lane = threadIdx.x & 63, wave = uniform(threadIdx.x >> 6), half = lane >> 5, col = lane & 31;
     // S == 1 (many tiles): XCD-aware order -- workgroup i runs on XCD i % 8, so every XCD is given one
     // contiguous range of tile groups and the partial lines of the skewed arrays that neighbouring tiles
     // write meet in one L2 (gridDim.x is a multiple of 8 then; see row_stats_tile_kernel)
@@ -210,16 +210,18 @@ __global__ __launch_bounds__(S == 1 ? 256 : S * 64) void joint_z_kernel(
         }
     };
     auto compute = [&](const float4 (&fv)[4], const float4 (&gv)[4], int cc) {
-        const bool in = cc * 32 + lcol < A;                // packets past the end were read elsewhere: cancel
+        // columns past the end were read elsewhere: cancel them through the maximum (VEC: the whole packet)
+        const int k = cc * 32 + lcol;
         const float pinf = -neg_inf<float>();
+        const bool in0 = k < A, in1 = VEC ? in0 : k + 1 < A, in2 = VEC ? in0 : k + 2 < A, in3 = VEC ? in0 : k + 3 < A;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const float a = in ? mfr[i] : pinf, d = in ? mgr[i] : pinf;
+            const float a = mfr[i], d = mgr[i];
             float4 e, h;
-            e.x = joint_exp(fv[i].x, a); e.y = joint_exp(fv[i].y, a);
-            e.z = joint_exp(fv[i].z, a); e.w = joint_exp(fv[i].w, a);
-            h.x = joint_exp(gv[i].x, d); h.y = joint_exp(gv[i].y, d);
-            h.z = joint_exp(gv[i].z, d); h.w = joint_exp(gv[i].w, d);
+            e.x = joint_exp(fv[i].x, in0 ? a : pinf); e.y = joint_exp(fv[i].y, in1 ? a : pinf);
+            e.z = joint_exp(fv[i].z, in2 ? a : pinf); e.w = joint_exp(fv[i].w, in3 ? a : pinf);
+            h.x = joint_exp(gv[i].x, in0 ? d : pinf); h.y = joint_exp(gv[i].y, in1 ? d : pinf);
+            h.z = joint_exp(gv[i].z, in2 ? d : pinf); h.w = joint_exp(gv[i].w, in3 ? d : pinf);
             *reinterpret_cast<float4*>(fs + (lrow + 8 * i) * kJointZPad + lcol) = e;
             *reinterpret_cast<float4*>(gs + (lrow + 8 * i) * kJointZPad + lcol) = h;
         }
@@ -273,7 +275,25 @@ __global__ __launch_bounds__(S == 1 ? 256 : S * 64) void joint_z_kernel(
     const float l2e = static_cast<float>(kLog2e), ln2 = static_cast<float>(kLn2);
     const float gbl = __builtin_fmaf(gu[blank], l2e, -mgu), glab = __builtin_fmaf(gu[lab], l2e, -mgu);   // base 2
 
-    auto finish = [&](int r, float z) {
+    // The per-cell gathers f[t,blank], f[t,label] and mf[t] of the registers this wavefront finishes are
+    // requested together, BEFORE the cell loop: inside it they were sixteen dependent memory round trips
+    // (the ballot / recompute loop between two cells keeps the compiler from batching them) -- most of a
+    // tile's time when the vocabulary is small.
+    constexpr int PER = S == 1 ? 16 : 16 / S;              // fragment registers finished by this wavefront
+    const int rbase = S == 1 ? 0 : wave * PER;
+    float fbl[PER], flb[PER], mtv[PER];
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        const int t = t0 + mfma_row(rbase + i, lane);
+        const int tc = t < Tb ? t : Tb - 1;
+        const float* ft = f + (static_cast<size_t>(b) * maxT + tc) * A;
+        fbl[i] = ft[blank];
+        flb[i] = ft[lab];
+        mtv[i] = mf[tc];
+    }
+
+    auto finish = [&](int i, float z) {                    // i-th register of this wavefront's share
+        const int r = rbase + i;
         const int t = t0 + mfma_row(r, lane);
         const bool valid = t < Tb && u < Ub;
         float lz = acc_log(z);
@@ -296,12 +316,10 @@ __global__ __launch_bounds__(S == 1 ? 256 : S * 64) void joint_z_kernel(
             if (lane == src) lz = v;
         }
         if (!valid) return;
-        const float* ft = f + (static_cast<size_t>(b) * maxT + t) * A;
-        const float mt = mf[t];
         LogPair<float> rec;                               // lattice log-probs are kept in base 2
         const float lz2 = lz * l2e;
-        rec.x = fmaxf(__builtin_fmaf(ft[blank], l2e, -mt) + gbl - lz2, log_zero<float>());
-        rec.y = has_lab ? fmaxf(__builtin_fmaf(ft[lab], l2e, -mt) + glab - lz2, log_zero<float>())
+        rec.x = fmaxf(__builtin_fmaf(fbl[i], l2e, -mtv[i]) + gbl - lz2, log_zero<float>());
+        rec.y = has_lab ? fmaxf(__builtin_fmaf(flb[i], l2e, -mtv[i]) + glab - lz2, log_zero<float>())
                         : log_zero<float>();
         const size_t idx = lat_index(b, t + u, u, maxT, maxU, Up);
         lp2[idx] = rec;
@@ -311,19 +329,210 @@ __global__ __launch_bounds__(S == 1 ? 256 : S * 64) void joint_z_kernel(
     if constexpr (S == 1) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) finish(r, acc[r]);
-    } else {
+        } else {
         // the wavefront's own (now idle) LDS slice carries its fragment to the others
 #pragma unroll
         for (int r = 0; r < 16; ++r) fs[r * 64 + lane] = acc[r];
         __syncthreads();
-        constexpr int per = 16 / S;                        // fragment registers finished by each wavefront
 #pragma unroll
-        for (int i = 0; i < per; ++i) {
-            const int r = wave * per + i;
+        for (int i = 0; i < PER; ++i) {
+            const int r = rbase + i;
             float z = 0.0f;
 #pragma unroll
             for (int s = 0; s < S; ++s) z += stage[s * kJointZSlice + r * 64 + lane];
-            finish(r, z);
+            finish(i, z);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Partition function, small vocabularies (A <= kJointZSmallA).  joint_z_kernel is bound there by the
+// ADDRESS rate of the vector L1 and by instruction issue, not by bytes (PMC on the c4 shape, A = 50:
+// 0.93 cache accesses per CU and cycle -- 4-byte operand loads that touch every 64-byte piece of a row
+// four times, one write request per lattice cell because consecutive u of one t are Up+1 elements
+// apart in the skewed arrays -- and ~1400 vector instructions per tile, most of them addresses).
+// Here a wavefront reads the 32 rows of f and of g its tile needs as ONE flat run each (rows of a sample
+// are adjacent in memory: 32*A consecutive floats, 256 contiguous bytes per buffer load, rows past the
+// sample come back as zeros from the descriptor's range check; all loads are requested before the first
+// is used) and keeps the RAW logits of the whole vocabulary in its private LDS slice (row stride AS odd:
+// conflict-free column reads).  exp(x - rowmax) is applied when the MFMA operands are read back (lane =
+// row, so the maximum is a per-lane constant), the blank / label logits of the epilogue come from the
+// same slice instead of global gathers, and the finished tile is turned through LDS so that the stores
+// run ALONG the anti-diagonals -- the direction in which the skewed arrays are contiguous (two diagonals
+// per store instruction).
+// grid = (ceil(tiles/4) rounded up to 8, N), block = 256, dynamic LDS = 4 * kJointZSmallSlice floats.
+constexpr int kJointZSmallA = 56;
+constexpr int kJointZSmallIt = kJointZSmallA / 2;          // flat loads per lane and operand (32 rows * A / 64)
+constexpr int kJointZOutPad = 34;                          // row stride of the turned tile (diagonal reads hit distinct banks)
+constexpr int kJointZSmallOp = 32 * (kJointZSmallA + 1);   // floats per operand
+constexpr int kJointZSmallSlice = 2 * kJointZSmallOp + 64; // per wavefront (>= 3 * 32 * kJointZOutPad); 4 slices < 64 KB
+static_assert(kJointZSmallSlice >= 3 * 32 * kJointZOutPad && 4 * kJointZSmallSlice * 4 <= 65536, "LDS budget");
+
+__global__ __launch_bounds__(256) void joint_z_small_kernel(
+        const float* __restrict__ f, const float* __restrict__ g, const float* __restrict__ rowmax,
+        const int* __restrict__ labels, const int* __restrict__ xlen, const int* __restrict__ ylen,
+        LogPair<float>* __restrict__ lp2, float* __restrict__ logz, int maxT, int maxU, int Up, int A,
+        int blank, int tilesU, int tiles, int N) {
+    extern __shared__ float4 zsmall4[];
+    constexpr int IT = kJointZSmallIt;
+    const int AS = A | 1;                                  // LDS row stride
+    const int b = blockIdx.y;
+    // the wavefront index as a SCALAR: everything derived from it (tile, row ranges, buffer descriptors)
+    // stays in SGPRs -- as a function of threadIdx the compiler treats it as divergent and wraps every
+    // buffer load in a waterfall loop
+    const int lane = threadIdx.x & 63, wave = uniform(threadIdx.x >> 6);
+    const int half = lane >> 5, col = lane & 31;
+    const int group = static_cast<int>((blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3));   // XCD-aware, as joint_z_kernel
+    const int tile = group * 4 + wave;
+    if (tile >= tiles) return;
+    const int Tb = xlen[b], Ub = ylen[b] + 1;
+    const int t0 = (tile / tilesU) * 32, u0 = (tile % tilesU) * 32;
+    if (t0 >= Tb || u0 >= Ub) return;
+    const float* mf = rowmax + static_cast<size_t>(b) * maxT;
+    const float* mg = rowmax + static_cast<size_t>(N) * maxT + static_cast<size_t>(b) * maxU;
+    const float* sentinel = rowmax + static_cast<size_t>(N) * (maxT + maxU);      // +inf: exp(x - inf) = 0
+    float* fs = reinterpret_cast<float*>(zsmall4) + wave * kJointZSmallSlice;     // [32][AS] raw f
+    float* gs = fs + kJointZSmallOp;                                              // [32][AS] raw g
+    float* spare = gs + kJointZSmallOp;
+
+    // ---- every global load of the tile is requested here, before anything waits
+    const int nf = (Tb - t0 < 32 ? Tb - t0 : 32) * A, ng = (Ub - u0 < 32 ? Ub - u0 : 32) * A;   // valid flat elements
+    const __amdgpu_buffer_rsrc_t rf = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(f) + (static_cast<size_t>(b) * maxT + t0) * A, 0, nf * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(g) + (static_cast<size_t>(b) * maxU + u0) * A, 0, ng * 4, 0x00020000);
+    float fv[IT], gv[IT];
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {                         // past the valid rows: 0
+        fv[i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rf, lane * 4, i * 256, 0));
+        gv[i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rg, lane * 4, i * 256, 0));
+    }
+    const float ma = *(t0 + col < Tb ? mf + t0 + col : sentinel);   // this lane's row of f as MFMA operand
+    const float mb = *(u0 + col < Ub ? mg + u0 + col : sentinel);   // ... of g; also the label row of its cells
+    const int u = u0 + col;
+    const bool has_lab = u < Ub - 1;
+    int lab = blank;
+    if (has_lab) lab = labels[static_cast<size_t>(b) * (maxU - 1) + u];
+    __builtin_amdgcn_sched_barrier(0);
+
+    // ---- raw logits into LDS: element e = 64 i + lane of the flat run is (row e / A, column e % A)
+    {
+        int r = lane / A, k = lane - r * A;
+        const int dr = 64 / A, dk = 64 - dr * A;
+#pragma unroll
+        for (int i = 0; i < IT; ++i) {
+            const bool in = r < 32;                        // branch-free: elements past the tile go to a spare word
+            const int off = r * AS + k;
+            (in ? fs + off : spare)[0] = fv[i];
+            (in ? gs + off : spare)[0] = gv[i];
+            k += dk; r += dr;
+            const bool wrap = k >= A;
+            k -= wrap ? A : 0;
+            r += wrap ? 1 : 0;
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+    // ---- contraction: lane half h takes columns 2s + h; four steps per group, the next group's LDS
+    //      reads are issued before the current group's exp / MFMA
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+    {
+        const float* fr = fs + col * AS + half;
+        const float* gr = gs + col * AS + half;
+        const int ngroup = (A + 7) >> 3;
+        auto rd = [&](float (&x)[4], float (&y)[4], int j) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { x[i] = fr[8 * j + 2 * i]; y[i] = gr[8 * j + 2 * i]; }
+        };
+        auto mm = [&](const float (&x)[4], const float (&y)[4], int j) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const bool kin = 8 * j + 2 * i + half < A; // a column past the end reads the next row: cancel it
+                const float a = kin ? joint_exp(x[i], ma) : 0.0f;
+                const float d = kin ? joint_exp(y[i], mb) : 0.0f;
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, d, acc, 0, 0, 0);
+            }
+        };
+        float x0[4], y0[4], x1[4], y1[4];
+        rd(x0, y0, 0);
+        int j = 0;
+        while (j + 1 < ngroup) {
+            rd(x1, y1, j + 1);
+            mm(x0, y0, j);
+            rd(x0, y0, j + 2);                             // past the last group: inside the slice, unused
+            mm(x1, y1, j + 1);
+            j += 2;
+        }
+        if (j < ngroup) mm(x0, y0, j);
+    }
+
+    // ---- epilogue: blank / label logits from the slice, the three values of every cell to LDS in tile order ...
+    const float l2e = static_cast<float>(kLog2e), ln2 = static_cast<float>(kLn2);
+    lab = lab < 0 ? 0 : (lab >= A ? A - 1 : lab);
+    const float gbl = __builtin_fmaf(gs[col * AS + blank], l2e, -mb);     // base 2
+    const float glab = __builtin_fmaf(gs[col * AS + lab], l2e, -mb);
+    float fbl[16], flb[16], mtv[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int tl = mfma_row(i, lane);
+        fbl[i] = fs[tl * AS + blank];
+        flb[i] = fs[tl * AS + lab];
+        mtv[i] = __shfl(ma, tl);                           // lane tl holds the maximum of row tl
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();                       // the logits are dead: the slice is reused
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    float* px = fs;
+    float* py = fs + 32 * kJointZOutPad;
+    float* pz = fs + 64 * kJointZOutPad;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int tl = mfma_row(i, lane);
+        const bool valid = t0 + tl < Tb && u < Ub;
+        const float z = acc[i];
+        float lz = acc_log(z);
+        // rows peaking far apart: direct log-sum-exp, as in joint_z_kernel (never taken for ordinary logits)
+        unsigned long long bad = __ballot(valid && !(z >= kJointFlagZ));
+        while (bad) {
+            const int src = __ffsll(static_cast<long long>(bad)) - 1;
+            bad &= bad - 1;
+            const int tt = t0 + mfma_row(i, src), uu = u0 + (src & 31);
+            const float* fr = f + (static_cast<size_t>(b) * maxT + tt) * A;
+            const float* gr = g + (static_cast<size_t>(b) * maxU + uu) * A;
+            float m = neg_inf<float>();
+            for (int k = lane; k < A; k += 64) m = fmaxf(m, fr[k] + gr[k]);
+            m = fmaxf(wave_max(m), kJointMinMax);
+            float sum = 0.0f;
+            for (int k = lane; k < A; k += 64) sum += fast_exp(fr[k] + gr[k] - m);
+            sum = wave_sum(sum);
+            const float v = (m - (mf[tt] + mg[uu]) * ln2) + acc_log(sum);
+            if (lane == src) lz = v;
+        }
+        const float lz2 = lz * l2e;                        // lattice log-probs are kept in base 2
+        px[tl * kJointZOutPad + col] = fmaxf(__builtin_fmaf(fbl[i], l2e, -mtv[i]) + gbl - lz2, log_zero<float>());
+        py[tl * kJointZOutPad + col] = has_lab ? fmaxf(__builtin_fmaf(flb[i], l2e, -mtv[i]) + glab - lz2, log_zero<float>())
+                                               : log_zero<float>();
+        pz[tl * kJointZOutPad + col] = lz;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // ... and leave along the anti-diagonals: diagonal d of the tile is cells (t0 + d - j, u0 + j), adjacent in j
+    const size_t base = lat_index(b, t0 + u0, u0, maxT, maxU, Up);
+#pragma unroll 4
+    for (int it = 0; it < 32; ++it) {
+        const int d = 2 * it + half, tl = d - col;
+        if (tl >= 0 && tl < 32 && t0 + tl < Tb && u < Ub) {
+            const size_t idx = base + static_cast<size_t>(d) * Up + col;
+            LogPair<float> rec;
+            rec.x = px[tl * kJointZOutPad + col];
+            rec.y = py[tl * kJointZOutPad + col];
+            lp2[idx] = rec;
+            logz[idx] = pz[tl * kJointZOutPad + col];
         }
     }
 }
@@ -363,7 +572,7 @@ __global__ __launch_bounds__(256) void joint_df_kernel(
         const int* __restrict__ xlen, const int* __restrict__ ylen, float* __restrict__ df, int maxT, int maxU,
         int Upad, int A, int N, int blank) {
     const int b = blockIdx.z;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5, col = lane & 31;
+    const int lane = threadIdx.x & 63, wave = uniform(threadIdx.x >> 6), half = lane >> 5, col = lane & 31;
     const int k0 = (static_cast<int>(blockIdx.x) * 4 + wave) * (32 * NK);
     if (k0 >= A) return;
     const int kc = k0 + NK * col;                          // first of this lane's NK columns
@@ -511,7 +720,7 @@ __global__ __launch_bounds__(256) void joint_dg_kernel(
         const float* __restrict__ wmat, const float* __restrict__ scale, const int* __restrict__ xlen,
         const int* __restrict__ ylen, float* __restrict__ dg, int maxT, int maxU, int Upad, int A, int N) {
     const int b = blockIdx.z;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5, col = lane & 31;
+    const int lane = threadIdx.x & 63, wave = uniform(threadIdx.x >> 6), half = lane >> 5, col = lane & 31;
     const int k0 = (static_cast<int>(blockIdx.x) * 4 + wave) * (32 * NK);
     if (k0 >= A) return;
     const int kc = k0 + NK * col;
@@ -608,7 +817,7 @@ __global__ __launch_bounds__(256) void joint_fix_kernel(
         float* __restrict__ df, float* __restrict__ dg, int maxT, int maxU, int A, int blank, int N, int skip_df) {
     __shared__ float red[2][4][64];
     const int b = blockIdx.z;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = uniform(threadIdx.x >> 6);
     const int ub0 = blockIdx.x * 64, tb0 = blockIdx.y * kJointFixT;
     const int Tb = xlen[b], Ub = ylen[b] + 1;
     if (tb0 >= Tb || ub0 >= Ub) return;                    // block-uniform

@@ -822,7 +822,7 @@ __global__ __launch_bounds__(256) void coef_cell_kernel(
     const unsigned per = gridDim.x >> 3;
     const unsigned blk = (blockIdx.x & 7u) * per + (blockIdx.x >> 3);
     const int D = maxT + maxU - 1;
-    const long long i0 = (static_cast<long long>(blk) * 4 + (threadIdx.x >> 6)) * 64;   // this wavefront's first cell
+    const long long i0 = (static_cast<long long>(blk) * 4 + uniform(threadIdx.x >> 6)) * 64;   // this wavefront's first cell
     if (i0 >= static_cast<long long>(D) * Up) return;
     const int n = uniform(static_cast<int>(i0 / Up));
     const int u = static_cast<int>(i0 - static_cast<long long>(n) * Up) + (threadIdx.x & 63);
@@ -864,7 +864,7 @@ __global__ __launch_bounds__(256) void coef_kernel(
     constexpr int DN = sizeof(L) == 4 ? 32 : 16;           // diagonals per tile (LDS: DN * 64 records)
     __shared__ Cell<L> recs[DN][64];
     const int b = blockIdx.y;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = uniform(threadIdx.x >> 6);
     const int tu = static_cast<int>(blockIdx.x) % tilesU, tn = static_cast<int>(blockIdx.x) / tilesU;
     const int n0 = tn * DN, u0 = tu * 64;
     const int D = maxT + maxU - 1;

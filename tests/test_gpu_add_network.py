@@ -12,6 +12,7 @@ SHAPES = [  # N, T, U, A
     (2, 7, 4, 5), (3, 20, 9, 40), (2, 33, 21, 257), (1, 50, 130, 12), (2, 9, 300, 7), (1, 70, 3, 1000),
     (2, 40, 16, 64), (1, 1, 1, 9), (2, 5, 1, 33), (2, 1, 6, 31), (3, 65, 33, 100),
     (2, 40, 35, 2048), (1, 34, 5, 5000), (2, 31, 70, 1030),   # vocabulary split over 8 / 4 wavefronts of a tile
+    (2, 65, 34, 56), (2, 40, 70, 57), (3, 33, 33, 2), (2, 64, 64, 50),   # either side of the small-vocabulary Z kernel's limit
 ]
 
 
@@ -98,17 +99,21 @@ def test_peak_separation_sweep(oracle, sep):
     assert np.allclose(dg, ref_gz.sum(axis=1), rtol=1e-3, atol=1e-3)
 
 
-def test_large_logit_range_is_safe(oracle):
+@pytest.mark.parametrize("shape", [(1, 6, 4, 50), (1, 6, 70, 50), (1, 5, 1, 20)])   # cell / tiled coefficient kernel, U = 1
+def test_large_logit_range_is_safe(oracle, shape):
     """Rows whose best f column and best g column differ by 100+ nats: every cell is recomputed directly."""
-    f, g, labels, tl, ll, blank = problem((1, 6, 4, 50), 77)
+    f, g, labels, tl, ll, blank = problem(shape, 77)
     f[..., 3] += 120.0
-    g[..., 40] += 150.0
+    g[..., 40 % shape[3]] += 150.0
     z = f[:, :, None, :].astype(np.float64) + g[:, None, :, :].astype(np.float64)
     ref_c, ref_gz = oracle.rnnt_logits(z, labels, tl, ll, blank)
     costs, df, dg = run_add(f, g, labels, tl, ll, blank)
     assert np.isfinite(costs).all() and np.abs(costs - ref_c).max() <= 2e-4 * np.abs(ref_c).max()
-    assert np.allclose(df, ref_gz.sum(axis=2), rtol=1e-4, atol=5e-4)
-    assert np.allclose(dg, ref_gz.sum(axis=1), rtol=1e-4, atol=5e-4)
+    # logits of magnitude 270 carry an fp32 rounding of 3e-5 in every exponent: the peak column's entries
+    # (up to 65 here) come out 2e-5 .. 3e-4 relative from the fp64 oracle in every mode of the library
+    # (one-hot / atomics, tiled / cell coefficients give the same numbers) -- north_star's gradient bar, 1e-3
+    assert np.allclose(df, ref_gz.sum(axis=2), rtol=1e-3, atol=5e-4)
+    assert np.allclose(dg, ref_gz.sum(axis=1), rtol=1e-3, atol=5e-4)
 
 
 def test_per_sample_grad_output_is_folded_in(oracle):

@@ -242,20 +242,21 @@ template <typename C> static void launch_lattice(Plan<C>& p, bool with_beta) {
 template <typename C> static void launch_coef(Plan<C>& p, bool joint = false, bool onehot = false) {
     float* wmat = joint ? p.wmat : nullptr;
     const int Upad = joint_upad(p.maxU);
+    const int planes = onehot ? joint_planes_onehot(p.maxU) : 1;
     if (p.maxU <= 48 || !tune().ctile) {
         // small lattices: one thread per skewed cell, scattered record store
         const long long skew_cells = static_cast<long long>(p.maxT + p.maxU - 1) * p.Up;
         const dim3 cgrid(static_cast<unsigned>(((skew_cells + 255) / 256 + 7) / 8 * 8), p.N);   // multiple of 8: XCD-aware remap
         hipLaunchKernelGGL((coef_cell_kernel<C>), cgrid, dim3(256), 0, p.stream, p.lp2, p.logz, p.alpha, p.beta, p.offa,
                            p.offb, p.llf, p.labels, p.input_lengths, p.label_lengths, p.rowtab, p.maxT, p.maxU, p.Up,
-                           wmat, Upad, p.fastemit, onehot ? 3 : 1);
+                           wmat, Upad, p.fastemit, planes);
     } else {
         const int DN = sizeof(C) == 4 ? 32 : 16;           // diagonals per tile (coef_kernel)
         const int tilesU = (p.maxU + 63) / 64, tilesN = (p.maxT + p.maxU - 1 + DN - 1) / DN;
         const dim3 cgrid(static_cast<unsigned>(tilesU * tilesN), p.N);
         hipLaunchKernelGGL((coef_kernel<C>), cgrid, dim3(256), 0, p.stream, p.lp2, p.logz, p.alpha, p.beta, p.offa,
                            p.offb, p.llf, p.labels, p.input_lengths, p.label_lengths, p.rowtab, p.maxT, p.maxU, p.Up,
-                           wmat, Upad, tilesU, p.fastemit, onehot ? 3 : 1);
+                           wmat, Upad, tilesU, p.fastemit, planes);
     }
     p.check();
 }
@@ -455,7 +456,8 @@ static rnntStatus_t run_gpu_joint(const float* f, const float* g, float* df, flo
         p.check();
         hipLaunchKernelGGL(joint_fix_kernel, dim3((maxU + 63) / 64, (maxT + kJointFixT - 1) / kJointFixT, N),
                            dim3(256), 0, p.stream, f, g, p.rowmax, p.rowtab, labels, grad_scale, input_lengths,
-                           label_lengths, df, dg, maxT, maxU, A, p.blank, N, onehot ? 1 : 0);
+                           label_lengths, df, dg, maxT, maxU, A, p.blank, N, onehot ? 1 : 0,
+                           onehot && joint_planes_onehot(maxU) == 4 ? p.wmat : nullptr, Upad);
         p.check();
     }
     mark(4);

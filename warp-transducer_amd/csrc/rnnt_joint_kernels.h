@@ -814,7 +814,8 @@ __global__ __launch_bounds__(256) void joint_fix_kernel(
         const float* __restrict__ f, const float* __restrict__ g, const float* __restrict__ rowmax,
         const Cell<float>* __restrict__ rowtab, const int* __restrict__ labels,
         const float* __restrict__ scale, const int* __restrict__ xlen, const int* __restrict__ ylen,
-        float* __restrict__ df, float* __restrict__ dg, int maxT, int maxU, int A, int blank, int N, int skip_df) {
+        float* __restrict__ df, float* __restrict__ dg, int maxT, int maxU, int A, int blank, int N, int skip_df,
+        const float* __restrict__ planes, int Upad) {     // planes != nullptr: c / cb / cl come from the dense planes
     __shared__ float red[2][4][64];
     const int b = blockIdx.z;
     const int lane = threadIdx.x & 63, wave = uniform(threadIdx.x >> 6);
@@ -836,7 +837,17 @@ __global__ __launch_bounds__(256) void joint_fix_kernel(
     for (int t = tb0 + wave; t < tend; t += 4) {
         Cell<float> rec;
         rec.x = log_zero<float>(); rec.y = 0.0f; rec.z = 0.0f; rec.w = 0.0f;
-        if (uin) rec = rowtab[(static_cast<size_t>(b) * maxT + t) * maxU + u];
+        if (planes != nullptr) {                           // (coef kernels, planes == 4: no records were written)
+            if (uin) {
+                const size_t plane = static_cast<size_t>(N) * maxT * Upad;
+                const size_t at = (static_cast<size_t>(b) * maxT + t) * Upad + u;
+                rec.x = reinterpret_cast<const float*>(rowtab)[at];
+                rec.y = planes[plane + at];
+                rec.z = planes[2 * plane + at];
+            }
+        } else if (uin) {
+            rec = rowtab[(static_cast<size_t>(b) * maxT + t) * maxU + u];
+        }
         rec.y *= sc;
         rec.z *= sc;
         dgb += rec.y;

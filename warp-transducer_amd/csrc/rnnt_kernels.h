@@ -749,6 +749,9 @@ __global__ __launch_bounds__(MAXW * 64) void lattice_kernel(
 // Formulas: reference gpu_rnnt_kernel.h:161-174, docs/rnnt_notes.tex:138-145.  The sums are
 // formed in fp64 from the scaled fp32 lattice values and their fp64 offsets.
 constexpr int kPadded = -2;
+// One-hot df corrections (additive joint, small vocabularies): planes written by the coefficient kernels.
+// 4 = the plane of c replaces the records (it must fit their memory: ceil8(maxU) <= 4 maxU), else 3.
+__host__ __device__ inline int joint_planes_onehot(int maxU) { return joint_upad(maxU) <= 4 * maxU ? 4 : 3; }
 
 // The record of one lattice cell (b, t, u) on diagonal n = t + u (the caller guarantees that the cell is a
 // row of the tensor).  Padded cells: c = "log zero" (exp(x + c) = 0 for any x), no corrections, flagged.
@@ -817,7 +820,10 @@ __global__ __launch_bounds__(256) void coef_cell_kernel(
         const double* __restrict__ offb, const double* __restrict__ ll_fwd,
         const int* __restrict__ labels, const int* __restrict__ xlen, const int* __restrict__ ylen,
         Cell<L>* __restrict__ rowtab, int maxT, int maxU, int Up, float* __restrict__ wmat, int Upad, float fastemit,
-        int planes) {                      // planes: 1 = W only, 3 = W, CB, CL (one-hot df corrections)
+        int planes) {   // planes: 1 = W only; 3 = W, CB, CL (one-hot df corrections); 4 = W, CB, CL and a plane of c
+                        // that is written INTO the record table's memory (stride Upad <= 4 maxU floats) instead of
+                        // the records -- with the one-hot DF nothing reads cb / cl / label per record any more,
+                        // and 16 instead of 28 bytes leave per cell
     const int b = blockIdx.y;
     const unsigned per = gridDim.x >> 3;
     const unsigned blk = (blockIdx.x & 7u) * per + (blockIdx.x >> 3);
@@ -831,15 +837,16 @@ __global__ __launch_bounds__(256) void coef_cell_kernel(
     if (u >= maxU || t < 0 || t >= maxT) return;              // not a row of the tensor
     const Cell<L> o = coef_cell<L>(lp2, logz, alpha_arr, beta, offa, offb, ll_fwd, labels, b, n, t, u, xlen[b],
                                    ylen[b] + 1, maxT, maxU, Up, fastemit);
-    rowtab[(static_cast<size_t>(b) * maxT + t) * maxU + u] = o;
+    if (planes != 4) rowtab[(static_cast<size_t>(b) * maxT + t) * maxU + u] = o;
     if (wmat != nullptr) {                                    // additive joint only: W = exp(c), cb, cl; row stride Upad
         const float c = static_cast<float>(o.x);
         const size_t at = (static_cast<size_t>(b) * maxT + t) * Upad + u;
         wmat[at] = c > kJointFarC ? 0.0f : fast_exp(c);
-        if (planes == 3) { wmat[plane + at] = static_cast<float>(o.y); wmat[2 * plane + at] = static_cast<float>(o.z); }
+        if (planes >= 3) { wmat[plane + at] = static_cast<float>(o.y); wmat[2 * plane + at] = static_cast<float>(o.z); }
+        if (planes == 4) reinterpret_cast<float*>(rowtab)[at] = c;   // plane of c in place of the records
         if (u == maxU - 1)                                    // the row's pad columns [maxU, Upad) are zero
             for (int k = 1; k <= Upad - maxU; ++k)
-                for (int pl = 0; pl < planes; ++pl) wmat[pl * plane + at + k] = 0.0f;
+                for (int pl = 0; pl < (planes < 3 ? planes : 3); ++pl) wmat[pl * plane + at + k] = 0.0f;
     }
 }
 
@@ -896,15 +903,16 @@ __global__ __launch_bounds__(256) void coef_kernel(
         const int u = ulo + c;
         if (u > u0 + 63 || u >= maxU || t + u >= n0 + DN || t + u >= D) continue;
         const Cell<L> o = recs[t + u - n0][u - u0];
-        rowtab[(static_cast<size_t>(b) * maxT + t) * maxU + u] = o;
+        if (planes != 4) rowtab[(static_cast<size_t>(b) * maxT + t) * maxU + u] = o;
         if (wmat != nullptr) {                             // additive joint only: W = exp(c), cb, cl; row stride Upad
             const float cc = static_cast<float>(o.x);
             const size_t at = (static_cast<size_t>(b) * maxT + t) * Upad + u;
             wmat[at] = cc > kJointFarC ? 0.0f : fast_exp(cc);
-            if (planes == 3) { wmat[plane + at] = static_cast<float>(o.y); wmat[2 * plane + at] = static_cast<float>(o.z); }
+            if (planes >= 3) { wmat[plane + at] = static_cast<float>(o.y); wmat[2 * plane + at] = static_cast<float>(o.z); }
+            if (planes == 4) reinterpret_cast<float*>(rowtab)[at] = cc;   // plane of c in place of the records
             if (u == maxU - 1)                             // the row's pad columns [maxU, Upad) are zero
                 for (int k = 1; k <= Upad - maxU; ++k)
-                    for (int pl = 0; pl < planes; ++pl) wmat[pl * plane + at + k] = 0.0f;
+                    for (int pl = 0; pl < (planes < 3 ? planes : 3); ++pl) wmat[pl * plane + at + k] = 0.0f;
         }
     }
 }

@@ -61,13 +61,16 @@ def make_inputs(w, dev, seed):
     return acts, labels, act_lens, label_lens
 
 
-def algorithmic_bytes(w, valid_rows=None):
+def algorithmic_bytes(w, valid_rows=None, packed=False):
     """acts read twice, grads written once, plus the fp32 lattice side arrays.
     With variable lengths only the valid (t < T_b, u < U_b) rows have to be READ; every row of
-    the gradient tensor is still written (zeros in the padding)."""
+    the gradient tensor is still written (zeros in the padding) -- unless the layout is packed,
+    where the padding does not exist."""
     N, T, U, A, s = w["N"], w["T"], w["L"] + 1, w["A"], ESIZE[w["dtype"]]
     R = N * T * U
     Rv = R if valid_rows is None else valid_rows
+    if packed:
+        R = Rv
     E, Ev = R * A, Rv * A
     return dict(E=E, R=R, path=2 * Ev * s + E * s + 48 * Rv, grad_kernel=Ev * s + E * s + 16 * R,
                 stats_kernel=Ev * s + 16 * Rv)
@@ -113,6 +116,9 @@ def main():
     ap.add_argument("--override", default="", help="dev: override workload fields, e.g. A=4992,N=64")
     ap.add_argument("--varlen", action="store_true",
                     help="robustness run: T_b ~ U[T/2,T], L_b ~ U[L/2,L] (seed 2, maxima forced), SURVEY.md 8d")
+    ap.add_argument("--packed", action="store_true",
+                    help="with --varlen: the same batch in the PACKED layout (compute_rnnt_loss_packed: no padded "
+                         "rows in the tensors at all); single GPU")
     ap.add_argument("--force-sharded", action="store_true",
                     help="dev: run the multi-GPU step (async entry + RCCL all-reduce) even with one rank")
     args = ap.parse_args()
@@ -149,13 +155,34 @@ def main():
             act_lens = torch.randint(T // 2, T + 1, (N,), generator=g2, device=dev, dtype=torch.int32)
             label_lens = torch.randint((U - 1) // 2, U, (N,), generator=g2, device=dev, dtype=torch.int32)
             act_lens[0], label_lens[0] = T, U - 1
+        offs = None
+        if args.packed:
+            from warprnnt_pytorch.packed import pack_joint, row_offsets
+            assert args.varlen and not sharded, "--packed goes with --varlen on one GPU"
+            acts_padded = acts
+            acts = pack_joint(acts_padded, act_lens, label_lens).contiguous()
+            del acts_padded
+            torch.cuda.empty_cache()
+            offs = row_offsets(act_lens, label_lens)
         grads = torch.empty_like(acts)
         esz = ESIZE[w["dtype"]]
         ws = torch.empty(_lib.workspace_bytes(T, U, N, True, esz), dtype=torch.uint8, device=dev)
         stream = torch.cuda.current_stream(dev).cuda_stream
         opt = _lib.rnntOptions(loc=_lib.RNNT_GPU, num_threads=0, stream=stream, blank_label=0, maxT=T,
                                maxU=U, batch_first=True)
-        if not sharded:
+        if args.packed:
+            costs = torch.zeros(N, dtype=torch.float32, device=dev)
+            code = {"fp32": _lib.DT_F32, "bf16": _lib.DT_BF16}[w["dtype"]]
+            argv = (acts.data_ptr(), grads.data_ptr(), labels.data_ptr(), label_lens.data_ptr(), act_lens.data_ptr(),
+                    offs.data_ptr(), acts.shape[0], A, N, costs.data_ptr(), None, ws.data_ptr(), opt, code, 0.0)
+
+            def step():
+                st = lib.compute_rnnt_loss_packed(*argv)
+                assert st == 0, _lib.status_string(st)
+                torch.cuda.synchronize(dev)
+                lib.rnnt_profile_collect()
+                return costs
+        elif not sharded:
             # the drop-in C-ABI call: host costs, one stream sync per call
             fn = {"fp32": lib.compute_rnnt_loss, "bf16": lib.compute_rnnt_loss_bf16}[w["dtype"]]
             costs = torch.zeros(N, dtype=torch.float32)
@@ -207,10 +234,10 @@ def main():
         calls = lib.rnnt_profile_read(stage, 5)
         stage_ms = [stage[i] / calls for i in range(5)] if calls else None
         valid_rows = int((act_lens.long() * (label_lens.long() + 1)).sum().item()) if args.varlen else None
-        ab = algorithmic_bytes(w, valid_rows)
+        ab = algorithmic_bytes(w, valid_rows, args.packed)
         res = dict(workload=name, ms_per_step=ms_step, stage_ms=stage_ms, bytes=ab, w=w,
                    loss_sum=float(out.sum()) if not sharded else float(out[0]))
-        if with_cpu and rank == 0:
+        if with_cpu and rank == 0 and not args.packed:
             res["cpu"] = cpu_baseline(w, acts, labels, act_lens, label_lens, args.cpu_samples)
         del acts, grads, ws
         torch.cuda.empty_cache()
@@ -228,7 +255,8 @@ def main():
         "dtype": {"fp32": "f32", "bf16": "bf16"}[w["dtype"]], "data": "synthetic",
         "config": {"workload": "%s: N=%d/GPU T=%d U=%d(L=%d) A=%d %s, loss+grad via compute_rnnt_loss%s"
                                % (args.workload, w["N"], w["T"], U, w["L"], w["A"], w["dtype"],
-                                  ", VARIABLE lengths T_b~U[T/2,T] L_b~U[L/2,L]" if args.varlen else ""),
+                                  (", VARIABLE lengths T_b~U[T/2,T] L_b~U[L/2,L]" if args.varlen else "")
+                                  + (", PACKED layout (compute_rnnt_loss_packed)" if args.packed else "")),
                    "global_batch": w["N"] * world, "per_gpu_batch": w["N"],
                    "parallelism": "batch-sharded x%d, one RCCL all-reduce of the summed loss" % world
                    if world > 1 else "single GPU"},

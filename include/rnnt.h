@@ -239,6 +239,60 @@ rnntStatus_t compute_rnnt_loss_fwd_fastemit(const void* activations,
                                             int prepare_backward,
                                             float fastemit_lambda);
 
+/* PACKED ("compact") activations (variable-length compaction).  The reference pads every
+ * sample to (maxT, maxU) and its gradient kernel writes zeros over the padding
+ * (include/detail/gpu_rnnt_kernel.h:159); here sample b is only its T_b x U_b real rows, stored back to back:
+ *   activations / gradients : (total_rows, alphabet_size), total_rows = sum_b T_b * U_b,  U_b = label_lengths[b] + 1
+ *   row (b, t, u)           : row_offsets[b] + t * U_b + u
+ *   row_offsets             : DEVICE int64[minibatch + 1], row_offsets[0] = 0, row_offsets[b+1] = row_offsets[b] + T_b * U_b
+ *   total_rows              : the same total on the HOST (grid sizes)
+ * Labels, lengths, options.maxT / maxU (the maxima over the batch: lattice and workspace are sized by them, the
+ * workspace query is unchanged), costs, grad_scale, dtype codes, stream semantics and FastEmit are as for
+ * compute_rnnt_loss_async / _fwd / _bwd / _fastemit.  No byte of padding is read or written.  Both tensors must
+ * be 16-byte aligned when gradients are requested (INVALID_VALUE otherwise); total_rows must be in
+ * (0, minibatch * maxT * maxU].  GPU only. */
+rnntStatus_t compute_rnnt_loss_packed(const void* activations,
+                                      void* gradients,
+                                      const int* const flat_labels,
+                                      const int* const label_lengths,
+                                      const int* const input_lengths,
+                                      const long long* const row_offsets,
+                                      long long total_rows,
+                                      int alphabet_size,
+                                      int minibatch,
+                                      void* costs_device,
+                                      const void* grad_scale_device,
+                                      void* workspace,
+                                      rnntOptions options,
+                                      int dtype_code,
+                                      float fastemit_lambda);
+
+rnntStatus_t compute_rnnt_loss_packed_fwd(const void* activations,
+                                          const int* const flat_labels,
+                                          const int* const label_lengths,
+                                          const int* const input_lengths,
+                                          const long long* const row_offsets,
+                                          long long total_rows,
+                                          int alphabet_size,
+                                          int minibatch,
+                                          void* costs_device,
+                                          void* workspace,
+                                          rnntOptions options,
+                                          int dtype_code,
+                                          int prepare_backward,
+                                          float fastemit_lambda);
+
+rnntStatus_t compute_rnnt_loss_packed_bwd(const void* activations,
+                                          void* gradients,
+                                          const void* grad_scale_device,
+                                          const long long* const row_offsets,
+                                          long long total_rows,
+                                          int alphabet_size,
+                                          int minibatch,
+                                          void* workspace,
+                                          rnntOptions options,
+                                          int dtype_code);
+
 /* Additive joint ("add network", the reference's add_network branch: README.md:4,
  * docs/rnnt_notes.tex:56-59,147-153, pytorch_binding/test/test_time.py:51-77).  The joint logits
  * are h(k,t,u) = trans_acts[b,t,k] + pred_acts[b,u,k]; the (B,T,U,V) tensor is never formed.

@@ -12,7 +12,7 @@ template <int G> void run(const float* acts, int* labels, int* xlen, int* ylen, 
     const int RT = 256 / G; const size_t lds = (size_t)RT * A * 4 + 32;
     if (lds > 64 * 1024) { printf("G=%d: tile too large\n", G); return; }
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    auto launch = [&] { hipLaunchKernelGGL((row_stats_tile_kernel<F32, G>), dim3(((R + RT - 1) / RT + 7) / 8 * 8), dim3(256), lds, 0, acts, labels, xlen, ylen, lp2, logz, R, T, U, Up, A, 0, xcd); };
+    auto launch = [&] { hipLaunchKernelGGL((row_stats_tile_kernel<F32, G>), dim3(((R + RT - 1) / RT + 7) / 8 * 8), dim3(256), lds, 0, acts, labels, xlen, ylen, lp2, logz, R, T, U, Up, A, 0, xcd, nullptr, 64); };
     for (int i = 0; i < 2; ++i) launch();
     CK(hipDeviceSynchronize()); CK(hipEventRecord(e0));
     for (int i = 0; i < 5; ++i) launch();

@@ -130,6 +130,8 @@ template <typename C> struct Plan {
     double *offa, *offb, *llf, *llb;
     float *rowmax, *wmat;
     float fastemit = 0.0f;         // FastEmit lambda (extension entries only)
+    const long long* offsets = nullptr;        // packed layout: cumulative row offsets (device, N+1 entries) ...
+    unsigned long long packed_rows = 0;        // ... and the total number of rows (host)
     C* costs_dev;
     bool failed = false;
     void check() { if (hipGetLastError() != hipSuccess) failed = true; }
@@ -177,14 +179,15 @@ static void launch_row_stats(Plan<typename Tag::comp>& p, const typename Tag::st
         while (G < 64 && (256 / G) * row_bytes + 32 > budget) G *= 2;
         const int RT = 256 / G;
         const size_t lds = RT * row_bytes + 32;
-        const unsigned long long Rall = static_cast<unsigned long long>(p.N) * p.cells_per_sample;
+        const unsigned long long Rall = p.offsets != nullptr ? p.packed_rows
+                                                             : static_cast<unsigned long long>(p.N) * p.cells_per_sample;
         const unsigned tgrid = static_cast<unsigned>((Rall + RT - 1) / RT);
         if (lds <= 64 * 1024) {
             const unsigned xgrid = tn.xcd ? (tgrid + 7u) / 8u * 8u : tgrid;   // XCD remap wants a multiple of 8
 #define RNNT_TILE(GG)                                                                                       \
     hipLaunchKernelGGL((row_stats_tile_kernel<Tag, GG>), dim3(xgrid), dim3(256), lds, p.stream, acts, p.labels, \
                        p.input_lengths, p.label_lengths, p.lp2, p.logz, Rall, p.maxT, p.maxU, p.Up,           \
-                       p.A, p.blank, tn.xcd)
+                       p.A, p.blank, tn.xcd, p.offsets, p.N)
             switch (G) {
                 case 1: RNNT_TILE(1); break;
                 case 2: RNNT_TILE(2); break;
@@ -206,10 +209,12 @@ static void launch_row_stats(Plan<typename Tag::comp>& p, const typename Tag::st
         const dim3 bgrid(p.cells_per_sample, p.N);
         if (tn.nta)
             hipLaunchKernelGGL((row_stats_block_kernel<Tag, true, 4>), bgrid, dim3(256), 0, p.stream, acts, p.labels,
-                               p.input_lengths, p.label_lengths, p.lp2, p.logz, p.maxT, p.maxU, p.Up, p.A, p.blank, vec_ok);
+                               p.input_lengths, p.label_lengths, p.lp2, p.logz, p.maxT, p.maxU, p.Up, p.A, p.blank, vec_ok,
+                               p.offsets);
         else
             hipLaunchKernelGGL((row_stats_block_kernel<Tag, false, 4>), bgrid, dim3(256), 0, p.stream, acts, p.labels,
-                               p.input_lengths, p.label_lengths, p.lp2, p.logz, p.maxT, p.maxU, p.Up, p.A, p.blank, vec_ok);
+                               p.input_lengths, p.label_lengths, p.lp2, p.logz, p.maxT, p.maxU, p.Up, p.A, p.blank, vec_ok,
+                               p.offsets);
         p.check();
         return;
     }
@@ -217,7 +222,7 @@ static void launch_row_stats(Plan<typename Tag::comp>& p, const typename Tag::st
 #define RNNT_STATS(WV, NT)                                                                                       \
     hipLaunchKernelGGL((row_stats_kernel<Tag, WV, NT>), dim3((p.cells_per_sample + WV - 1) / WV, p.N), dim3(WV * 64), \
                        0, p.stream, acts, p.labels, p.input_lengths, p.label_lengths, p.lp2, p.logz, p.maxT, p.maxU, \
-                       p.Up, p.A, p.blank, vec_ok)
+                       p.Up, p.A, p.blank, vec_ok, p.offsets)
     if (tn.nta) { if (tn.sw == 8) RNNT_STATS(8, true); else if (tn.sw == 2) RNNT_STATS(2, true); else RNNT_STATS(4, true); }
     else { if (tn.sw == 8) RNNT_STATS(8, false); else if (tn.sw == 2) RNNT_STATS(2, false); else RNNT_STATS(4, false); }
 #undef RNNT_STATS
@@ -249,14 +254,14 @@ template <typename C> static void launch_coef(Plan<C>& p, bool joint = false, bo
         const dim3 cgrid(static_cast<unsigned>(((skew_cells + 255) / 256 + 7) / 8 * 8), p.N);   // multiple of 8: XCD-aware remap
         hipLaunchKernelGGL((coef_cell_kernel<C>), cgrid, dim3(256), 0, p.stream, p.lp2, p.logz, p.alpha, p.beta, p.offa,
                            p.offb, p.llf, p.labels, p.input_lengths, p.label_lengths, p.rowtab, p.maxT, p.maxU, p.Up,
-                           wmat, Upad, p.fastemit, planes);
+                           wmat, Upad, p.fastemit, planes, p.offsets);
     } else {
         const int DN = sizeof(C) == 4 ? 32 : 16;           // diagonals per tile (coef_kernel)
         const int tilesU = (p.maxU + 63) / 64, tilesN = (p.maxT + p.maxU - 1 + DN - 1) / DN;
         const dim3 cgrid(static_cast<unsigned>(tilesU * tilesN), p.N);
         hipLaunchKernelGGL((coef_kernel<C>), cgrid, dim3(256), 0, p.stream, p.lp2, p.logz, p.alpha, p.beta, p.offa,
                            p.offb, p.llf, p.labels, p.input_lengths, p.label_lengths, p.rowtab, p.maxT, p.maxU, p.Up,
-                           wmat, Upad, tilesU, p.fastemit, planes);
+                           wmat, Upad, tilesU, p.fastemit, planes, p.offsets);
     }
     p.check();
 }
@@ -270,9 +275,11 @@ static void launch_grad(Plan<typename Tag::comp>& p, const typename Tag::store* 
     const Tune& tn = tune();
     const uintptr_t pa = reinterpret_cast<uintptr_t>(acts), pg = reinterpret_cast<uintptr_t>(grads);
     const size_t row_bytes = static_cast<size_t>(p.A) * sizeof(S);
-    const unsigned long long R = static_cast<unsigned long long>(p.N) * p.cells_per_sample;
+    const bool packed = p.offsets != nullptr;
+    const unsigned long long R = packed ? p.packed_rows : static_cast<unsigned long long>(p.N) * p.cells_per_sample;
     const unsigned long long E = R * p.A;
-    const bool flat_ok = vec_ok && (pa & 15u) == 0 && (pg & 15u) == 0 && p.A <= (1 << 23) && !tn.rows;
+    const bool flat_ok = vec_ok && (pa & 15u) == 0 && (pg & 15u) == 0 && p.A <= (1 << 23) && (!tn.rows || packed);
+    if (packed && !flat_ok) { p.failed = true; return; }   // (run_gpu has validated the alignment: not reached)
     if (flat_ok) {
         const unsigned long long npk = E / V;
         const int ppt = (tn.ppt == 1 || tn.ppt == 4) ? tn.ppt : 2;
@@ -286,8 +293,8 @@ static void launch_grad(Plan<typename Tag::comp>& p, const typename Tag::store* 
         const float invA = 1.0f / static_cast<float>(p.A);
 #define RNNT_FLAT(SC, PP, PS)                                                                                       \
     hipLaunchKernelGGL((grad_flat_kernel<Tag, SC, PP, PS>), dim3(grid), dim3(256), 0, p.stream, acts, grads, p.rowtab, \
-                       grad_scale, E, R, p.A, p.blank, p.cells_per_sample, invA, dq, drem)
-        const bool padskip = tn.pskip && row_bytes >= 8192;     // skip reading padded rows only where rows are long
+                       grad_scale, E, R, p.A, p.blank, p.cells_per_sample, invA, dq, drem, p.offsets, p.N)
+        const bool padskip = tn.pskip && row_bytes >= 8192 && !packed;   // skip reading padded rows only where rows are long
         if (grad_scale) { if (padskip) RNNT_FLAT(true, 2, true); else RNNT_FLAT(true, 2, false); }
         else if (ppt == 1) RNNT_FLAT(false, 1, false);
         else if (ppt == 4) RNNT_FLAT(false, 4, false);
@@ -316,7 +323,7 @@ static rnntStatus_t run_gpu(const typename Tag::store* acts, typename Tag::store
                             int A, int N, typename Tag::comp* costs_host,
                             typename Tag::comp* costs_device_out, const typename Tag::comp* grad_scale,
                             void* workspace, const rnntOptions& opt, int phases = 3, int want_grad = -1,
-                            float fastemit = 0.0f) {
+                            float fastemit = 0.0f, const long long* offsets = nullptr, long long packed_rows = 0) {
     using S = typename Tag::store;
     using C = typename Tag::comp;
     Plan<C> p;
@@ -324,6 +331,14 @@ static rnntStatus_t run_gpu(const typename Tag::store* acts, typename Tag::store
         return RNNT_STATUS_INVALID_VALUE;
     if (!(fastemit >= 0.0f)) return RNNT_STATUS_INVALID_VALUE;
     p.fastemit = fastemit;
+    if (offsets != nullptr) {
+        // packed layout: the record table is sized for N*maxT*maxU rows, the packed tensor cannot have more
+        if (packed_rows <= 0 || static_cast<unsigned long long>(packed_rows) >
+                                    static_cast<unsigned long long>(N) * p.cells_per_sample)
+            return RNNT_STATUS_INVALID_VALUE;
+        p.offsets = offsets;
+        p.packed_rows = static_cast<unsigned long long>(packed_rows);
+    }
     const bool training = want_grad < 0 ? grads != nullptr : want_grad != 0;
     const bool do_fwd = (phases & 1) != 0, do_bwd = (phases & 2) != 0 && training;
     if (do_bwd && grads == nullptr) return RNNT_STATUS_INVALID_VALUE;
@@ -332,6 +347,9 @@ static rnntStatus_t run_gpu(const typename Tag::store* acts, typename Tag::store
     const uintptr_t pa = reinterpret_cast<uintptr_t>(acts), pg = reinterpret_cast<uintptr_t>(grads);
     int vec_ok = (pa % sizeof(S) == 0) ? 1 : 0;
     if (grads != nullptr && ((pa ^ pg) & 15u)) vec_ok = 0;
+    // the packed layout has only the flat gradient kernel: both tensors 16-byte aligned
+    if (p.offsets != nullptr && do_bwd && (!vec_ok || (pa & 15u) || (pg & 15u) || A > (1 << 23)))
+        return RNNT_STATUS_INVALID_VALUE;
 
     const bool prof = prof_prepare();
     auto mark = [&](int i) { if (prof) (void)hipEventRecord(g_prof.ev[i], p.stream); };
@@ -562,24 +580,24 @@ rnntStatus_t compute_rnnt_loss_fp16(const uint16_t* const activations, uint16_t*
 static rnntStatus_t run_async(const void* acts, void* grads, const int* labels, const int* label_lengths,
                               const int* input_lengths, int A, int N, void* costs_device, const void* scale,
                               void* workspace, const rnntOptions& o, int dtype_code, int phases, int want_grad,
-                              float fastemit = 0.0f) {
+                              float fastemit = 0.0f, const long long* offsets = nullptr, long long packed_rows = 0) {
     switch (dtype_code) {
         case 0:
             return run_gpu<F32>(static_cast<const float*>(acts), static_cast<float*>(grads), labels, label_lengths,
                                 input_lengths, A, N, nullptr, static_cast<float*>(costs_device),
-                                static_cast<const float*>(scale), workspace, o, phases, want_grad, fastemit);
+                                static_cast<const float*>(scale), workspace, o, phases, want_grad, fastemit, offsets, packed_rows);
         case 1:
             return run_gpu<F64>(static_cast<const double*>(acts), static_cast<double*>(grads), labels, label_lengths,
                                 input_lengths, A, N, nullptr, static_cast<double*>(costs_device),
-                                static_cast<const double*>(scale), workspace, o, phases, want_grad, fastemit);
+                                static_cast<const double*>(scale), workspace, o, phases, want_grad, fastemit, offsets, packed_rows);
         case 2:
             return run_gpu<BF16>(static_cast<const uint16_t*>(acts), static_cast<uint16_t*>(grads), labels,
                                  label_lengths, input_lengths, A, N, nullptr, static_cast<float*>(costs_device),
-                                 static_cast<const float*>(scale), workspace, o, phases, want_grad, fastemit);
+                                 static_cast<const float*>(scale), workspace, o, phases, want_grad, fastemit, offsets, packed_rows);
         case 3:
             return run_gpu<F16>(static_cast<const uint16_t*>(acts), static_cast<uint16_t*>(grads), labels,
                                 label_lengths, input_lengths, A, N, nullptr, static_cast<float*>(costs_device),
-                                static_cast<const float*>(scale), workspace, o, phases, want_grad, fastemit);
+                                static_cast<const float*>(scale), workspace, o, phases, want_grad, fastemit, offsets, packed_rows);
         default: return RNNT_STATUS_INVALID_VALUE;
     }
 }
@@ -640,6 +658,44 @@ rnntStatus_t compute_rnnt_loss_fwd_fastemit(const void* activations, const int* 
     return run_async(activations, nullptr, flat_labels, label_lengths, input_lengths, alphabet_size, minibatch,
                      costs_device, nullptr, workspace, options, dtype_code, 1, prepare_backward != 0 ? 1 : 0,
                      fastemit_lambda);
+}
+
+rnntStatus_t compute_rnnt_loss_packed(const void* activations, void* gradients, const int* const flat_labels,
+                                      const int* const label_lengths, const int* const input_lengths,
+                                      const long long* const row_offsets, long long total_rows, int alphabet_size,
+                                      int minibatch, void* costs_device, const void* grad_scale_device,
+                                      void* workspace, rnntOptions options, int dtype_code, float fastemit_lambda) {
+    if (bad_args(activations, flat_labels, label_lengths, input_lengths, costs_device, workspace,
+                 alphabet_size, minibatch, options) || row_offsets == nullptr || options.loc != RNNT_GPU)
+        return RNNT_STATUS_INVALID_VALUE;
+    return run_async(activations, gradients, flat_labels, label_lengths, input_lengths, alphabet_size, minibatch,
+                     costs_device, grad_scale_device, workspace, options, dtype_code, 3, -1, fastemit_lambda,
+                     row_offsets, total_rows);
+}
+
+rnntStatus_t compute_rnnt_loss_packed_fwd(const void* activations, const int* const flat_labels,
+                                          const int* const label_lengths, const int* const input_lengths,
+                                          const long long* const row_offsets, long long total_rows,
+                                          int alphabet_size, int minibatch, void* costs_device, void* workspace,
+                                          rnntOptions options, int dtype_code, int prepare_backward,
+                                          float fastemit_lambda) {
+    if (bad_args(activations, flat_labels, label_lengths, input_lengths, costs_device, workspace,
+                 alphabet_size, minibatch, options) || row_offsets == nullptr || options.loc != RNNT_GPU)
+        return RNNT_STATUS_INVALID_VALUE;
+    return run_async(activations, nullptr, flat_labels, label_lengths, input_lengths, alphabet_size, minibatch,
+                     costs_device, nullptr, workspace, options, dtype_code, 1, prepare_backward != 0 ? 1 : 0,
+                     fastemit_lambda, row_offsets, total_rows);
+}
+
+rnntStatus_t compute_rnnt_loss_packed_bwd(const void* activations, void* gradients, const void* grad_scale_device,
+                                          const long long* const row_offsets, long long total_rows,
+                                          int alphabet_size, int minibatch, void* workspace, rnntOptions options,
+                                          int dtype_code) {
+    if (activations == nullptr || gradients == nullptr || row_offsets == nullptr || workspace == nullptr ||
+        alphabet_size <= 0 || minibatch <= 0 || options.maxT <= 0 || options.maxU <= 0 || options.loc != RNNT_GPU)
+        return RNNT_STATUS_INVALID_VALUE;
+    return run_async(activations, gradients, nullptr, nullptr, nullptr, alphabet_size, minibatch, nullptr,
+                     grad_scale_device, workspace, options, dtype_code, 2, 1, 0.0f, row_offsets, total_rows);
 }
 
 rnntStatus_t compute_rnnt_loss_add(const float* const trans_acts, const float* const pred_acts,

@@ -100,7 +100,7 @@ __global__ __launch_bounds__(WAVES * 64) void row_stats_kernel(
         const typename Tag::store* __restrict__ acts, const int* __restrict__ labels,
         const int* __restrict__ xlen, const int* __restrict__ ylen,
         LogPair<typename Tag::comp>* __restrict__ lp2, typename Tag::comp* __restrict__ logz,
-        int maxT, int maxU, int Up, int A, int blank, int vec_ok) {
+        int maxT, int maxU, int Up, int A, int blank, int vec_ok, const long long* __restrict__ offsets) {
     using S = typename Tag::store;
     using C = typename Tag::comp;
     constexpr int V = Vec<Tag>::N;
@@ -108,11 +108,17 @@ __global__ __launch_bounds__(WAVES * 64) void row_stats_kernel(
     const int lane = threadIdx.x & 63;
     const int q = uniform(blockIdx.x * WAVES + (threadIdx.x >> 6));
     if (q >= maxT * maxU) return;
-    const int t = q / maxU, u = q - t * maxU;
     const int Tb = xlen[b], Ub = ylen[b] + 1;
+    if (Tb <= 0 || Ub <= 0) return;
+    // packed layout (offsets != nullptr, include/rnnt.h compute_rnnt_loss_packed): sample b is T_b * U_b
+    // consecutive rows starting at row offsets[b], row (t, u) at t * U_b + u -- no padded rows exist
+    const int ustride = offsets != nullptr ? Ub : maxU;
+    const int t = q / ustride, u = q - t * ustride;
     if (t >= Tb || u >= Ub) return;   // padded cell: never read
 
-    const S* row = acts + (static_cast<size_t>(b) * maxT * maxU + q) * A;
+    const size_t rix = offsets != nullptr ? static_cast<size_t>(offsets[b]) + q
+                                          : static_cast<size_t>(b) * maxT * maxU + q;
+    const S* row = acts + rix * A;
     const bool has_lab = u < Ub - 1;
     int lab = blank;
     if (has_lab) {
@@ -179,7 +185,7 @@ __global__ __launch_bounds__(256) void row_stats_block_kernel(
         const typename Tag::store* __restrict__ acts, const int* __restrict__ labels,
         const int* __restrict__ xlen, const int* __restrict__ ylen,
         LogPair<typename Tag::comp>* __restrict__ lp2, typename Tag::comp* __restrict__ logz,
-        int maxT, int maxU, int Up, int A, int blank, int vec_ok) {
+        int maxT, int maxU, int Up, int A, int blank, int vec_ok, const long long* __restrict__ offsets) {
     using S = typename Tag::store;
     using C = typename Tag::comp;
     constexpr int V = Vec<Tag>::N;
@@ -187,11 +193,15 @@ __global__ __launch_bounds__(256) void row_stats_block_kernel(
     const int b = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int q = blockIdx.x;
-    const int t = q / maxU, u = q - t * maxU;
     const int Tb = xlen[b], Ub = ylen[b] + 1;
+    if (Tb <= 0 || Ub <= 0) return;
+    const int ustride = offsets != nullptr ? Ub : maxU;      // packed layout: see row_stats_kernel
+    const int t = q / ustride, u = q - t * ustride;
     if (t >= Tb || u >= Ub) return;   // padded cell: never read (block-uniform)
 
-    const S* row = acts + (static_cast<size_t>(b) * maxT * maxU + q) * A;
+    const size_t rix = offsets != nullptr ? static_cast<size_t>(offsets[b]) + q
+                                          : static_cast<size_t>(b) * maxT * maxU + q;
+    const S* row = acts + rix * A;
     int head, nvec, tail0;
     row_split<S>(reinterpret_cast<uintptr_t>(row), A, vec_ok != 0, head, nvec, tail0);
 
@@ -330,7 +340,8 @@ __global__ __launch_bounds__(256) void row_stats_tile_kernel(
         const typename Tag::store* __restrict__ acts, const int* __restrict__ labels,
         const int* __restrict__ xlen, const int* __restrict__ ylen,
         LogPair<typename Tag::comp>* __restrict__ lp2, typename Tag::comp* __restrict__ logz,
-        unsigned long long R, int maxT, int maxU, int Up, int A, int blank, int xcd_remap) {
+        unsigned long long R, int maxT, int maxU, int Up, int A, int blank, int xcd_remap,
+        const long long* __restrict__ offsets, int N) {    // offsets != nullptr: packed layout, R = offsets[N] rows
     using S = typename Tag::store;
     using C = typename Tag::comp;
     constexpr int V = Vec<Tag>::N;
@@ -378,16 +389,47 @@ __global__ __launch_bounds__(256) void row_stats_tile_kernel(
     // they have long arrived when the epilogue needs them.  Done at the end, as two dependent global
     // latencies, they held the block's LDS tile for 2.6 us of its 8.7 us life (c4).
     const int rl = threadIdx.x / G, j = threadIdx.x % G;
-    const unsigned TU = static_cast<unsigned>(maxT) * maxU;
-    const unsigned long long b0 = r0 / TU;                 // block-uniform
-    unsigned q = static_cast<unsigned>(r0 - b0 * TU) + static_cast<unsigned>(rl);
-    int b = static_cast<int>(b0);
-    while (q >= TU) { q -= TU; ++b; }
-    const int nb = static_cast<int>(R / TU);
-    b = b < nb ? b : nb - 1;                               // lanes past the last row: any valid sample
-    const int t = static_cast<int>(q / static_cast<unsigned>(maxU));
-    const int u = static_cast<int>(q) - t * maxU;
-    const int Tb = xlen[b], Ub = ylen[b] + 1;
+    int b, t, u, Tb, Ub;
+    if (offsets == nullptr) {
+        const unsigned TU = static_cast<unsigned>(maxT) * maxU;
+        const unsigned long long b0 = r0 / TU;             // block-uniform
+        unsigned q = static_cast<unsigned>(r0 - b0 * TU) + static_cast<unsigned>(rl);
+        b = static_cast<int>(b0);
+        while (q >= TU) { q -= TU; ++b; }
+        const int nb = static_cast<int>(R / TU);
+        b = b < nb ? b : nb - 1;                           // lanes past the last row: any valid sample
+        t = static_cast<int>(q / static_cast<unsigned>(maxU));
+        u = static_cast<int>(q) - t * maxU;
+        Tb = xlen[b]; Ub = ylen[b] + 1;
+    } else {
+        // Packed layout: the sample of the tile's first row by a block-uniform (scalar) binary search over the
+        // cumulative row offsets, its neighbour's data as scalars too; a lane's row is in one of the two unless
+        // the tile spans three or more samples (tiny samples), which takes the per-lane search.
+        int lo = 0, hi = N;                                // offsets[lo] <= r0 < offsets[hi]
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (r0 >= static_cast<unsigned long long>(offsets[mid])) lo = mid; else hi = mid;
+        }
+        const int b1 = lo + 1 < N ? lo + 1 : lo;
+        const unsigned long long o0 = static_cast<unsigned long long>(offsets[lo]);
+        const unsigned long long o1 = static_cast<unsigned long long>(offsets[lo + 1]);
+        const int T0 = xlen[lo], U0 = ylen[lo] + 1, T1 = xlen[b1], U1 = ylen[b1] + 1;
+        const unsigned long long r = r0 + static_cast<unsigned>(rl);
+        unsigned long long ob = o0;
+        b = lo; Tb = T0; Ub = U0;
+        if (r >= o1 && lo + 1 < N) {
+            b = b1; Tb = T1; Ub = U1; ob = o1;
+            if (b + 1 < N && r >= static_cast<unsigned long long>(offsets[b + 1])) {
+                while (b + 1 < N && r >= static_cast<unsigned long long>(offsets[b + 1])) ++b;
+                ob = static_cast<unsigned long long>(offsets[b]);
+                Tb = xlen[b]; Ub = ylen[b] + 1;
+            }
+        }
+        const unsigned q = static_cast<unsigned>(r - ob);  // rows past the end: t >= Tb, never stored
+        const unsigned us = Ub > 0 ? static_cast<unsigned>(Ub) : 1u;
+        t = static_cast<int>(q / us);
+        u = static_cast<int>(q - static_cast<unsigned>(t) * us);
+    }
     int lab = labels[maxU > 1 ? static_cast<size_t>(b) * (maxU - 1) + (u < maxU - 1 ? u : maxU - 2) : 0];
     if (!(RNNT_TILE_ABLATE & 2)) {
         uint4* dst = tile_raw + (phase + head) / V;
@@ -820,7 +862,7 @@ __global__ __launch_bounds__(256) void coef_cell_kernel(
         const double* __restrict__ offb, const double* __restrict__ ll_fwd,
         const int* __restrict__ labels, const int* __restrict__ xlen, const int* __restrict__ ylen,
         Cell<L>* __restrict__ rowtab, int maxT, int maxU, int Up, float* __restrict__ wmat, int Upad, float fastemit,
-        int planes) {   // planes: 1 = W only; 3 = W, CB, CL (one-hot df corrections); 4 = W, CB, CL and a plane of c
+        int planes, const long long* __restrict__ offsets) {   // offsets: packed row order (see row_stats_kernel)   // planes: 1 = W only; 3 = W, CB, CL (one-hot df corrections); 4 = W, CB, CL and a plane of c
                         // that is written INTO the record table's memory (stride Upad <= 4 maxU floats) instead of
                         // the records -- with the one-hot DF nothing reads cb / cl / label per record any more,
                         // and 16 instead of 28 bytes leave per cell
@@ -835,9 +877,14 @@ __global__ __launch_bounds__(256) void coef_cell_kernel(
     const int t = n - u;
     const size_t plane = static_cast<size_t>(gridDim.y) * maxT * Upad;      // gridDim.y = N
     if (u >= maxU || t < 0 || t >= maxT) return;              // not a row of the tensor
-    const Cell<L> o = coef_cell<L>(lp2, logz, alpha_arr, beta, offa, offb, ll_fwd, labels, b, n, t, u, xlen[b],
-                                   ylen[b] + 1, maxT, maxU, Up, fastemit);
-    if (planes != 4) rowtab[(static_cast<size_t>(b) * maxT + t) * maxU + u] = o;
+    const int Tb = xlen[b], Ub = ylen[b] + 1;
+    const Cell<L> o = coef_cell<L>(lp2, logz, alpha_arr, beta, offa, offb, ll_fwd, labels, b, n, t, u, Tb, Ub, maxT, maxU,
+                                   Up, fastemit);
+    if (offsets != nullptr) {
+        if (t < Tb && u < Ub) rowtab[static_cast<size_t>(offsets[b]) + static_cast<size_t>(t) * Ub + u] = o;
+    } else if (planes != 4) {
+        rowtab[(static_cast<size_t>(b) * maxT + t) * maxU + u] = o;
+    }
     if (wmat != nullptr) {                                    // additive joint only: W = exp(c), cb, cl; row stride Upad
         const float c = static_cast<float>(o.x);
         const size_t at = (static_cast<size_t>(b) * maxT + t) * Upad + u;
@@ -867,7 +914,7 @@ __global__ __launch_bounds__(256) void coef_kernel(
         const double* __restrict__ offb, const double* __restrict__ ll_fwd,
         const int* __restrict__ labels, const int* __restrict__ xlen, const int* __restrict__ ylen,
         Cell<L>* __restrict__ rowtab, int maxT, int maxU, int Up, float* __restrict__ wmat, int Upad, int tilesU,
-        float fastemit, int planes) {
+        float fastemit, int planes, const long long* __restrict__ offsets) {
     constexpr int DN = sizeof(L) == 4 ? 32 : 16;           // diagonals per tile (LDS: DN * 64 records)
     __shared__ Cell<L> recs[DN][64];
     const int b = blockIdx.y;
@@ -903,7 +950,11 @@ __global__ __launch_bounds__(256) void coef_kernel(
         const int u = ulo + c;
         if (u > u0 + 63 || u >= maxU || t + u >= n0 + DN || t + u >= D) continue;
         const Cell<L> o = recs[t + u - n0][u - u0];
-        if (planes != 4) rowtab[(static_cast<size_t>(b) * maxT + t) * maxU + u] = o;
+        if (offsets != nullptr) {                          // packed row order: the run of a time row stays contiguous
+            if (t < Tb && u < Ub) rowtab[static_cast<size_t>(offsets[b]) + static_cast<size_t>(t) * Ub + u] = o;
+        } else if (planes != 4) {
+            rowtab[(static_cast<size_t>(b) * maxT + t) * maxU + u] = o;
+        }
         if (wmat != nullptr) {                             // additive joint only: W = exp(c), cb, cl; row stride Upad
             const float cc = static_cast<float>(o.x);
             const size_t at = (static_cast<size_t>(b) * maxT + t) * Upad + u;
@@ -933,7 +984,7 @@ __global__ __launch_bounds__(256) void grad_flat_kernel(
         const typename Tag::store* __restrict__ acts, typename Tag::store* __restrict__ grads,
         const Cell<typename Tag::comp>* __restrict__ rowtab, const typename Tag::comp* __restrict__ grad_scale,
         unsigned long long E, unsigned long long R, int A, int blank, int TU, float invA,
-        unsigned long long dq, int drem) {
+        unsigned long long dq, int drem, const long long* __restrict__ offsets, int N) {
     using C = typename Tag::comp;
     constexpr int V = Vec<Tag>::N;
     constexpr int kChunkPackets = PPT * 256;
@@ -947,8 +998,23 @@ __global__ __launch_bounds__(256) void grad_flat_kernel(
     unsigned long long r = (c * CH) / static_cast<unsigned>(A);                   // row of the chunk start
     int rem = static_cast<int>((c * CH) - r * static_cast<unsigned>(A));          // offset inside it
 
+    // Per-sample scale of a row.  Padded layout: sample = row / (maxT*maxU).  Packed layout (offsets != nullptr):
+    // `pb` is the sample of the chunk's first row (block-uniform, advanced with the chunks), `pnext` the first row
+    // of the sample after it and `ps` its scale: a packet's row is below `pnext` unless the chunk crosses into the
+    // next sample(s), and only then are the offsets searched.
+    int pb = -1;                                            // nothing known yet: every lookup searches
+    unsigned long long pnext = 0;
+    C ps = C(1);
     auto scale_of = [&](unsigned long long row) -> C {
-        if constexpr (SCALED) return grad_scale[row / static_cast<unsigned>(TU)]; else return C(1);
+        if constexpr (SCALED) {
+            if (offsets == nullptr) return grad_scale[row / static_cast<unsigned>(TU)];
+            if (row < pnext) return ps;
+            int bb = pb + 1;
+            while (bb + 1 < N && row >= static_cast<unsigned long long>(offsets[bb + 1])) ++bb;
+            return grad_scale[bb];
+        } else {
+            return C(1);
+        }
     };
     // One element at position `pos` of a row with record `rec`.
     auto elem = [&](const Cell<C>& rec, int pos, C x, C gs) -> C {
@@ -963,6 +1029,14 @@ __global__ __launch_bounds__(256) void grad_flat_kernel(
 
     for (; c < nchunks; c += gridDim.x) {
         const unsigned long long pk0 = c * kChunkPackets;
+        if constexpr (SCALED) {
+            if (offsets != nullptr) {                       // block-uniform
+                while (pb + 1 < N && r >= static_cast<unsigned long long>(offsets[pb + 1])) ++pb;
+                if (pb < 0) pb = 0;
+                pnext = pb + 1 < N ? static_cast<unsigned long long>(offsets[pb + 1]) : ~0ull;
+                ps = grad_scale[pb];
+            }
+        }
         uint4 raw[PPT];
         Cell<C> rec[PPT], rec2[PPT];                        // rec2: the NEXT row's record, for packets that straddle
         int v0[PPT];

@@ -46,6 +46,12 @@ EXPORTS = {
                                              _PTR, _PTR, rnntOptions, C.c_int, C.c_float]),
     "compute_rnnt_loss_fwd_fastemit": (C.c_int, [_PTR, _PTR, _PTR, _PTR, C.c_int, C.c_int, _PTR, _PTR, rnntOptions,
                                                  C.c_int, C.c_int, C.c_float]),
+    "compute_rnnt_loss_packed": (C.c_int, [_PTR, _PTR, _PTR, _PTR, _PTR, _PTR, C.c_longlong, C.c_int, C.c_int, _PTR,
+                                           _PTR, _PTR, rnntOptions, C.c_int, C.c_float]),
+    "compute_rnnt_loss_packed_fwd": (C.c_int, [_PTR, _PTR, _PTR, _PTR, _PTR, C.c_longlong, C.c_int, C.c_int, _PTR,
+                                               _PTR, rnntOptions, C.c_int, C.c_int, C.c_float]),
+    "compute_rnnt_loss_packed_bwd": (C.c_int, [_PTR, _PTR, _PTR, _PTR, C.c_longlong, C.c_int, C.c_int, _PTR,
+                                               rnntOptions, C.c_int]),
     "compute_rnnt_loss_add": (C.c_int, [_PTR, _PTR, _PTR, _PTR, _PTR, _PTR, _PTR, C.c_int, C.c_int, _PTR, _PTR,
                                         rnntOptions]),
     "compute_rnnt_loss_add_fwd": (C.c_int, [_PTR, _PTR, _PTR, _PTR, _PTR, C.c_int, C.c_int, _PTR, _PTR, rnntOptions,

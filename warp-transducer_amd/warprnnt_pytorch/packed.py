@@ -1,0 +1,142 @@
+"""RNN-T loss on PACKED ("compact") joint activations: sample b contributes only its T_b x U_b real rows.
+
+The reference pads every sample of the joint tensor to (max T, max U+1) and writes zeros over the padding
+of the gradient (pytorch_binding/warprnnt_pytorch/__init__.py:24, include/detail/gpu_rnnt_kernel.h:159).
+With the lengths of a real batch spread over [max/2, max] that padding is ~40 % of the tensor.  Here
+
+    acts : (sum_b T_b * (U_b + 1), V)       row (b, t, u) = offsets[b] + t * (U_b + 1) + u
+
+(`pack_joint` builds it from a padded tensor; a joint network evaluated on gathered (t, u) pairs produces it
+directly), and the library (compute_rnnt_loss_packed_fwd / _bwd of include/rnnt.h) neither reads nor writes a
+byte of padding.  Same values as ``RNNTLoss`` on the padded tensor.  GPU only.
+"""
+import torch
+from torch.autograd import Function
+from torch.nn import Module
+
+from . import _lib, check_contiguous, check_dim, check_type
+from .warp_rnnt import _DT
+
+__all__ = ["rnnt_loss_packed", "RNNTLossPacked", "pack_joint", "unpack_joint", "row_offsets"]
+
+
+def row_offsets(act_lens, label_lens):
+    """int64 (N+1,) cumulative row counts: offsets[b+1] - offsets[b] = T_b * (U_b + 1)."""
+    rows = act_lens.to(torch.int64) * (label_lens.to(torch.int64) + 1)
+    return torch.cat([rows.new_zeros(1), rows.cumsum(0)])
+
+
+def pack_joint(acts, act_lens, label_lens):
+    """(N, T, U+1, V) padded -> (sum T_b (U_b+1), V) packed."""
+    return torch.cat([acts[b, :int(t), :int(l) + 1].reshape(-1, acts.shape[-1])
+                      for b, (t, l) in enumerate(zip(act_lens.tolist(), label_lens.tolist()))])
+
+
+def unpack_joint(packed, act_lens, label_lens, T=None, U=None):
+    """Inverse of `pack_joint`; the padding is zero-filled."""
+    tl, ll = act_lens.tolist(), label_lens.tolist()
+    T = max(tl) if T is None else T
+    U = max(ll) + 1 if U is None else U
+    out = packed.new_zeros((len(tl), T, U, packed.shape[-1]))
+    at = 0
+    for b, (t, l) in enumerate(zip(tl, ll)):
+        n = t * (l + 1)
+        out[b, :t, :l + 1] = packed[at:at + n].reshape(t, l + 1, -1)
+        at += n
+    return out
+
+
+class _RNNTPacked(Function):
+    @staticmethod
+    def forward(ctx, acts, labels, act_lens, label_lens, blank, reduction, fastemit_lambda, max_T, max_U):
+        check_type(labels, torch.int32, "labels")
+        check_type(label_lens, torch.int32, "label_lengths")
+        check_type(act_lens, torch.int32, "lengths")
+        for var, name in ((acts, "acts"), (labels, "labels"), (act_lens, "lengths"), (label_lens, "label_lengths")):
+            check_contiguous(var, name)
+        check_dim(acts, 2, "acts")
+        check_dim(labels, 2, "labels")
+        check_dim(act_lens, 1, "lengths")
+        check_dim(label_lens, 1, "label_lengths")
+        if not acts.is_cuda:
+            raise ValueError("the packed layout runs on the GPU only")
+        if acts.dtype not in _DT:
+            raise TypeError("unsupported dtype %s" % acts.dtype)
+        N = act_lens.shape[0]
+        if label_lens.shape[0] != N or labels.shape[0] != N:
+            raise ValueError("must have a length per example.")
+        offs = row_offsets(act_lens, label_lens)
+        if max_T is None or max_U is None:
+            # one host round trip for the lattice dimensions (pass max_T / max_U to avoid it)
+            mt, ml, total = torch.stack([act_lens.max().to(torch.int64), label_lens.max().to(torch.int64),
+                                         offs[-1]]).tolist()
+            max_T, max_U = mt, ml + 1
+            if total != acts.shape[0]:
+                raise ValueError("acts has %d rows, the lengths describe %d" % (acts.shape[0], total))
+        if labels.shape[1] != max_U - 1:
+            raise ValueError("Output length mismatch")
+        lib = _lib.lib()
+        R, V = acts.shape
+        code, esz = _DT[acts.dtype]
+        dev = acts.device
+        cost_dtype = torch.float64 if acts.dtype == torch.float64 else torch.float32
+        need_grad = acts.requires_grad
+        with torch.cuda.device(dev):
+            costs = torch.empty(N, dtype=cost_dtype, device=dev)
+            ws = torch.empty(_lib.workspace_bytes(max_T, max_U, N, True, esz), dtype=torch.uint8, device=dev)
+            opt = _lib.rnntOptions(loc=_lib.RNNT_GPU, num_threads=0,
+                                   stream=torch.cuda.current_stream(dev).cuda_stream, blank_label=int(blank),
+                                   maxT=int(max_T), maxU=int(max_U), batch_first=True)
+            lab_ptr = labels.data_ptr() if labels.numel() else costs.data_ptr()   # maxU == 1: never read
+            st = lib.compute_rnnt_loss_packed_fwd(acts.data_ptr(), lab_ptr, label_lens.data_ptr(), act_lens.data_ptr(),
+                                                  offs.data_ptr(), R, V, N, costs.data_ptr(), ws.data_ptr(), opt, code,
+                                                  1 if need_grad else 0, float(fastemit_lambda))
+            _lib.check(st, "compute_rnnt_loss_packed_fwd")
+            ws.record_stream(torch.cuda.current_stream(dev))
+        ctx.save_for_backward(acts, offs)
+        ctx.workspace = ws if need_grad else None
+        ctx.opt_dims = (int(blank), int(max_T), int(max_U), N)
+        ctx.mean_scale = 1.0 / N if reduction == "mean" else 1.0
+        if reduction in ("sum", "mean"):
+            costs = costs.sum().unsqueeze_(-1)
+            if reduction == "mean":
+                costs /= N
+        return costs
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        acts, offs = ctx.saved_tensors
+        blank, max_T, max_U, N = ctx.opt_dims
+        lib = _lib.lib()
+        R, V = acts.shape
+        code, _ = _DT[acts.dtype]
+        dev = acts.device
+        sdt = torch.float64 if acts.dtype == torch.float64 else torch.float32
+        with torch.cuda.device(dev):
+            scale = (grad_output.reshape(-1).to(device=dev, dtype=sdt) * ctx.mean_scale).expand(N).contiguous()
+            grads = torch.empty_like(acts)
+            opt = _lib.rnntOptions(loc=_lib.RNNT_GPU, num_threads=0,
+                                   stream=torch.cuda.current_stream(dev).cuda_stream, blank_label=blank,
+                                   maxT=max_T, maxU=max_U, batch_first=True)
+            st = lib.compute_rnnt_loss_packed_bwd(acts.data_ptr(), grads.data_ptr(), scale.data_ptr(), offs.data_ptr(),
+                                                  R, V, N, ctx.workspace.data_ptr(), opt, code)
+            _lib.check(st, "compute_rnnt_loss_packed_bwd")
+            ctx.workspace.record_stream(torch.cuda.current_stream(dev))
+        return grads, None, None, None, None, None, None, None, None
+
+
+def rnnt_loss_packed(acts, labels, act_lens, label_lens, blank=0, reduction="mean", fastemit_lambda=0.0,
+                     max_T=None, max_U=None):
+    """RNN-T loss of packed activations ``acts`` (sum_b T_b (U_b+1), V); other arguments as `rnnt_loss`.
+    ``max_T`` / ``max_U`` (= max label length + 1): the batch maxima, if the caller knows them on the host."""
+    return _RNNTPacked.apply(acts, labels, act_lens, label_lens, blank, reduction, fastemit_lambda, max_T, max_U)
+
+
+class RNNTLossPacked(Module):
+    def __init__(self, blank=0, reduction="mean", fastemit_lambda=0.0):
+        super().__init__()
+        self.blank, self.reduction, self.fastemit_lambda = blank, reduction, fastemit_lambda
+
+    def forward(self, acts, labels, act_lens, label_lens, max_T=None, max_U=None):
+        return rnnt_loss_packed(acts, labels, act_lens, label_lens, self.blank, self.reduction,
+                                self.fastemit_lambda, max_T, max_U)

@@ -514,3 +514,32 @@ def test_sharded_wrapper_over_rccl_single_rank():
     finally:
         if created:
             dist.destroy_process_group()
+
+
+def test_label_equal_to_blank_is_the_true_derivative(oracle):
+    """A label that EQUALS the blank symbol: both corrections of gpu_rnnt_kernel.h:165-173 hit the same logit
+    (the reference's CPU backward overwrites one with the other instead, cpu_rnnt.h:256-263, so its gradients
+    are not a derivative there).  The forward cost is unambiguous, so the check is a central finite difference
+    of the oracle's fp64 COST against this library's fp64 gradients -- every logit of a small problem."""
+    rng = np.random.default_rng(12)
+    N, T, U, A, blank = 2, 4, 3, 4, 2
+    acts = rng.standard_normal((N, T, U, A))
+    labels = np.array([[blank, 1], [3, blank]], dtype=np.int32)
+    tl = np.array([4, 3], dtype=np.int32)
+    ll = np.array([2, 2], dtype=np.int32)
+    costs, grads = run_gpu(acts, labels, tl, ll, blank, dtype=torch.float64)
+    ref_c, _ = oracle.rnnt_logits(acts, labels, tl, ll, blank, want_grad=False)
+    assert np.allclose(costs, ref_c, rtol=1e-10)
+    eps = 1e-5
+    num = np.zeros_like(acts)
+    for idx in np.ndindex(*acts.shape):
+        hi, lo = acts.copy(), acts.copy()
+        hi[idx] += eps
+        lo[idx] -= eps
+        ch, _ = oracle.rnnt_logits(hi, labels, tl, ll, blank, want_grad=False)
+        cl, _ = oracle.rnnt_logits(lo, labels, tl, ll, blank, want_grad=False)
+        num[idx] = (ch[idx[0]] - cl[idx[0]]) / (2 * eps)
+    assert np.abs(grads - num).max() < 1e-8
+    c32, g32 = run_gpu(acts.astype(np.float32), labels, tl, ll, blank)
+    assert np.abs(g32 - num).max() < 1e-5
+

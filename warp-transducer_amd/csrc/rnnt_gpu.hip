@@ -291,10 +291,18 @@ static void launch_grad(Plan<typename Tag::comp>& p, const typename Tag::store* 
         const unsigned long long dq = stride / p.A;
         const int drem = static_cast<int>(stride % p.A);
         const float invA = 1.0f / static_cast<float>(p.A);
+        // packed + per-sample scale: one scale per packed row, in the (by now dead) alpha array of the workspace
+        using CC = typename Tag::comp;
+        CC* rowscale = nullptr;
+        if (packed && grad_scale) {
+            rowscale = reinterpret_cast<CC*>(p.alpha);
+            hipLaunchKernelGGL((fill_row_scale_kernel<CC>), dim3(p.N, 8), dim3(256), 0, p.stream, p.offsets, grad_scale,
+                               rowscale);
+        }
 #define RNNT_FLAT(SC, PP, PS)                                                                                       \
-    hipLaunchKernelGGL((grad_flat_kernel<Tag, SC, PP, PS>), dim3(grid), dim3(256), 0, p.stream, acts, grads, p.rowtab, \
-                       grad_scale, E, R, p.A, p.blank, p.cells_per_sample, invA, dq, drem, p.offsets, p.N)
-        const bool padskip = tn.pskip && row_bytes >= 8192 && !packed;   // skip reading padded rows only where rows are long
+    hipLaunchKernelGGL((grad_flat_kernel<Tag, SC, PP, PS>), dim3(grid), dim3(256), 0, p.stream, acts, grads,        \
+                       p.rowtab, grad_scale, E, R, p.A, p.blank, p.cells_per_sample, invA, dq, drem, rowscale)
+        const bool padskip = tn.pskip && row_bytes >= 8192;     // skip reading padded rows only where rows are long
         if (grad_scale) { if (padskip) RNNT_FLAT(true, 2, true); else RNNT_FLAT(true, 2, false); }
         else if (ppt == 1) RNNT_FLAT(false, 1, false);
         else if (ppt == 4) RNNT_FLAT(false, 4, false);

@@ -969,6 +969,21 @@ __global__ __launch_bounds__(256) void coef_kernel(
 }
 
 // ------------------------------------------------------------------------------------------
+// Packed layout with a per-sample gradient scale: one scale per packed ROW, so that the gradient kernel's lookup
+// needs no search (rowscale lives in the `alpha` array of the workspace, dead once the coefficients exist).
+// grid = (N, 8), block = 256.
+template <typename C>
+__global__ __launch_bounds__(256) void fill_row_scale_kernel(
+        const long long* __restrict__ offsets, const C* __restrict__ grad_scale, C* __restrict__ rowscale) {
+    const int b = blockIdx.x;
+    const long long lo = offsets[b], hi = offsets[b + 1];
+    const C s = grad_scale[b];
+    for (long long r = lo + static_cast<long long>(blockIdx.y) * 256 + threadIdx.x; r < hi;
+         r += static_cast<long long>(gridDim.y) * 256)
+        rowscale[r] = s;
+}
+
+// ------------------------------------------------------------------------------------------
 // Pass B, FLAT form (the production path).  The (N,T,U,A) tensor is streamed as one flat array
 // of 16-byte packets: a block owns a contiguous, 16 KB-aligned chunk of kChunkPackets packets
 // per iteration (each of its 4 wavefronts moves whole 1 KB lines) and grid-strides over the
@@ -984,7 +999,7 @@ __global__ __launch_bounds__(256) void grad_flat_kernel(
         const typename Tag::store* __restrict__ acts, typename Tag::store* __restrict__ grads,
         const Cell<typename Tag::comp>* __restrict__ rowtab, const typename Tag::comp* __restrict__ grad_scale,
         unsigned long long E, unsigned long long R, int A, int blank, int TU, float invA,
-        unsigned long long dq, int drem, const long long* __restrict__ offsets, int N) {
+        unsigned long long dq, int drem, const typename Tag::comp* __restrict__ rowscale) {
     using C = typename Tag::comp;
     constexpr int V = Vec<Tag>::N;
     constexpr int kChunkPackets = PPT * 256;
@@ -998,20 +1013,14 @@ __global__ __launch_bounds__(256) void grad_flat_kernel(
     unsigned long long r = (c * CH) / static_cast<unsigned>(A);                   // row of the chunk start
     int rem = static_cast<int>((c * CH) - r * static_cast<unsigned>(A));          // offset inside it
 
-    // Per-sample scale of a row.  Padded layout: sample = row / (maxT*maxU).  Packed layout (offsets != nullptr):
-    // `pb` is the sample of the chunk's first row (block-uniform, advanced with the chunks), `pnext` the first row
-    // of the sample after it and `ps` its scale: a packet's row is below `pnext` unless the chunk crosses into the
-    // next sample(s), and only then are the offsets searched.
-    int pb = -1;                                            // nothing known yet: every lookup searches
-    unsigned long long pnext = 0;
-    C ps = C(1);
+    // Per-sample scale of a row.  Padded layout: sample = row / (maxT*maxU).  Packed layout: the host has expanded
+    // the per-sample scales into one value per packed row (`rowscale`, fill_row_scale_kernel) -- a stateless lookup
+    // like the padded one.  (Tried first: the sample of a chunk kept as block-uniform state with the offsets in
+    // LDS or global memory; every form of it ran the c3 gradient pass at 2.9-3.4 ms instead of 1.5.)
     auto scale_of = [&](unsigned long long row) -> C {
         if constexpr (SCALED) {
-            if (offsets == nullptr) return grad_scale[row / static_cast<unsigned>(TU)];
-            if (row < pnext) return ps;
-            int bb = pb + 1;
-            while (bb + 1 < N && row >= static_cast<unsigned long long>(offsets[bb + 1])) ++bb;
-            return grad_scale[bb];
+            if (rowscale != nullptr) return rowscale[row];
+            return grad_scale[row / static_cast<unsigned>(TU)];
         } else {
             return C(1);
         }
@@ -1029,14 +1038,6 @@ __global__ __launch_bounds__(256) void grad_flat_kernel(
 
     for (; c < nchunks; c += gridDim.x) {
         const unsigned long long pk0 = c * kChunkPackets;
-        if constexpr (SCALED) {
-            if (offsets != nullptr) {                       // block-uniform
-                while (pb + 1 < N && r >= static_cast<unsigned long long>(offsets[pb + 1])) ++pb;
-                if (pb < 0) pb = 0;
-                pnext = pb + 1 < N ? static_cast<unsigned long long>(offsets[pb + 1]) : ~0ull;
-                ps = grad_scale[pb];
-            }
-        }
         uint4 raw[PPT];
         Cell<C> rec[PPT], rec2[PPT];                        // rec2: the NEXT row's record, for packets that straddle
         int v0[PPT];

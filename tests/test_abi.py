@@ -93,3 +93,20 @@ def test_loader_fails_loudly_without_library(monkeypatch, tmp_path):
     monkeypatch.setattr(_lib, "_lib", None)
     with pytest.raises(ImportError):
         _lib.lib()
+
+
+@pytest.mark.parametrize("lang,std,cc", [("c", "c99", "gcc"), ("c++", "c++11", "g++")])
+def test_header_is_plain_c_and_cxx(tmp_path, lang, std, cc):
+    """include/rnnt.h is the drop-in boundary: a C99 or C++11 translation unit that only includes it must
+    compile (no torch / HIP types in the signatures) and see every entry point as a C symbol."""
+    import shutil
+    import subprocess
+    if shutil.which(cc) is None:
+        pytest.skip("%s not installed" % cc)
+    src = tmp_path / ("use_rnnt." + ("c" if lang == "c" else "cpp"))
+    calls = "\n".join("    p = (void*)&%s; (void)p;" % n for n in declared_functions())
+    src.write_text('#include "rnnt.h"\nint main(void) {\n    void* p;\n%s\n    return 0;\n}\n' % calls)
+    r = subprocess.run([cc, "-std=" + std, "-Wall", "-Werror", "-fsyntax-only", "-I", os.path.join(ROOT, "include"), str(src)],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+

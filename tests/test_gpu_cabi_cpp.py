@@ -22,7 +22,7 @@ def test_cpp_golden_tests():
     out = subprocess.run([_binary("test_gpu")], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "Tests pass" in out.stdout
-    for name in ("small_test", "options_test", "inf_test", "grad_check"):
+    for name in ("small_test", "options_test", "inf_test", "grad_check", "packed_test"):
         assert "finish %s 1" % name in out.stdout
 
 

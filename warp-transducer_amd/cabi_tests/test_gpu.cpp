@@ -148,6 +148,63 @@ static bool grad_check(int A, int T, int L, int B, float tol) {
     return diff / tot < tol;
 }
 
+// Extension: the packed layout through the C-ABI (compute_rnnt_loss_packed).  options_test's shape with ragged
+// lengths {4,3} x {2,1}: sample b keeps only its T_b x U_b rows; costs and gradients must equal the padded
+// call's on those rows.
+static bool packed_test() {
+    const int B = 2, T = 4, U = 3, A = 3;
+    std::vector<float> acts(static_cast<size_t>(B) * T * U * A);
+    {
+        std::mt19937 engine(5);
+        std::uniform_real_distribution<> unit(0, 1);
+        for (auto& x : acts) x = static_cast<float>(unit(engine));
+    }
+    const std::vector<int> labels = {1, 2, 1, 1}, ll = {2, 1}, tl = {4, 3};
+    std::vector<float> padded_grads;
+    const auto padded_costs = run(acts, labels, ll, tl, T, U, A, 0, &padded_grads);
+    std::vector<float> packed;
+    std::vector<long long> offsets = {0};
+    std::vector<size_t> origin;                            // padded element index of every packed element
+    for (int b = 0; b < B; ++b) {
+        for (int t = 0; t < tl[b]; ++t)
+            for (int u = 0; u <= ll[b]; ++u)
+                for (int k = 0; k < A; ++k) {
+                    const size_t at = ((static_cast<size_t>(b) * T + t) * U + u) * A + k;
+                    packed.push_back(acts[at]);
+                    origin.push_back(at);
+                }
+        offsets.push_back(static_cast<long long>(packed.size() / A));
+    }
+    const long long rows = offsets.back();
+    DeviceArray<float> d_acts(packed), d_grads(packed.size()), d_costs(static_cast<size_t>(B));
+    DeviceArray<int> d_labels(labels), d_ll(ll), d_tl(tl);
+    DeviceArray<long long> d_off(offsets);
+    rnntOptions options{};
+    options.maxT = T; options.maxU = U; options.blank_label = 0; options.loc = RNNT_GPU;   // default stream
+    size_t bytes = 0;
+    ok(get_workspace_size(T, U, B, true, &bytes), "get_workspace_size");
+    void* ws = nullptr;
+    hip_ok(hipMalloc(&ws, bytes), "hipMalloc workspace");
+    ok(compute_rnnt_loss_packed(d_acts.p, d_grads.p, d_labels.p, d_ll.p, d_tl.p, d_off.p, rows, A, B, d_costs.p, nullptr,
+                                ws, options, 0, 0.0f),
+       "compute_rnnt_loss_packed");
+    hip_ok(hipDeviceSynchronize(), "sync");
+    std::vector<float> costs(B), grads(packed.size());
+    hip_ok(hipMemcpy(costs.data(), d_costs.p, B * sizeof(float), hipMemcpyDeviceToHost), "D2H");
+    hip_ok(hipMemcpy(grads.data(), d_grads.p, grads.size() * sizeof(float), hipMemcpyDeviceToHost), "D2H");
+    bool good = true;
+    for (int b = 0; b < B; ++b) good = good && std::fabs(costs[b] - padded_costs[b]) < 1e-5f * std::fabs(padded_costs[b]);
+    for (size_t i = 0; i < grads.size(); ++i) good = good && std::fabs(grads[i] - padded_grads[origin[i]]) < 1e-5f;
+    // misuse: more rows than the workspace was sized for, no offsets
+    good = good && compute_rnnt_loss_packed(d_acts.p, d_grads.p, d_labels.p, d_ll.p, d_tl.p, d_off.p,
+                                            static_cast<long long>(B) * T * U + 1, A, B, d_costs.p, nullptr, ws,
+                                            options, 0, 0.0f) == RNNT_STATUS_INVALID_VALUE;
+    good = good && compute_rnnt_loss_packed(d_acts.p, d_grads.p, d_labels.p, d_ll.p, d_tl.p, nullptr, rows, A, B,
+                                            d_costs.p, nullptr, ws, options, 0, 0.0f) == RNNT_STATUS_INVALID_VALUE;
+    (void)hipFree(ws);
+    return good;
+}
+
 int main() {
     if (get_warprnnt_version() != 1) { std::fprintf(stderr, "Invalid Warp-transducer version.\n"); return 1; }
     std::printf("Running GPU tests through the C-ABI\n");
@@ -159,6 +216,7 @@ int main() {
         status &= grad_check(20, 50, 15, 1, 1e-2f);
         status &= grad_check(5, 10, 5, 65, 1e-2f);
         std::printf("finish grad_check %d\n", status);
+        status &= packed_test();             std::printf("finish packed_test %d\n", status);
     } catch (const std::exception& e) {
         std::fprintf(stderr, "exception: %s\n", e.what());
         return 1;

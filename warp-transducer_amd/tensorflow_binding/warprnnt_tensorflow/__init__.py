@@ -1,0 +1,27 @@
+"""warprnnt_tensorflow -- the reference's TensorFlow API (tensorflow_binding/warprnnt_tensorflow/__init__.py:9-47)
+over this library: ``rnnt_loss(acts, labels, input_lengths, label_lengths, blank_label=0)`` with the gradient
+registered for the "WarpRNNT" op.  Needs tensorflow-rocm and kernels.so built by ../build.sh; GPU only (the op has
+no CPU kernel: the GPU location of the library never falls back to the host)."""
+import os
+
+import tensorflow as tf
+
+_kernels = tf.load_op_library(os.path.join(os.path.dirname(os.path.abspath(__file__)), "kernels.so"))
+
+__all__ = ["rnnt_loss"]
+
+
+def rnnt_loss(acts, labels, input_lengths, label_lengths, blank_label=0):
+    """RNN-T loss of joint-network logits.
+
+    acts: (B, T, U, V) float32 logits (log-softmax is applied inside the kernels); labels: (B, U-1) int32, zero
+    padded; input_lengths, label_lengths: (B,) int32.  Returns the (B,) negative log-likelihoods."""
+    costs, _ = _kernels.warp_rnnt(acts, labels, input_lengths, label_lengths, blank_label=blank_label)
+    return costs
+
+
+@tf.RegisterGradient("WarpRNNT")
+def _rnnt_loss_grad(op, grad_costs, _unused_grad_of_grads):
+    # the op's second output IS d(cost_b)/d(acts_b); chain with the incoming per-sample gradient
+    scale = tf.reshape(grad_costs, (-1, 1, 1, 1))
+    return [scale * op.outputs[1], None, None, None]

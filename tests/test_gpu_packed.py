@@ -133,3 +133,51 @@ def test_single_call_entry_and_validation():
                                         0.0) == 0                                                # score only
     torch.cuda.synchronize()
     assert torch.allclose(costs, loss.detach(), rtol=1e-6)
+
+
+def test_packed_two_phase_is_graph_capturable(oracle):
+    """Forward + backward of the packed entries (incl. the per-row scale expansion) are enqueue-only: captured in
+    a HIP graph and replayed on changed activations and scales."""
+    from warprnnt_pytorch import _lib
+    from warprnnt_pytorch.packed import pack_joint, row_offsets
+    acts, labels, tl, ll, blank = problem((3, 12, 6, 40), 17)
+    N, T, U, A = acts.shape
+    dev = torch.device("cuda:0")
+    t_lab, t_tl, t_ll = (torch.tensor(x, device=dev) for x in (labels, tl, ll))
+    p = pack_joint(torch.tensor(acts, device=dev), t_tl, t_ll).contiguous()
+    R = p.shape[0]
+    offs = row_offsets(t_tl, t_ll)
+    lib = _lib.lib()
+    ws = torch.empty(_lib.workspace_bytes(T, U, N, True, 4), dtype=torch.uint8, device=dev)
+    costs, grads = torch.zeros(N, device=dev), torch.zeros_like(p)
+    scale = torch.ones(N, device=dev)
+
+    def enqueue():
+        opt = _lib.rnntOptions(loc=1, num_threads=0, stream=torch.cuda.current_stream().cuda_stream,
+                               blank_label=blank, maxT=T, maxU=U, batch_first=True)
+        assert lib.compute_rnnt_loss_packed_fwd(p.data_ptr(), t_lab.data_ptr(), t_ll.data_ptr(), t_tl.data_ptr(),
+                                                offs.data_ptr(), R, A, N, costs.data_ptr(), ws.data_ptr(), opt, 0, 1,
+                                                0.0) == 0
+        assert lib.compute_rnnt_loss_packed_bwd(p.data_ptr(), grads.data_ptr(), scale.data_ptr(), offs.data_ptr(), R, A,
+                                                N, ws.data_ptr(), opt, 0) == 0
+
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):                       # warm-up outside capture
+        enqueue()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        enqueue()
+    for f, w in ((1.0, [1.0, 1.0, 1.0]), (0.5, [2.0, -1.0, 0.25])):
+        p.copy_(pack_joint(torch.tensor(acts * f, device=dev), t_tl, t_ll))
+        scale.copy_(torch.tensor(w))
+        costs.zero_(); grads.zero_()
+        graph.replay()
+        torch.cuda.synchronize()
+        ref_c, ref_g = oracle.rnnt_logits((acts * f).astype(np.float32).astype(np.float64), labels, tl, ll, blank)
+        ref_pk = np.concatenate([(ref_g[b, :tl[b], :ll[b] + 1] * w[b]).reshape(-1, A) for b in range(N)])
+        assert np.abs(costs.cpu().numpy() - ref_c).max() <= 1e-4 * np.abs(ref_c).max()
+        assert np.abs(grads.cpu().numpy() - ref_pk).max() < 2e-4
+

@@ -1,0 +1,44 @@
+"""Argument validation shared by the loss wrappers (`RNNTLoss`, `RNNTLossAdd`, `RNNTLossPacked`).
+
+Behavioural contract = the reference binding's (pytorch_binding/warprnnt_pytorch/__init__.py:103-140): the same
+checks in the same ORDER (so the first violated one decides the exception), the same exception types and the
+same message texts -- including its spelling "lenghts" in two of them, which callers may be matching on.
+"""
+import torch
+
+
+def check_type(var, t, name):
+    if var.dtype is not t:
+        raise TypeError("%s must be %s" % (name, t))
+
+
+def check_contiguous(var, name):
+    if not var.is_contiguous():
+        raise ValueError("%s must be contiguous" % name)
+
+
+def check_dim(var, dim, name):
+    if var.dim() != dim:
+        raise ValueError("%s must be %dD" % (name, dim))
+
+
+def certify_inputs(log_probs, labels, lengths, label_lengths):
+    """(N,T,U,V) activations, (N,U-1) int32 labels, (N,) int32 lengths: dtype, contiguity, one length per sample,
+    ranks, and T == max(lengths), U == max(label_lengths) + 1 (one device-to-host read each)."""
+    arg = {"log_probs": log_probs, "labels": labels, "lengths": lengths, "label_lengths": label_lengths}
+    for name in ("labels", "label_lengths", "lengths"):
+        check_type(arg[name], torch.int32, name)
+    for name in ("log_probs", "labels", "label_lengths", "lengths"):
+        check_contiguous(arg[name], name)
+    batch = log_probs.shape[0]
+    if lengths.shape[0] != batch:
+        raise ValueError("must have a length per example.")
+    if label_lengths.shape[0] != batch:
+        raise ValueError("must have a label length per example.")
+    for name, rank, shown in (("log_probs", 4, "log_probs"), ("labels", 2, "labels"),
+                              ("lengths", 1, "lenghts"), ("label_lengths", 1, "label_lenghts")):
+        check_dim(arg[name], rank, shown)
+    if log_probs.shape[1] != int(lengths.max()):
+        raise ValueError("Input length mismatch")
+    if log_probs.shape[2] != int(label_lengths.max()) + 1:
+        raise ValueError("Output length mismatch")

@@ -250,7 +250,9 @@ rnntStatus_t compute_rnnt_loss_fwd_fastemit(const void* activations,
  * workspace query is unchanged), costs, grad_scale, dtype codes, stream semantics and FastEmit are as for
  * compute_rnnt_loss_async / _fwd / _bwd / _fastemit.  No byte of padding is read or written.  Both tensors must
  * be 16-byte aligned when gradients are requested (INVALID_VALUE otherwise); total_rows must be in
- * (0, minibatch * maxT * maxU].  GPU only. */
+ * (0, minibatch * maxT * maxU].  compute_rnnt_loss_packed also accepts options.loc == RNNT_CPU with the CPU
+ * location's contract (every array incl. row_offsets and costs on the HOST, log-probabilities in, sparse
+ * log-prob gradients out, fp32 / fp64, no scale, lambda = 0); the _fwd / _bwd pair is GPU only. */
 rnntStatus_t compute_rnnt_loss_packed(const void* activations,
                                       void* gradients,
                                       const int* const flat_labels,

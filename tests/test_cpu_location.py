@@ -124,3 +124,42 @@ def test_bad_lengths_are_rejected(oracle):
     assert call(2, 2) == 0
     opt.blank_label = 4
     assert call(2, 2) == 2
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_packed_layout_on_the_cpu_location(oracle, dtype):
+    """compute_rnnt_loss_packed with RNNT_CPU: ragged samples stored back to back (row = offsets[b] + t*U_b + u),
+    every array on the host.  Costs and the sparse log-prob gradients must equal the padded CPU call's on the
+    rows that exist; wrong row counts are refused."""
+    rng = np.random.default_rng(4)
+    N, T, U, A, blank = 4, 9, 5, 6, 2
+    lp = oracle.log_softmax(rng.standard_normal((N, T, U, A))).astype(dtype)
+    labels = rng.integers(0, A, size=(N, U - 1)).astype(np.int32)
+    labels[labels == blank] = (blank + 1) % A
+    tl = np.array([9, 3, 7, 1], dtype=np.int32)
+    ll = np.array([4, 0, 2, 3], dtype=np.int32)
+    c_pad, g_pad = cpu_loss(lp, labels, tl, ll, blank=blank)
+    rows = [lp[b, :tl[b], :ll[b] + 1].reshape(-1, A) for b in range(N)]
+    packed = np.ascontiguousarray(np.concatenate(rows))
+    offs = np.concatenate([[0], np.cumsum([r.shape[0] for r in rows])]).astype(np.int64)
+    lib = _lib.lib()
+    esz = packed.dtype.itemsize
+    ws = np.empty(_lib.workspace_bytes(T, U, N, False, esz), dtype=np.uint8)
+    costs = np.zeros(N, dtype=dtype)
+    grads = np.full_like(packed, 7.0)
+    opt = _lib.rnntOptions(loc=_lib.RNNT_CPU, num_threads=2, stream=None, blank_label=blank, maxT=T, maxU=U,
+                           batch_first=True)
+
+    def call(rows_total=int(offs[-1]), offsets=offs, code=0 if dtype == np.float32 else 1, lam=0.0):
+        return lib.compute_rnnt_loss_packed(packed.ctypes.data, grads.ctypes.data, labels.ctypes.data, ll.ctypes.data,
+                                            tl.ctypes.data, offsets.ctypes.data, rows_total, A, N, costs.ctypes.data,
+                                            None, ws.ctypes.data, opt, code, lam)
+
+    assert call() == 0
+    assert np.allclose(costs, c_pad, rtol=1e-6)
+    expect = np.concatenate([g_pad[b, :tl[b], :ll[b] + 1].reshape(-1, A) for b in range(N)])
+    assert np.allclose(grads, expect, rtol=1e-6, atol=1e-7)
+    bad = offs.copy(); bad[2] += 1
+    assert call(offsets=bad) == 2                     # a sample whose row count is not T_b * U_b
+    assert call(rows_total=0) == 2 and call(code=2) == 2 and call(lam=0.1) == 2
+

@@ -105,9 +105,12 @@ R one_sample(const SampleView<R>& s, const int* y, int T, int U, int blank, R* s
     return loglik;
 }
 
+// offsets != nullptr: PACKED layout (include/rnnt.h compute_rnnt_loss_packed) -- sample b is T_b x U_b rows
+// starting at row offsets[b] (host array of N+1 cumulative row counts), row (t,u) at t*U_b + u.
 template <typename R>
 rnntStatus_t run(const R* log_probs, R* grads, const int* labels, const int* label_lengths,
-                 const int* input_lengths, int A, int N, R* costs, void* workspace, const rnntOptions& opt) {
+                 const int* input_lengths, int A, int N, R* costs, void* workspace, const rnntOptions& opt,
+                 const long long* offsets = nullptr) {
     const int maxT = opt.maxT, maxU = opt.maxU, blank = opt.blank_label;
     if (blank < 0 || blank >= A) return RNNT_STATUS_INVALID_VALUE;
     const size_t per_sample = static_cast<size_t>(maxT) * maxU * 4;   // reals of scratch per sample
@@ -128,12 +131,26 @@ rnntStatus_t run(const R* log_probs, R* grads, const int* labels, const int* lab
             continue;
         }
         SampleView<R> s;
+        if (offsets != nullptr) {
+            if (offsets[b + 1] - offsets[b] != static_cast<long long>(T) * U) {
+#pragma omp atomic write
+                bad = 1;
+                continue;
+            }
+            const size_t base = static_cast<size_t>(offsets[b]) * A;
+            s.lp = log_probs + base;
+            s.grad = grads ? grads + base : nullptr;
+            s.u_stride = static_cast<size_t>(A);
+            s.t_stride = s.u_stride * U;
+            if (grads) std::memset(s.grad, 0, sizeof(R) * static_cast<size_t>(T) * U * A);
+        } else {
         const size_t base = bf ? b * slab : static_cast<size_t>(b) * A;
         s.lp = log_probs + base;
         s.grad = grads ? grads + base : nullptr;
         s.u_stride = bf ? static_cast<size_t>(A) : static_cast<size_t>(N) * A;
         s.t_stride = s.u_stride * maxU;
         if (grads && bf) std::memset(s.grad, 0, sizeof(R) * slab);   // cpu_rnnt.h:155-158
+        }
         const R ll = one_sample<R>(s, labels + static_cast<size_t>(b) * (maxU - 1), T, U, blank,
                                    scratch_all + b * per_sample);
         costs[b] = -ll;
@@ -157,6 +174,16 @@ rnntStatus_t cpu_rnnt_f64(const double* log_probs, double* grads, const int* lab
                           const int* input_lengths, int A, int N, double* costs, void* workspace,
                           const rnntOptions& opt) {
     return run<double>(log_probs, grads, labels, label_lengths, input_lengths, A, N, costs, workspace, opt);
+}
+
+rnntStatus_t cpu_rnnt_packed(const void* log_probs, void* grads, const int* labels, const int* label_lengths,
+                             const int* input_lengths, const long long* offsets, int A, int N, void* costs,
+                             void* workspace, const rnntOptions& opt, bool fp64) {
+    if (fp64)
+        return run<double>(static_cast<const double*>(log_probs), static_cast<double*>(grads), labels, label_lengths,
+                           input_lengths, A, N, static_cast<double*>(costs), workspace, opt, offsets);
+    return run<float>(static_cast<const float*>(log_probs), static_cast<float*>(grads), labels, label_lengths,
+                      input_lengths, A, N, static_cast<float*>(costs), workspace, opt, offsets);
 }
 
 }  // namespace rnnt

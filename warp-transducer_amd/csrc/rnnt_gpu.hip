@@ -674,8 +674,18 @@ rnntStatus_t compute_rnnt_loss_packed(const void* activations, void* gradients, 
                                       int minibatch, void* costs_device, const void* grad_scale_device,
                                       void* workspace, rnntOptions options, int dtype_code, float fastemit_lambda) {
     if (bad_args(activations, flat_labels, label_lengths, input_lengths, costs_device, workspace,
-                 alphabet_size, minibatch, options) || row_offsets == nullptr || options.loc != RNNT_GPU)
+                 alphabet_size, minibatch, options) || row_offsets == nullptr)
         return RNNT_STATUS_INVALID_VALUE;
+    if (options.loc == RNNT_CPU) {
+        // the reference's CPU contract on the packed rows: every array on the host (row_offsets and costs too),
+        // log-probabilities in, sparse log-prob gradients out (rnnt_cpu.cpp); fp32 / fp64, no scale, no FastEmit
+        if (dtype_code > 1 || dtype_code < 0 || grad_scale_device != nullptr || fastemit_lambda != 0.0f ||
+            total_rows <= 0)
+            return RNNT_STATUS_INVALID_VALUE;
+        return cpu_rnnt_packed(activations, gradients, flat_labels, label_lengths, input_lengths, row_offsets,
+                               alphabet_size, minibatch, costs_device, workspace, options, dtype_code == 1);
+    }
+    if (options.loc != RNNT_GPU) return RNNT_STATUS_INVALID_VALUE;
     return run_async(activations, gradients, flat_labels, label_lengths, input_lengths, alphabet_size, minibatch,
                      costs_device, grad_scale_device, workspace, options, dtype_code, 3, -1, fastemit_lambda,
                      row_offsets, total_rows);

@@ -8,7 +8,8 @@ With the lengths of a real batch spread over [max/2, max] that padding is ~40 % 
 
 (`pack_joint` builds it from a padded tensor; a joint network evaluated on gathered (t, u) pairs produces it
 directly), and the library (compute_rnnt_loss_packed_fwd / _bwd of include/rnnt.h) neither reads nor writes a
-byte of padding.  Same values as ``RNNTLoss`` on the padded tensor.  GPU only.
+byte of padding.  Same values as ``RNNTLoss`` on the padded tensor.  CPU tensors take the library's RNNT_CPU
+location (log_softmax applied here, gradients computed in forward), as `RNNTLoss` does.
 """
 import torch
 from torch.autograd import Function
@@ -58,14 +59,16 @@ class _RNNTPacked(Function):
         check_dim(labels, 2, "labels")
         check_dim(act_lens, 1, "lengths")
         check_dim(label_lens, 1, "label_lengths")
-        if not acts.is_cuda:
-            raise ValueError("the packed layout runs on the GPU only")
         if acts.dtype not in _DT:
             raise TypeError("unsupported dtype %s" % acts.dtype)
         N = act_lens.shape[0]
         if label_lens.shape[0] != N or labels.shape[0] != N:
             raise ValueError("must have a length per example.")
         offs = row_offsets(act_lens, label_lens)
+        ctx.on_gpu = acts.is_cuda
+        if not acts.is_cuda:
+            return _RNNTPacked._forward_cpu(ctx, acts, labels, act_lens, label_lens, offs, blank, reduction,
+                                            fastemit_lambda, max_T, max_U)
         if max_T is None or max_U is None:
             # one host round trip for the lattice dimensions (pass max_T / max_U to avoid it)
             mt, ml, total = torch.stack([act_lens.max().to(torch.int64), label_lens.max().to(torch.int64),
@@ -104,7 +107,50 @@ class _RNNTPacked(Function):
         return costs
 
     @staticmethod
+    def _forward_cpu(ctx, logp, labels, act_lens, label_lens, offs, blank, reduction, fastemit_lambda, max_T, max_U):
+        """RNNT_CPU location (compute_rnnt_loss_packed with host arrays): `logp` are LOG-PROBABILITIES (the caller,
+        `rnnt_loss_packed`, applied log_softmax as `rnnt_loss` does on the CPU); gradients are computed here and
+        scaled in backward, as in the reference's flow."""
+        if logp.dtype not in (torch.float32, torch.float64):
+            raise TypeError("the CPU location takes float32 or float64")
+        if fastemit_lambda:
+            raise NotImplementedError("fastemit_lambda is an extension of the GPU route")
+        N = act_lens.shape[0]
+        max_T = int(act_lens.max()) if max_T is None else int(max_T)
+        max_U = int(label_lens.max()) + 1 if max_U is None else int(max_U)
+        if int(offs[-1]) != logp.shape[0]:
+            raise ValueError("acts has %d rows, the lengths describe %d" % (logp.shape[0], int(offs[-1])))
+        if labels.shape[1] != max_U - 1:
+            raise ValueError("Output length mismatch")
+        lib = _lib.lib()
+        R, V = logp.shape
+        code, esz = _DT[logp.dtype]
+        costs = torch.zeros(N, dtype=logp.dtype)
+        grads = torch.empty_like(logp) if logp.requires_grad else None
+        ws = torch.empty(_lib.workspace_bytes(max_T, max_U, N, False, esz), dtype=torch.uint8)
+        opt = _lib.rnntOptions(loc=_lib.RNNT_CPU, num_threads=0, stream=None, blank_label=int(blank), maxT=max_T,
+                               maxU=max_U, batch_first=True)
+        lab_ptr = labels.data_ptr() if labels.numel() else costs.data_ptr()
+        st = lib.compute_rnnt_loss_packed(logp.data_ptr(), grads.data_ptr() if grads is not None else None, lab_ptr,
+                                          label_lens.data_ptr(), act_lens.data_ptr(), offs.data_ptr(), R, V, N,
+                                          costs.data_ptr(), None, ws.data_ptr(), opt, code, 0.0)
+        _lib.check(st, "compute_rnnt_loss_packed")
+        ctx.cpu_grads = grads
+        ctx.cpu_rows = offs[1:] - offs[:-1]
+        ctx.mean_scale = 1.0 / N if reduction == "mean" else 1.0
+        if reduction in ("sum", "mean"):
+            costs = costs.sum().unsqueeze_(-1)
+            if reduction == "mean":
+                costs /= N
+        return costs
+
+    @staticmethod
     def backward(ctx, grad_output):
+        if not ctx.on_gpu:
+            n = ctx.cpu_rows.shape[0]
+            per_sample = (grad_output.reshape(-1).to(ctx.cpu_grads.dtype) * ctx.mean_scale).expand(n)
+            per_row = torch.repeat_interleave(per_sample, ctx.cpu_rows)
+            return ctx.cpu_grads * per_row.unsqueeze(1), None, None, None, None, None, None, None, None
         acts, offs = ctx.saved_tensors
         blank, max_T, max_U, N = ctx.opt_dims
         lib = _lib.lib()
@@ -129,6 +175,8 @@ def rnnt_loss_packed(acts, labels, act_lens, label_lens, blank=0, reduction="mea
                      max_T=None, max_U=None):
     """RNN-T loss of packed activations ``acts`` (sum_b T_b (U_b+1), V); other arguments as `rnnt_loss`.
     ``max_T`` / ``max_U`` (= max label length + 1): the batch maxima, if the caller knows them on the host."""
+    if not acts.is_cuda:
+        acts = torch.nn.functional.log_softmax(acts, -1)      # the CPU location takes log-probabilities
     return _RNNTPacked.apply(acts, labels, act_lens, label_lens, blank, reduction, fastemit_lambda, max_T, max_U)
 
 

@@ -302,7 +302,13 @@ rnntStatus_t compute_rnnt_loss_packed_bwd(const void* activations,
  * pred_grads receive dL/d(trans_acts) = sum_u dL/dh and dL/d(pred_acts) = sum_t dL/dh (both NULL:
  * score only).  Same conventions as compute_rnnt_loss_async: `costs_device` is a DEVICE array of
  * `minibatch` floats, the call only enqueues on options.stream; size the workspace with
- * get_workspace_size(maxT, maxU, minibatch, true, &bytes, 4). */
+ * get_workspace_size_add(maxT, maxU, minibatch, &bytes) -- the lattice workspace of
+ * get_workspace_size plus the row maxima and the dense weight planes only this path uses (a
+ * workspace of that size also serves every other GPU entry point). */
+rnntStatus_t get_workspace_size_add(int maxT, int maxU,
+                                    int minibatch,
+                                    size_t* size_bytes);
+
 rnntStatus_t compute_rnnt_loss_add(const float* const trans_acts,
                                    const float* const pred_acts,
                                    float* trans_grads,

@@ -30,6 +30,18 @@ def test_library_exports_every_declared_symbol():
     assert set(names) == set(_lib.EXPORTS), (names, sorted(_lib.EXPORTS))
 
 
+def test_dynamic_symbol_table_is_the_c_abi_only():
+    """The reference's libwarprnnt.so exports its five C entry points and nothing else; this one exports
+    exactly what include/rnnt.h declares (no C++ helpers, no host-side kernel handles)."""
+    import shutil
+    import subprocess
+    nm = shutil.which("nm") or "/opt/rocm/lib/llvm/bin/llvm-nm"
+    out = subprocess.run([nm, "-D", "--defined-only", _lib.library_path()], check=True, capture_output=True,
+                         text=True).stdout
+    exported = {line.split()[-1] for line in out.splitlines() if line.strip()}
+    assert exported == set(declared_functions()), sorted(exported ^ set(declared_functions()))
+
+
 def test_version_and_status_strings():
     lib = _lib.lib()
     assert lib.get_warprnnt_version() == 1                       # tests/test_cpu.cpp:382
@@ -57,6 +69,9 @@ def test_workspace_size_contract():
     assert n.value == gpu32                                                  # 16-bit acts keep an fp32 lattice
     assert lib.get_workspace_size(150, 21, 128, True, C.byref(n), 8) == 0
     assert n.value > gpu32
+    assert lib.get_workspace_size_add(150, 21, 128, C.byref(n)) == 0         # additive joint: + maxima and W planes
+    assert n.value > gpu32
+    assert lib.get_workspace_size_add(0, 21, 128, C.byref(n)) == 2
     # must hold the skewed lattice: 5 fp32 words per cell of N*(T+U-1)*U
     assert gpu32 >= 5 * 4 * 128 * (150 + 21 - 1) * 21
 

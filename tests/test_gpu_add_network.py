@@ -147,7 +147,7 @@ def test_single_call_entry_equals_two_phase():
     U = g.shape[1]
     df, dg = torch.full_like(tf, 7.0), torch.full_like(tg, 7.0)      # every element must be overwritten
     costs = torch.empty(N, device=dev)
-    ws = torch.empty(_lib.workspace_bytes(T, U, N, True, 4), dtype=torch.uint8, device=dev)
+    ws = torch.empty(_lib.workspace_bytes_add(T, U, N), dtype=torch.uint8, device=dev)
     opt = _lib.rnntOptions(loc=1, num_threads=0, stream=torch.cuda.current_stream().cuda_stream, blank_label=blank,
                            maxT=T, maxU=U, batch_first=True)
     lib = _lib.lib()
@@ -179,7 +179,7 @@ def test_graph_capture_and_replay(oracle):
     tf, tg = torch.tensor(f, device=dev), torch.tensor(g, device=dev)
     tlab, ttl, tll = (torch.tensor(a, device=dev) for a in (labels, tl, ll))
     df, dg, costs = torch.empty_like(tf), torch.empty_like(tg), torch.empty(N, device=dev)
-    ws = torch.empty(_lib.workspace_bytes(T, U, N, True, 4), dtype=torch.uint8, device=dev)
+    ws = torch.empty(_lib.workspace_bytes_add(T, U, N), dtype=torch.uint8, device=dev)
     lib = _lib.lib()
 
     def call():

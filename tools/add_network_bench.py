@@ -31,7 +31,7 @@ for name in [a for a in sys.argv[1:] if not a.startswith("--")] or ["c3"]:
     ll = torch.full((N,), U - 1, dtype=torch.int32, device=dev)
     df, dg = torch.empty_like(f), torch.empty_like(g)
     costs = torch.empty(N, device=dev)
-    ws = torch.empty(_lib.workspace_bytes(T, U, N, True, 4), dtype=torch.uint8, device=dev)
+    ws = torch.empty(_lib.workspace_bytes_add(T, U, N), dtype=torch.uint8, device=dev)
     opt = _lib.rnntOptions(loc=1, num_threads=0, stream=torch.cuda.current_stream().cuda_stream, blank_label=0,
                            maxT=T, maxU=U, batch_first=True)
 

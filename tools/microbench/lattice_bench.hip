@@ -1,5 +1,4 @@
-// Development microbenchmark for the lattice kernel: time per diagonal, with ablations
-// (-DRNNT_LAT_ABLATE=1 no stores, =2 no loads, =3 neither).
+// Development microbenchmark for the lattice kernel: time per diagonal.
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -35,6 +34,6 @@ int main(int argc, char** argv) {
     CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
     float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= reps;
     float c0; CK(hipMemcpy(&c0, costs, 4, hipMemcpyDeviceToHost));
-    printf("ablate=%d N=%d T=%d U=%d: %.1f us, %.1f ns/diagonal (cost[0]=%.3f)\n", RNNT_LAT_ABLATE, N, T, U, ms * 1e3, ms * 1e6 / (T + U - 2), c0);
+    printf("N=%d T=%d U=%d: %.1f us, %.1f ns/diagonal (cost[0]=%.3f)\n", N, T, U, ms * 1e3, ms * 1e6 / (T + U - 2), c0);
     return 0;
 }

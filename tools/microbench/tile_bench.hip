@@ -1,4 +1,4 @@
-// Development microbenchmark for the LDS-tile row-stats kernel (c4 shape), with ablations.
+// Development microbenchmark for the LDS-tile row-stats kernel (c4 shape).
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -18,7 +18,7 @@ template <int G> void run(const float* acts, int* labels, int* xlen, int* ylen, 
     for (int i = 0; i < 5; ++i) launch();
     CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
     float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= 5;
-    printf("ablate=%d G=%-2d tile=%5.1f KB: %7.3f ms %7.1f GB/s\n", RNNT_TILE_ABLATE, G, lds / 1024.0, ms, bytes / ms / 1e6);
+    printf("G=%-2d tile=%5.1f KB: %7.3f ms %7.1f GB/s\n", G, lds / 1024.0, ms, bytes / ms / 1e6);
 }
 int main(int argc, char** argv) {
     const int N = 64, T = 1500, U = 301, A = argc > 1 ? atoi(argv[1]) : 50;

@@ -30,7 +30,9 @@ struct Layout {
 };
 
 // lat = bytes of one lattice value (4: fp32 lattice for 16/32-bit activations, 8: fp64).
-static Layout make_layout(int maxT, int maxU, int N, size_t lat) {
+// joint: also the additive-joint planes (get_workspace_size_add); they sit BEHIND everything the
+// materialised path uses, so a plan carved with joint = true is valid for both.
+static Layout make_layout(int maxT, int maxU, int N, size_t lat, bool joint) {
     const size_t D = lat_rows(maxT, maxU);      // diagonals + padding rows
     const size_t Up = (static_cast<size_t>(maxU) + 63) / 64 * 64;   // one 64-lane row per wavefront
     const size_t W = Up / 64;
@@ -48,8 +50,11 @@ static Layout make_layout(int maxT, int maxU, int N, size_t lat) {
     l.llb = o;   o = align_up(o + N * sizeof(double));
     l.costs = o; o = align_up(o + N * sizeof(double));
     // additive joint only: row maxima of f and g, dense matrices W, CB, CL (row stride = maxU rounded up to 8)
-    l.rowmax = o; o = align_up(o + ((static_cast<size_t>(maxT) + maxU) * N + 1) * sizeof(float));   // + the +inf sentinel
-    l.wmat = o;   o = align_up(o + 3 * static_cast<size_t>(maxT) * joint_upad(maxU) * N * sizeof(float));   // W | CB | CL
+    l.rowmax = o; l.wmat = o;
+    if (joint) {
+        o = align_up(o + ((static_cast<size_t>(maxT) + maxU) * N + 1) * sizeof(float));   // + the +inf sentinel
+        l.wmat = o;   o = align_up(o + 3 * static_cast<size_t>(maxT) * joint_upad(maxU) * N * sizeof(float));   // W | CB | CL
+    }
     l.total = o + kAlign;                       // slack to align the caller's base pointer
     return l;
 }
@@ -87,8 +92,9 @@ static void prof_accumulate() {
 }
 
 // ----------------------------------------------------------------------------- tuning knobs
-// Development A/B switches, read once from RNNT_TUNE="key=value,key=value" (defaults are the
-// measured best; see profiles/).  sw = waves per block of the row-stats kernel (2|4|8),
+// The measured-best launch parameters.  A release build has exactly these constants; a development
+// build (make dev: -DRNNT_DEV, lib/dev/libwarprnnt.so) can override them for A/B runs with
+// RNNT_TUNE="key=value,key=value".  sw = waves per block of the row-stats kernel (2|4|8),
 // nta = non-temporal stats loads, gmax = grid cap of the flat gradient kernel, rows = 1 forces
 // the row-form gradient kernel, tile / tilekb = LDS-tile stats kernel on/off and its LDS budget,
 // ppt = packets per thread of the flat gradient kernel.  Additive joint: jfnk / jgnk = columns
@@ -96,28 +102,42 @@ static void prof_accumulate() {
 // blk = block-per-row statistics kernel for rows >= 12 KB on/off, jzs = vocabulary split of the Z kernel (1|4|8),
 // xcd = XCD-aware tile order of the short-row statistics kernel on/off, ctile = tiled coefficient kernel on/off,
 // pskip = the gradient kernel's skip-padded-rows form for rows >= 8 KB on/off, joh = one-hot df corrections in the
-// additive-joint DF kernel (-1: vocabularies <= 256).
+// additive-joint DF kernel (-1: vocabularies <= 256), one = single-launch path for tiny problems on/off.
 struct Tune { int sw = 4, nta = 1, gmax = 4194304, rows = 0, tile = 1, tilekb = 52, ppt = 2;
-              int jfnk = 0, jfpf = 1, jgnk = 0, jgpf = 1, blk = 1, jzs = 0, xcd = 1, ctile = 1, pskip = 1, joh = -1; };
-static Tune g_tune;
-static bool g_tune_read = false;
-static const Tune& tune() {
-    if (!g_tune_read) {
-        g_tune_read = true;
-        if (const char* e = getenv("RNNT_TUNE")) {
-            auto get = [&](const char* key, int& dst) {
-                const char* p = strstr(e, key);
-                if (p && p[strlen(key)] == '=') dst = atoi(p + strlen(key) + 1);
-            };
-            get("sw", g_tune.sw); get("nta", g_tune.nta);
-            get("gmax", g_tune.gmax); get("rows", g_tune.rows); get("tile", g_tune.tile);
-            get("tilekb", g_tune.tilekb); get("ppt", g_tune.ppt);
-            get("jfnk", g_tune.jfnk); get("jfpf", g_tune.jfpf); get("jgnk", g_tune.jgnk); get("jgpf", g_tune.jgpf);
-            get("blk", g_tune.blk); get("jzs", g_tune.jzs); get("xcd", g_tune.xcd); get("ctile", g_tune.ctile); get("pskip", g_tune.pskip); get("joh", g_tune.joh);
-        }
+              int jfnk = 0, jfpf = 1, jgnk = 0, jgpf = 1, blk = 1, jzs = 0, xcd = 1, ctile = 1, pskip = 1, joh = -1;
+              int one = 1, lat2 = 1; };
+#ifdef RNNT_DEV
+static Tune read_tune() {
+    Tune t;
+    const char* e = getenv("RNNT_TUNE");
+    if (e == nullptr) return t;
+    const struct { const char* key; int* dst; } keys[] = {
+        {"sw", &t.sw}, {"nta", &t.nta}, {"gmax", &t.gmax}, {"rows", &t.rows}, {"tile", &t.tile},
+        {"tilekb", &t.tilekb}, {"ppt", &t.ppt}, {"jfnk", &t.jfnk}, {"jfpf", &t.jfpf}, {"jgnk", &t.jgnk},
+        {"jgpf", &t.jgpf}, {"blk", &t.blk}, {"jzs", &t.jzs}, {"xcd", &t.xcd}, {"ctile", &t.ctile},
+        {"pskip", &t.pskip}, {"joh", &t.joh}, {"one", &t.one}, {"lat2", &t.lat2}};
+    // tokens are separated by ',', a token is key=value with the WHOLE key compared
+    for (const char* p = e; *p;) {
+        const char* end = strchr(p, ',');
+        const size_t len = end ? static_cast<size_t>(end - p) : strlen(p);
+        const char* eq = static_cast<const char*>(memchr(p, '=', len));
+        if (eq != nullptr)
+            for (const auto& k : keys)
+                if (strlen(k.key) == static_cast<size_t>(eq - p) && strncmp(k.key, p, eq - p) == 0) *k.dst = atoi(eq + 1);
+        p += len + (end ? 1 : 0);
     }
-    return g_tune;
+    return t;
 }
+static const Tune& tune() {
+    static const Tune t = read_tune();     // function-local static: initialised once, thread-safe
+    return t;
+}
+#else
+static const Tune& tune() {
+    static const Tune t;
+    return t;
+}
+#endif
 
 // ----------------------------------------------------------------------------- launch
 // Everything one call needs: problem dimensions, the carved workspace, the stream.
@@ -139,7 +159,8 @@ template <typename C> struct Plan {
 
 template <typename C>
 static bool make_plan(Plan<C>& p, int A, int N, const rnntOptions& opt, void* workspace, const int* labels,
-                      const int* label_lengths, const int* input_lengths, C* costs_device_out) {
+                      const int* label_lengths, const int* input_lengths, C* costs_device_out, bool joint = false) {
+    (void)hipGetLastError();                       // a stale error of an unrelated earlier HIP call is not ours
     p.N = N; p.maxT = opt.maxT; p.maxU = opt.maxU; p.A = A; p.blank = opt.blank_label;
     if (p.blank < 0 || p.blank >= A) return false;
     if (p.maxU > 1024) return false;               // one lane per label position (as the reference)
@@ -149,7 +170,7 @@ static bool make_plan(Plan<C>& p, int A, int N, const rnntOptions& opt, void* wo
     p.cells_per_sample = p.maxT * p.maxU;
     p.stream = reinterpret_cast<hipStream_t>(opt.stream);
     p.labels = labels; p.input_lengths = input_lengths; p.label_lengths = label_lengths;
-    const Layout lay = make_layout(p.maxT, p.maxU, N, sizeof(C));
+    const Layout lay = make_layout(p.maxT, p.maxU, N, sizeof(C), joint);
     char* ws = reinterpret_cast<char*>(align_up(reinterpret_cast<size_t>(workspace)));
     p.lp2 = reinterpret_cast<LogPair<C>*>(ws + lay.lp2);
     p.logz = reinterpret_cast<C*>(ws + lay.logz);
@@ -379,6 +400,10 @@ static rnntStatus_t run_gpu(const typename Tag::store* acts, typename Tag::store
             return RNNT_STATUS_MEMOPS_FAILED;
         if (hipStreamSynchronize(p.stream) != hipSuccess) return RNNT_STATUS_EXECUTION_FAILED;
         if (prof) prof_accumulate();
+        // device-side lengths that do not fit the tensor (lattice_kernel marks the sample's cost): the same
+        // status the CPU location returns for them (rnnt_cpu.cpp)
+        for (int b = 0; b < N; ++b)
+            if (is_cost_invalid<C>(costs_host[b])) return RNNT_STATUS_INVALID_VALUE;
     } else if (prof) {
         g_prof.pending = true;     // the caller synchronises, then calls rnnt_profile_collect()
     }
@@ -396,7 +421,7 @@ static rnntStatus_t run_gpu_joint(const float* f, const float* g, float* df, flo
                                   float* costs_device, const float* grad_scale, void* workspace,
                                   const rnntOptions& opt, int phases, bool want_grad, float fastemit = 0.0f) {
     Plan<float> p;
-    if (!make_plan(p, A, N, opt, workspace, labels, label_lengths, input_lengths, costs_device))
+    if (!make_plan(p, A, N, opt, workspace, labels, label_lengths, input_lengths, costs_device, /*joint=*/true))
         return RNNT_STATUS_INVALID_VALUE;
     if (!(fastemit >= 0.0f)) return RNNT_STATUS_INVALID_VALUE;
     p.fastemit = fastemit;
@@ -503,6 +528,9 @@ static bool bad_args(const void* acts, const int* labels, const int* label_lengt
 
 using namespace rnnt;
 
+// The library is compiled with -fvisibility=hidden: only the C entry points of include/rnnt.h are exported
+// (the reference exports exactly its five: nm -D of its libwarprnnt.so).
+#pragma GCC visibility push(default)
 extern "C" {
 
 int get_warprnnt_version() { return 1; }
@@ -524,9 +552,15 @@ rnntStatus_t get_workspace_size(int maxT, int maxU, int minibatch, bool gpu, siz
     if (minibatch <= 0 || maxT <= 0 || maxU <= 0 || size_bytes == nullptr) return RNNT_STATUS_INVALID_VALUE;
     const size_t lat = dtype_size >= 8 ? 8 : 4;
     if (gpu)
-        *size_bytes = make_layout(maxT, maxU, minibatch, lat).total;
+        *size_bytes = make_layout(maxT, maxU, minibatch, lat, false).total;
     else
         *size_bytes = cpu_workspace_bytes(maxT, maxU, minibatch, lat);
+    return RNNT_STATUS_SUCCESS;
+}
+
+rnntStatus_t get_workspace_size_add(int maxT, int maxU, int minibatch, size_t* size_bytes) {
+    if (minibatch <= 0 || maxT <= 0 || maxU <= 0 || size_bytes == nullptr) return RNNT_STATUS_INVALID_VALUE;
+    *size_bytes = make_layout(maxT, maxU, minibatch, 4, true).total;
     return RNNT_STATUS_SUCCESS;
 }
 
@@ -788,3 +822,4 @@ int rnnt_profile_read(double* ms, int n) {
 }
 
 }  // extern "C"
+#pragma GCC visibility pop

@@ -174,7 +174,7 @@ __global__ __launch_bounds__(S == 1 ? 256 : S * 64) void joint_z_kernel(
                              : static_cast<int>(blockIdx.x);
     const int tile = S == 1 ? group * 4 + wave : group;
     if (tile >= tiles) return;                             // S == 1 only: a whole wavefront leaves
-    const int Tb = xlen[b], Ub = ylen[b] + 1;
+    const int Tb = clamp_len(xlen[b], maxT), Ub = clamp_len(ylen[b] + 1, maxU);
     const int t0 = (tile / tilesU) * 32, u0 = (tile % tilesU) * 32;
     if (t0 >= Tb || u0 >= Ub) return;                      // tile of padding (block-uniform when S > 1)
     const float* mf = rowmax + static_cast<size_t>(b) * maxT;
@@ -385,7 +385,7 @@ __global__ __launch_bounds__(256) void joint_z_small_kernel(
     const int group = static_cast<int>((blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3));   // XCD-aware, as joint_z_kernel
     const int tile = group * 4 + wave;
     if (tile >= tiles) return;
-    const int Tb = xlen[b], Ub = ylen[b] + 1;
+    const int Tb = clamp_len(xlen[b], maxT), Ub = clamp_len(ylen[b] + 1, maxU);
     const int t0 = (tile / tilesU) * 32, u0 = (tile % tilesU) * 32;
     if (t0 >= Tb || u0 >= Ub) return;
     const float* mf = rowmax + static_cast<size_t>(b) * maxT;
@@ -578,7 +578,7 @@ __global__ __launch_bounds__(256) void joint_df_kernel(
     const int kc = k0 + NK * col;                          // first of this lane's NK columns
     const bool kin = kc < A;                               // A % NK == 0: all NK columns or none
     const int t0 = blockIdx.y * 32;
-    const int Tb = xlen[b], Ub = ylen[b] + 1;
+    const int Tb = clamp_len(xlen[b], maxT), Ub = clamp_len(ylen[b] + 1, maxU);
     const float* mf = rowmax + static_cast<size_t>(b) * maxT;
     const float* fb = f + static_cast<size_t>(b) * maxT * A + (kin ? kc : A - NK);   // lanes past the vocabulary read a valid column
     float* dfb = df + static_cast<size_t>(b) * maxT * A + kc;
@@ -726,7 +726,7 @@ __global__ __launch_bounds__(256) void joint_dg_kernel(
     const int kc = k0 + NK * col;
     const bool kin = kc < A;
     const int u0 = blockIdx.y * 32;
-    const int Tb = xlen[b], Ub = ylen[b] + 1;
+    const int Tb = clamp_len(xlen[b], maxT), Ub = clamp_len(ylen[b] + 1, maxU);
     const float* mg = rowmax + static_cast<size_t>(N) * maxT + static_cast<size_t>(b) * maxU;
     f32x16 acc[NK];
 #pragma unroll
@@ -820,7 +820,7 @@ __global__ __launch_bounds__(256) void joint_fix_kernel(
     const int b = blockIdx.z;
     const int lane = threadIdx.x & 63, wave = uniform(threadIdx.x >> 6);
     const int ub0 = blockIdx.x * 64, tb0 = blockIdx.y * kJointFixT;
-    const int Tb = xlen[b], Ub = ylen[b] + 1;
+    const int Tb = clamp_len(xlen[b], maxT), Ub = clamp_len(ylen[b] + 1, maxU);
     if (tb0 >= Tb || ub0 >= Ub) return;                    // block-uniform
     const int u = ub0 + lane;
     const bool uin = u < Ub, has_lab = u < Ub - 1;

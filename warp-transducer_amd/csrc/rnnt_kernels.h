@@ -58,6 +58,24 @@ __host__ __device__ inline int joint_upad(int maxU) { return (maxU + 7) & ~7; }
 
 // The skewed arrays carry kLatPad spare rows before diagonal 0 and after diagonal D-1 of every
 // sample, so the last (partial) chunk of a sweep can run its full C steps without bounds checks.
+// Cost written for a sample whose device-side lengths do not fit the tensor (T_b outside [1,maxT] or
+// U_b outside [1,maxU]): a quiet NaN with a recognisable payload.
+template <typename L> __host__ __device__ inline L cost_invalid();
+template <> __host__ __device__ inline float cost_invalid<float>() {
+    const unsigned int bits = 0x7fc0deadu; float f; __builtin_memcpy(&f, &bits, 4); return f;
+}
+template <> __host__ __device__ inline double cost_invalid<double>() {
+    const unsigned long long bits = 0x7ff8dead00000000ull; double d; __builtin_memcpy(&d, &bits, 8); return d;
+}
+template <typename L> inline bool is_cost_invalid(L v) {
+    const L m = cost_invalid<L>();
+    return __builtin_memcmp(&v, &m, sizeof(L)) == 0;
+}
+
+// Device-side lengths clamped to the tensor (see lattice_kernel: such a sample is flagged through its cost;
+// every kernel clamps so that nothing is read or written outside the caller's arrays).
+__device__ __forceinline__ int clamp_len(int v, int hi) { return v > hi ? hi : v; }
+
 constexpr int kLatPad = 16;
 __host__ __device__ inline size_t lat_rows(int maxT, int maxU) { return static_cast<size_t>(maxT) + maxU - 1 + 2 * kLatPad; }
 // element index of (b, n, u) in a skewed array with row stride Up
@@ -108,7 +126,7 @@ __global__ __launch_bounds__(WAVES * 64) void row_stats_kernel(
     const int lane = threadIdx.x & 63;
     const int q = uniform(blockIdx.x * WAVES + (threadIdx.x >> 6));
     if (q >= maxT * maxU) return;
-    const int Tb = xlen[b], Ub = ylen[b] + 1;
+    const int Tb = clamp_len(xlen[b], maxT), Ub = clamp_len(ylen[b] + 1, maxU);
     if (Tb <= 0 || Ub <= 0) return;
     // packed layout (offsets != nullptr, include/rnnt.h compute_rnnt_loss_packed): sample b is T_b * U_b
     // consecutive rows starting at row offsets[b], row (t, u) at t * U_b + u -- no padded rows exist
@@ -193,7 +211,7 @@ __global__ __launch_bounds__(256) void row_stats_block_kernel(
     const int b = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int q = blockIdx.x;
-    const int Tb = xlen[b], Ub = ylen[b] + 1;
+    const int Tb = clamp_len(xlen[b], maxT), Ub = clamp_len(ylen[b] + 1, maxU);
     if (Tb <= 0 || Ub <= 0) return;
     const int ustride = offsets != nullptr ? Ub : maxU;      // packed layout: see row_stats_kernel
     const int t = q / ustride, u = q - t * ustride;
@@ -331,9 +349,6 @@ __device__ __forceinline__ void tile_reduce_words(const W* __restrict__ words, i
 }
 
 constexpr int kTileMaxRowBytes = 2048;
-#ifndef RNNT_TILE_ABLATE
-#define RNNT_TILE_ABLATE 0     // development only: bit0 skips the LDS reduce phase, bit1 the global loads, bit2 the result stores
-#endif
 
 template <typename Tag, int G>
 __global__ __launch_bounds__(256) void row_stats_tile_kernel(
@@ -375,14 +390,12 @@ __global__ __launch_bounds__(256) void row_stats_tile_kernel(
     constexpr int kTilePk = 12;                            // packets per thread: tiles up to 48 KB
     uint4 pk[kTilePk];
     const u32x4* src = reinterpret_cast<const u32x4*>(base + head);
-    if (!(RNNT_TILE_ABLATE & 2)) {
 #pragma unroll
-        for (int i = 0; i < kTilePk; ++i)
-            if (i * 256 < nbody) {                         // block-uniform
-                const int pi = i * 256 + static_cast<int>(threadIdx.x);
-                pk[i] = load_packet<true>(src + (pi < nbody ? pi : nbody - 1));
-            }
-    }
+    for (int i = 0; i < kTilePk; ++i)
+        if (i * 256 < nbody) {                             // block-uniform
+            const int pi = i * 256 + static_cast<int>(threadIdx.x);
+            pk[i] = load_packet<true>(src + (pi < nbody ? pi : nbody - 1));
+        }
     __builtin_amdgcn_sched_barrier(0);                     // the packets go out before the index arithmetic below
     // The row's position, lengths and label: requested right behind the tile's packets, by every lane,
     // as three independent loads (the label index is clamped instead of depending on the lengths), so
@@ -400,7 +413,7 @@ __global__ __launch_bounds__(256) void row_stats_tile_kernel(
         b = b < nb ? b : nb - 1;                           // lanes past the last row: any valid sample
         t = static_cast<int>(q / static_cast<unsigned>(maxU));
         u = static_cast<int>(q) - t * maxU;
-        Tb = xlen[b]; Ub = ylen[b] + 1;
+        Tb = clamp_len(xlen[b], maxT); Ub = clamp_len(ylen[b] + 1, maxU);
     } else {
         // Packed layout: the sample of the tile's first row by a block-uniform (scalar) binary search over the
         // cumulative row offsets, its neighbour's data as scalars too; a lane's row is in one of the two unless
@@ -413,7 +426,7 @@ __global__ __launch_bounds__(256) void row_stats_tile_kernel(
         const int b1 = lo + 1 < N ? lo + 1 : lo;
         const unsigned long long o0 = static_cast<unsigned long long>(offsets[lo]);
         const unsigned long long o1 = static_cast<unsigned long long>(offsets[lo + 1]);
-        const int T0 = xlen[lo], U0 = ylen[lo] + 1, T1 = xlen[b1], U1 = ylen[b1] + 1;
+        const int T0 = clamp_len(xlen[lo], maxT), U0 = clamp_len(ylen[lo] + 1, maxU), T1 = clamp_len(xlen[b1], maxT), U1 = clamp_len(ylen[b1] + 1, maxU);
         const unsigned long long r = r0 + static_cast<unsigned>(rl);
         unsigned long long ob = o0;
         b = lo; Tb = T0; Ub = U0;
@@ -422,7 +435,7 @@ __global__ __launch_bounds__(256) void row_stats_tile_kernel(
             if (b + 1 < N && r >= static_cast<unsigned long long>(offsets[b + 1])) {
                 while (b + 1 < N && r >= static_cast<unsigned long long>(offsets[b + 1])) ++b;
                 ob = static_cast<unsigned long long>(offsets[b]);
-                Tb = xlen[b]; Ub = ylen[b] + 1;
+                Tb = clamp_len(xlen[b], maxT); Ub = clamp_len(ylen[b] + 1, maxU);
             }
         }
         const unsigned q = static_cast<unsigned>(r - ob);  // rows past the end: t >= Tb, never stored
@@ -431,7 +444,7 @@ __global__ __launch_bounds__(256) void row_stats_tile_kernel(
         u = static_cast<int>(q - static_cast<unsigned>(t) * us);
     }
     int lab = labels[maxU > 1 ? static_cast<size_t>(b) * (maxU - 1) + (u < maxU - 1 ? u : maxU - 2) : 0];
-    if (!(RNNT_TILE_ABLATE & 2)) {
+    {
         uint4* dst = tile_raw + (phase + head) / V;
 #pragma unroll
         for (int i = 0; i < kTilePk; ++i) {
@@ -445,7 +458,6 @@ __global__ __launch_bounds__(256) void row_stats_tile_kernel(
 
     // ---- G lanes per row
     if (rl >= nrows) return;                                   // whole lane groups leave together
-    if ((RNNT_TILE_ABLATE & 1) && threadIdx.x != 9999) { if (tile[phase + threadIdx.x] == S(12345)) logz[0] = 1; return; }
     const S* rowp = tile + phase + rl * A;
     C m = neg_inf<C>(), sum = 0, shift = 0;
     constexpr int H = V / 2;                                   // elements per 8-byte LDS read
@@ -490,14 +502,10 @@ __global__ __launch_bounds__(256) void row_stats_tile_kernel(
         LogPair<C> rec;                            // lattice log-probs are kept in base 2
         rec.x = vmax((load1<Tag>(rowp + blank) - logZ) * C(kLog2e), log_zero<C>());
         rec.y = has_lab ? vmax((load1<Tag>(rowp + lab) - logZ) * C(kLog2e), log_zero<C>()) : log_zero<C>();
-        if ((RNNT_TILE_ABLATE & 4) && rec.x != C(12345)) {
-            // development only: results computed, not stored
-        } else {
-            // two scattered stores per row: they combine into full lines in the XCD's L2 (tile order above)
-            const size_t idx = lat_index(b, t + u, u, maxT, maxU, Up);
-            lp2[idx] = rec;
-            logz[idx] = logZ;
-        }
+        // two scattered stores per row: they combine into full lines in the XCD's L2 (tile order above)
+        const size_t idx = lat_index(b, t + u, u, maxT, maxU, Up);
+        lp2[idx] = rec;
+        logz[idx] = logZ;
     }
 }
 
@@ -536,9 +544,6 @@ __global__ __launch_bounds__(256) void row_stats_tile_kernel(
 template <typename L, int MAXW> struct LatChunk {
     static constexpr int C = (sizeof(L) == 4 ? 16 : 8) / (MAXW > 8 ? 2 : 1);
 };
-#ifndef RNNT_LAT_ABLATE
-#define RNNT_LAT_ABLATE 0      // development only: bit0 drops the lattice stores, bit1 the loads
-#endif
 
 typedef unsigned int lat_u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int lat_u32x4 __attribute__((ext_vector_type(4)));
@@ -592,7 +597,13 @@ __global__ __launch_bounds__(MAXW * 64) void lattice_kernel(
     const int lane = u & 63;
     const int wave = uniform(u >> 6);
     const int W = blockDim.x >> 6;
-    const int Tb = xlen[b], Ub = ylen[b] + 1;
+    // Lengths live on the device, so the host cannot validate them (the CPU location does: rnnt_cpu.cpp).  A
+    // sample whose lengths do not fit the tensor is run on clamped lengths (memory-safe) and its cost becomes
+    // the marker NaN of cost_invalid(), which the synchronous entry points turn into RNNT_STATUS_INVALID_VALUE.
+    const int Tb_raw = xlen[b], Ub_raw = ylen[b] + 1;
+    const bool bad_len = Tb_raw < 1 || Ub_raw < 1 || Tb_raw > maxT || Ub_raw > maxU;
+    const int Tb = Tb_raw < 1 ? 1 : (Tb_raw > maxT ? maxT : Tb_raw);
+    const int Ub = Ub_raw < 1 ? 1 : (Ub_raw > maxU ? maxU : Ub_raw);
     const int Db = Tb + Ub - 1;
     const size_t Dp = lat_rows(maxT, maxU);
     // descriptors start at the first PAD row of this sample: row n lives at (n + kLatPad)
@@ -622,12 +633,10 @@ __global__ __launch_bounds__(MAXW * 64) void lattice_kernel(
         if (u == 0) IO::store(rb, vb, kLatPad * beta_row, L(0));
         if (lane == 0) off[0] = 0.0;
         auto fetch = [&](int j, L* xb, L* xl) {     // chunk j: diagonals j*C+1 .. j*C+C read SOURCE rows j*C .. j*C+C-1
-            if (RNNT_LAT_ABLATE & 2) { for (int k = 0; k < C; ++k) { xb[k] = L(-1.5); xl[k] = L(-2.5); } return; }
 #pragma unroll
             for (int k = 0; k < C; ++k) IO::load_xy(rc, vc, (j * C + k + kLatPad) * cell_row, xb[k], xl[k]);
         };
         auto flush = [&]() {                        // results of chunk jprev (issued BEFORE the next prefetch)
-            if (RNNT_LAT_ABLATE & 1) return;
 #pragma unroll
             for (int k = 0; k < C; ++k) IO::store(rb, vb, (jprev * C + 1 + k + kLatPad) * beta_row, hist[k]);
             if (lane < C) off[jprev * C + 1 + lane] = Cused;
@@ -697,7 +706,7 @@ __global__ __launch_bounds__(MAXW * 64) void lattice_kernel(
             IO::load_xy(rc, vc, (Db - 1 + kLatPad) * cell_row, xb_, xl_);
             const double ll2 = static_cast<double>(a_last) + o_last + static_cast<double>(xb_);
             ll_fwd[b] = ll2;                                  // base 2, for the coefficient kernel
-            costs_dev[b] = static_cast<L>(-ll2 * kLn2);
+            costs_dev[b] = bad_len ? cost_invalid<L>() : static_cast<L>(-ll2 * kLn2);
         }
     } else {
         // ------------------------------- beta -------------------------------
@@ -709,12 +718,10 @@ __global__ __launch_bounds__(MAXW * 64) void lattice_kernel(
         }
         if (lane == 0) off[Db - 1] = 0.0;
         auto fetch = [&](int j, L* xb, L* xl) {     // chunk j: steps i = j*C .. j*C+C-1, TARGET rows n = Db-2-i
-            if (RNNT_LAT_ABLATE & 2) { for (int k = 0; k < C; ++k) { xb[k] = L(-1.5); xl[k] = L(-2.5); } return; }
 #pragma unroll
             for (int k = 0; k < C; ++k) IO::load_xy(rc, vc, (Db - 2 - (j * C + k) + kLatPad) * cell_row, xb[k], xl[k]);
         };
         auto flush = [&]() {
-            if (RNNT_LAT_ABLATE & 1) return;
 #pragma unroll
             for (int k = 0; k < C; ++k) IO::store(rb, vb, (Db - 2 - (jprev * C + k) + kLatPad) * beta_row, hist[k]);
             if (lane < C) off[Db - 2 - (jprev * C + lane)] = Cused;
@@ -877,7 +884,7 @@ __global__ __launch_bounds__(256) void coef_cell_kernel(
     const int t = n - u;
     const size_t plane = static_cast<size_t>(gridDim.y) * maxT * Upad;      // gridDim.y = N
     if (u >= maxU || t < 0 || t >= maxT) return;              // not a row of the tensor
-    const int Tb = xlen[b], Ub = ylen[b] + 1;
+    const int Tb = clamp_len(xlen[b], maxT), Ub = clamp_len(ylen[b] + 1, maxU);
     const Cell<L> o = coef_cell<L>(lp2, logz, alpha_arr, beta, offa, offb, ll_fwd, labels, b, n, t, u, Tb, Ub, maxT, maxU,
                                    Up, fastemit);
     if (offsets != nullptr) {
@@ -922,7 +929,7 @@ __global__ __launch_bounds__(256) void coef_kernel(
     const int tu = static_cast<int>(blockIdx.x) % tilesU, tn = static_cast<int>(blockIdx.x) / tilesU;
     const int n0 = tn * DN, u0 = tu * 64;
     const int D = maxT + maxU - 1;
-    const int Tb = xlen[b], Ub = ylen[b] + 1;
+    const int Tb = clamp_len(xlen[b], maxT), Ub = clamp_len(ylen[b] + 1, maxU);
 
     // ---- compute, skewed order
     {

@@ -62,7 +62,13 @@ class _RNNT(Function):
             grads = torch.empty_like(acts) if acts.requires_grad else torch.zeros(0).to(acts)
             loss_func = warp_rnnt.gpu_rnnt if is_cuda else warp_rnnt.cpu_rnnt
             costs = torch.zeros(minibatch_size, dtype=cost_dtype)   # host, as the C-ABI requires
-            loss_func(acts, labels, act_lens, label_lens, costs, grads, blank, 0)
+            # cpu_rnnt / gpu_rnnt keep the reference extension module's behaviour for an unsupported dtype
+            # (a line on stderr and -1, binding.cpp:46-81,111-153), which the reference wrapper ignores and
+            # then returns a zero loss with zero gradients; here nothing would have been written at all, so
+            # it is an error.
+            if loss_func(acts, labels, act_lens, label_lens, costs, grads, blank, 0) != 0:
+                raise TypeError("rnnt_loss: unsupported dtype %s for the %s location"
+                                % (acts.dtype, "GPU" if is_cuda else "CPU"))
 
         if reduction in ['sum', 'mean']:
             costs = costs.sum().unsqueeze_(-1)
@@ -86,8 +92,10 @@ class _RNNT(Function):
             grads = torch.empty_like(acts)
             warp_rnnt.gpu_rnnt_bwd(acts, grads, scale, ctx.workspace, ctx.blank)
             return grads, None, None, None, None, None, None
+        # out of place (the reference scales the saved tensor in place, __init__.py:47-50, so a second
+        # backward through a retained graph compounds the factors and gradcheck fails)
         grad_output = grad_output.view(-1, 1, 1, 1).to(ctx.grads)
-        return ctx.grads.mul_(grad_output), None, None, None, None, None, None
+        return ctx.grads * grad_output, None, None, None, None, None, None
 
 
 def rnnt_loss(acts, labels, act_lens, label_lens, blank=0, reduction='mean', fastemit_lambda=0.0):

@@ -52,6 +52,7 @@ EXPORTS = {
                                                _PTR, rnntOptions, C.c_int, C.c_int, C.c_float]),
     "compute_rnnt_loss_packed_bwd": (C.c_int, [_PTR, _PTR, _PTR, _PTR, C.c_longlong, C.c_int, C.c_int, _PTR,
                                                rnntOptions, C.c_int]),
+    "get_workspace_size_add": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_size_t)]),
     "compute_rnnt_loss_add": (C.c_int, [_PTR, _PTR, _PTR, _PTR, _PTR, _PTR, _PTR, C.c_int, C.c_int, _PTR, _PTR,
                                         rnntOptions]),
     "compute_rnnt_loss_add_fwd": (C.c_int, [_PTR, _PTR, _PTR, _PTR, _PTR, C.c_int, C.c_int, _PTR, _PTR, rnntOptions,
@@ -108,4 +109,11 @@ def workspace_bytes(maxT, maxU, minibatch, gpu, dtype_size):
     n = C.c_size_t(0)
     check(lib().get_workspace_size(int(maxT), int(maxU), int(minibatch), bool(gpu), C.byref(n),
                                    int(dtype_size)), "get_workspace_size")
+    return n.value
+
+
+def workspace_bytes_add(maxT, maxU, minibatch):
+    """Workspace of the additive-joint entries (compute_rnnt_loss_add*)."""
+    n = C.c_size_t(0)
+    check(lib().get_workspace_size_add(int(maxT), int(maxU), int(minibatch), C.byref(n)), "get_workspace_size_add")
     return n.value

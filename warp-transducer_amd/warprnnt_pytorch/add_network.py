@@ -63,7 +63,7 @@ class _RNNTAdd(Function):
         dev = trans_acts.device
         with torch.cuda.device(dev):
             costs = torch.empty(B, dtype=torch.float32, device=dev)
-            ws = torch.empty(_lib.workspace_bytes(T, U, B, True, 4), dtype=torch.uint8, device=dev)
+            ws = torch.empty(_lib.workspace_bytes_add(T, U, B), dtype=torch.uint8, device=dev)
             opt = _lib.rnntOptions(loc=_lib.RNNT_GPU, num_threads=0,
                                    stream=torch.cuda.current_stream(dev).cuda_stream, blank_label=int(blank),
                                    maxT=T, maxU=U, batch_first=True)

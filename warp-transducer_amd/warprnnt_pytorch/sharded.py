@@ -37,7 +37,8 @@ class _ShardedRNNT(Function):
         else:
             costs = torch.zeros(n, dtype=cost_dtype)
             grads = torch.empty_like(acts) if acts.requires_grad else torch.zeros(0).to(acts)
-            warp_rnnt.cpu_rnnt(acts, labels, act_lens, label_lens, costs, grads, blank, 0)
+            if warp_rnnt.cpu_rnnt(acts, labels, act_lens, label_lens, costs, grads, blank, 0) != 0:
+                raise TypeError("sharded_rnnt_loss: unsupported dtype %s for the CPU location" % acts.dtype)
         distributed = dist.is_available() and dist.is_initialized()
         ctx.scale = 1.0
         if reduction == "none":
@@ -78,7 +79,7 @@ class _ShardedRNNT(Function):
         g = g.reshape(-1, 1, 1, 1).to(ctx.grads)
         if not isinstance(ctx.scale, float) or ctx.scale != 1.0:
             g = g * ctx.scale
-        return ctx.grads.mul_(g.to(ctx.grads.dtype)), None, None, None, None, None, None
+        return ctx.grads * g.to(ctx.grads.dtype), None, None, None, None, None, None
 
 
 def sharded_rnnt_loss(acts, labels, act_lens, label_lens, blank=0, reduction="mean", group=None):

@@ -112,6 +112,8 @@ def gpu_rnnt_fwd(acts, labels, input_lengths, label_lengths, costs_device, blank
     gradient-coefficient table `gpu_rnnt_bwd` needs and must be kept (untouched) until then.  Enqueue only."""
     lib = _lib.lib()
     N, T, U, A = acts.shape
+    if acts.dtype not in _DT:
+        raise TypeError("rnnt_loss: unsupported dtype %s for the GPU location" % acts.dtype)
     code, esz = _DT[acts.dtype]
     with torch.cuda.device(acts.device):
         ws = torch.empty(_lib.workspace_bytes(T, U, N, True, esz), dtype=torch.uint8, device=acts.device)

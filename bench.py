@@ -1,8 +1,12 @@
 #!/usr/bin/env python
 """bench.py -- RNN-T loss+grad hot path on MI355X: ms/batch and fraction of the HBM roofline.
 
-Contract (driver):  python bench.py --gpus N --steps K --warmup W   (N>1: launched by
-torch.distributed.run, one rank per GPU, RCCL).  Rank 0 prints ONE JSON line.
+Contract (driver):  python bench.py --gpus N --steps K --warmup W.  Rank 0 prints ONE JSON line.
+N>1: one rank per GPU over RCCL.  Either the driver launches the ranks itself
+(python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N: WORLD_SIZE is set and must
+equal N), or a plain `python bench.py --gpus N` re-launches itself under torch.distributed.run on
+127.0.0.1.  Fewer than N visible devices is an error (exit code 2) -- never a silent 1-GPU run.
+N=1 defaults to c3 (the headline configuration), N>1 to c5 (BASELINE config 5: bf16, 128 samples per GPU).
 
 A "step" = one pass of the hot path over one synthetic batch already resident in HBM:
 `compute_rnnt_loss` of include/rnnt.h with gradients (row statistics -> lattice -> coefficients
@@ -78,30 +82,70 @@ def algorithmic_bytes(w, valid_rows=None, packed=False):
 
 def cpu_baseline(w, acts, labels, act_lens, label_lens, budget_samples):
     """The REFERENCE's own CPU path (oracle/_ref, compiled from /root/reference) on the host
-    cores of this box, on a bounded sample of the same workload.  Input = log-probs (the
-    reference CPU contract), so log_softmax is not in its time."""
+    cores of this box, on a bounded sample of the same workload (last row).  Three legs:
+      value             all host cores, the reference CPU contract (log-probs in, sparse log-prob
+                        gradients out: log_softmax is NOT in its time) -- tests/test_time.cpp's measurement
+      single_thread     the same call with num_threads = 1 on a smaller slice
+      with_log_softmax  like for like with the GPU path (logits in, dense logit gradients out):
+                        torch.log_softmax forward + the reference call + log_softmax backward, all cores"""
     from oracle import oracle as O
-    n = min(w["N"], budget_samples)
-    lp = torch.cat([torch.log_softmax(acts[i:i + 16].float(), -1).cpu() for i in range(0, n, 16)]).numpy()
+    N = w["N"]
+    n = min(N, budget_samples)
+    x = torch.cat([acts[i:i + 16].float().cpu() for i in range(0, n, 16)])
+    lp_t = torch.log_softmax(x, -1)
+    lp = lp_t.numpy()
     lab, tl, ll = labels[:n].cpu().numpy(), act_lens[:n].cpu().numpy(), label_lens[:n].cpu().numpy()
     cores = os.cpu_count() or 1
     threads = min(cores, n)
     if O.have_ref():
-        kind, fn = "reference", lambda: O.ref_rnnt_logprobs(lp, lab, tl, ll, 0, True, threads)
+        kind = "reference"
+
+        def call(lpa, k, nthreads, want_grads=False):
+            return O.ref_rnnt_logprobs(lpa[:k], lab[:k], tl[:k], ll[:k], 0, True, nthreads)
     else:
-        O.lib().oracle_set_num_threads(threads)
-        kind, fn = "port", lambda: O.rnnt_logprobs(lp, lab, tl, ll, 0, True)
-    fn()   # page-fault warm-up (the reference harness pays it inside its timing: BASELINE.md 3)
-    times = []
-    for _ in range(3):
-        t0 = time.perf_counter()
-        fn()
-        times.append((time.perf_counter() - t0) * 1e3)
-    ms = float(np.median(times)) * (w["N"] / n)
-    return dict(value=round(ms, 3), unit="ms/batch", cores=threads, kind=kind,
-                sample="%d of %d samples (T=%d,U=%d,A=%d, fp32 log-probs in, sparse log-prob grads out), "
+        kind = "port"
+
+        def call(lpa, k, nthreads, want_grads=False):
+            O.lib().oracle_set_num_threads(nthreads)
+            return O.rnnt_logprobs(lpa[:k], lab[:k], tl[:k], ll[:k], 0, True)
+
+    def timed(fn, reps=3):
+        fn()   # page-fault warm-up (the reference harness pays it inside its timing: BASELINE.md 3)
+        times = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            fn()
+            times.append((time.perf_counter() - t0) * 1e3)
+        return float(np.median(times))
+
+    ms_all = timed(lambda: call(lp, n, threads)) * (N / n)
+    # one thread: a slice sized to a few seconds (the whole-batch call above took ms_all on `threads` threads)
+    n1 = max(1, min(n, int(n * 4000.0 / max(ms_all * (n / N) * threads, 1.0))))
+    ms_one = timed(lambda: call(lp, n1, 1), reps=2) * (N / n1)
+
+    # like for like: logits -> loss + dense logit gradients
+    n2 = min(n, 32)
+    torch.set_num_threads(threads)
+
+    def full():
+        xx = x[:n2].clone().requires_grad_(True)
+        l = torch.log_softmax(xx, -1)
+        _, g_lp = call(l.detach().numpy(), n2, min(threads, n2))
+        l.backward(torch.from_numpy(np.ascontiguousarray(g_lp)))
+        return xx.grad
+    ms_full = timed(full, reps=2) * (N / n2)
+    shape = "T=%d,U=%d,A=%d" % (w["T"], w["L"] + 1, w["A"])
+    return dict(value=round(ms_all, 3), unit="ms/batch", cores=threads, kind=kind,
+                sample="%d of %d samples (%s, fp32 log-probs in, sparse log-prob grads out), "
                        "median of 3 warmed calls, scaled x%.2f to the full batch; host has %d cores"
-                       % (n, w["N"], w["T"], w["L"] + 1, w["A"], w["N"] / n, cores))
+                       % (n, N, shape, N / n, cores),
+                single_thread=dict(value=round(ms_one, 3), unit="ms/batch", cores=1,
+                                   sample="%d of %d samples, median of 2 warmed calls, scaled x%.2f" % (n1, N, N / n1)),
+                with_log_softmax=dict(value=round(ms_full, 3), unit="ms/batch", cores=threads,
+                                      sample="%d of %d samples: torch.log_softmax forward + reference CPU call + "
+                                             "log_softmax backward (logits in, dense logit grads out, the GPU "
+                                             "path's contract), median of 2 warmed calls, scaled x%.2f"
+                                             % (n2, N, N / n2)))
 
 
 def main():
@@ -109,7 +153,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS),
+                    help="default: c3 on one GPU (the headline configuration), c5 when --gpus > 1")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-samples", type=int, default=128)
     ap.add_argument("--extra", action="store_true", help="also time the other single-GPU workloads")
@@ -122,12 +167,36 @@ def main():
     ap.add_argument("--force-sharded", action="store_true",
                     help="dev: run the multi-GPU step (async entry + RCCL all-reduce) even with one rank")
     args = ap.parse_args()
+    if args.gpus < 1:
+        ap.error("--gpus must be >= 1")
+    if args.workload is None:
+        args.workload = "c3" if args.gpus == 1 else "c5"
 
+    if not torch.cuda.is_available():
+        print("bench.py needs an MI355X: the HIP path has no CPU fallback", file=sys.stderr)
+        raise SystemExit(2)
+    ndev = torch.cuda.device_count()
+    if ndev < args.gpus:
+        print("bench.py: --gpus %d asked for, %d device(s) visible -- refusing to run on fewer GPUs than requested"
+              % (args.gpus, ndev), file=sys.stderr)
+        raise SystemExit(2)
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # plain `python bench.py --gpus N`: become the launcher of N ranks (one per GPU, RCCL), rendezvous on
+        # 127.0.0.1 (the container's hostname may not resolve)
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    if world != args.gpus:
+        print("bench.py: --gpus %d but the launcher started %d rank(s)" % (args.gpus, world), file=sys.stderr)
+        raise SystemExit(2)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     sharded = world > 1 or args.force_sharded
@@ -199,13 +268,14 @@ def main():
             code = {"fp32": _lib.DT_F32, "bf16": _lib.DT_BF16}[w["dtype"]]
             argv = (acts.data_ptr(), grads.data_ptr(), labels.data_ptr(), label_lens.data_ptr(),
                     act_lens.data_ptr(), A, N, costs.data_ptr(), None, ws.data_ptr(), opt, code)
+            packed = torch.zeros(2, dtype=torch.float64, device=dev)     # [summed loss, sample count]
 
             def step():
                 st = lib.compute_rnnt_loss_async(*argv)
                 assert st == 0, _lib.status_string(st)
-                packed = torch.stack([costs.sum(dtype=torch.float64),
-                                      torch.tensor(float(N), dtype=torch.float64, device=dev)])
-                dist.all_reduce(packed)
+                torch.sum(costs, dtype=torch.float64, out=packed[0])
+                packed[1] = float(N)
+                dist.all_reduce(packed)          # the one collective of the data path (RCCL over xGMI)
                 torch.cuda.synchronize(dev)
                 lib.rnnt_profile_collect()
                 return packed
@@ -218,13 +288,16 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
         t0 = time.perf_counter()
+        marks = []
         for _ in range(steps):
-            out = step()
+            out = step()                          # every form of step() ends with a device synchronisation
+            marks.append(time.perf_counter())
         torch.cuda.synchronize(dev)
         if sharded:
             dist.barrier()
         elapsed = time.perf_counter() - t0
         lib.rnnt_profile_enable(0)
+        per_step = np.diff(np.array([t0] + marks)) * 1e3
         if sharded:
             tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -236,6 +309,9 @@ def main():
         valid_rows = int((act_lens.long() * (label_lens.long() + 1)).sum().item()) if args.varlen else None
         ab = algorithmic_bytes(w, valid_rows, args.packed)
         res = dict(workload=name, ms_per_step=ms_step, stage_ms=stage_ms, bytes=ab, w=w,
+                   step_ms=dict(median=round(float(np.median(per_step)), 4), p10=round(float(np.percentile(per_step, 10)), 4),
+                                p90=round(float(np.percentile(per_step, 90)), 4), n=int(per_step.size),
+                                note="per-step wall clock on rank 0 (each step ends in a device sync)"),
                    loss_sum=float(out.sum()) if not sharded else float(out[0]))
         if with_cpu and rank == 0 and not args.packed:
             res["cpu"] = cpu_baseline(w, acts, labels, act_lens, label_lens, args.cpu_samples)
@@ -261,6 +337,7 @@ def main():
                    "parallelism": "batch-sharded x%d, one RCCL all-reduce of the summed loss" % world
                    if world > 1 else "single GPU"},
         "samples_per_s": round(w["N"] * world / (ms * 1e-3), 1),
+        "step_ms": r["step_ms"],
         "path_roofline": {"bound": "hbm", "achieved": round(ab["path"] / (ms * 1e-3) / 1e9, 1),
                           "peak": HBM_PEAK_GBS, "unit": "GB/s",
                           "frac": round(ab["path"] / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
@@ -271,18 +348,21 @@ def main():
         sm = r["stage_ms"]
         gk = sm[3]
         traffic = None
-        try:   # PMC-measured HBM bytes per launch of this kernel, from the committed rocprofv3 passes
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
+        traffic_file = None
+        try:   # PMC-measured HBM bytes per launch of this kernel, from the committed rocprofv3 passes (newest round)
+            import glob
+            traffic_file = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))[-1]
+            tj = json.load(open(traffic_file))
             if not args.override and not args.varlen:
                 traffic = tj[args.workload]["grad_flat_kernel"]["traffic_bytes"]
-        except (OSError, KeyError, ValueError):
+        except (OSError, KeyError, ValueError, IndexError):
             pass
         out["roofline"] = {"bound": "hbm", "kernel": "grad_flat_kernel (second read of the logits + dense gradient write-back)",
                            "achieved": round(ab["grad_kernel"] / (gk * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS,
                            "unit": "GB/s", "frac": round(ab["grad_kernel"] / (gk * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                            "traffic": traffic, "bytes_algo": ab["grad_kernel"], "avg_ms": round(gk, 4),
-                           "traffic_source": "profiles/r01_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)"
-                           if traffic else None}
+                           "traffic_source": "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)"
+                           % os.path.basename(traffic_file) if traffic else None}
         out["stage_ms"] = {"row_stats": round(sm[0], 4), "lattice": round(sm[1], 4), "coef": round(sm[2], 4),
                            "grad": round(sm[3], 4), "enqueue_span": round(sm[4], 4)}
         out["stats_roofline"] = {"achieved": round(ab["stats_kernel"] / (sm[0] * 1e-3) / 1e9, 1),

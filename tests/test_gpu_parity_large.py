@@ -1,0 +1,218 @@
+"""-m gpu: parity at BASELINE.json's full sizes on the REFERENCE's input streams, past 2^31 elements, at the
+lattice kernels' structural limits, and the validation the reference leaves undefined.
+
+Tolerances (BASELINE.json north_star; SURVEY.md 8c "tolerance floor"): loss within 1e-4 RELATIVE of the fp64
+oracle, gradients within 1e-3 absolute for fp32 storage; bf16 storage 4e-3 = half a bf16 ulp at |g| ~ 1 (2^-8),
+the quantum of the STORAGE type -- the arithmetic is the same fp32 as for fp32 storage."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from tests.test_gpu_parity import run_gpu
+
+pytestmark = pytest.mark.gpu
+
+
+def _ref_stream_batch(oracle, n_ref, N, T, U, A, dev):
+    """A (N,T,U,A) fp32 batch whose first `n_ref` samples are the head of the reference harness's mt19937(0)
+    stream (tests/random.cpp:4-12: batch is the slowest dimension, so these ARE its samples 0..n_ref-1); the rest
+    is device-generated uniform(0,1).  Labels: genLabels(A, L) for every sample (tests/test_time.cu:52-58)."""
+    x = torch.empty((N, T, U, A), dtype=torch.float32, device=dev)
+    head = oracle.gen_acts(n_ref * T * U * A).reshape(n_ref, T, U, A)
+    x[:n_ref] = torch.from_numpy(head).to(dev)
+    if n_ref < N:
+        g = torch.Generator(device=dev).manual_seed(99)
+        x[n_ref:] = torch.rand((N - n_ref, T, U, A), generator=g, device=dev)
+    lab = oracle.gen_labels(A, U - 1)
+    labels = np.tile(lab, (N, 1)).astype(np.int32)
+    return x, head, labels
+
+
+def _gpu_call(x, labels, tl, ll):
+    from warprnnt_pytorch import warp_rnnt
+    dev = x.device
+    costs = torch.zeros(x.shape[0])
+    grads = torch.full_like(x, 7.0)
+    assert warp_rnnt.gpu_rnnt(x, torch.tensor(labels, device=dev), torch.tensor(tl, device=dev),
+                              torch.tensor(ll, device=dev), costs, grads, 0, 0) == 0
+    return costs, grads
+
+
+def test_c2_whole_batch_on_the_reference_stream(oracle):
+    """BASELINE config 2 (README row N=16,T=150,L=40,A=28) exactly as tests/test_time.cu feeds it: every element
+    of the batch from the reference's generators, every sample against the fp64 oracle."""
+    N, T, U, A = 16, 150, 41, 28
+    dev = torch.device("cuda:0")
+    x, head, labels = _ref_stream_batch(oracle, N, N, T, U, A, dev)
+    tl, ll = np.full(N, T, np.int32), np.full(N, U - 1, np.int32)
+    costs, grads = _gpu_call(x, labels, tl, ll)
+    ref_c, ref_g = oracle.rnnt_logits(head.astype(np.float64), labels, tl, ll)
+    assert np.abs(costs.double().numpy() - ref_c).max() <= 1e-4 * np.abs(ref_c).max()
+    assert np.abs(grads.double().cpu().numpy() - ref_g).max() < 1e-4
+    # the reference library itself (fp32 CPU path + log_softmax + chain rule) where it is available
+    if oracle.have_ref():
+        lp = oracle.log_softmax(head.astype(np.float64)).astype(np.float32)
+        rc, rg = oracle.ref_rnnt_logprobs(lp, labels, tl, ll, 0, True, 4)
+        assert np.abs(costs.numpy() - rc).max() <= 1e-4 * np.abs(rc).max()
+        rgl = oracle.chain_rule_to_logits(lp.astype(np.float64), rg.astype(np.float64))
+        assert np.abs(grads.double().cpu().numpy() - rgl).max() < 1e-3
+
+
+@pytest.mark.parametrize("name,shape", [("c3", (128, 150, 21, 5000)), ("c4", (64, 1500, 301, 50))])
+def test_full_size_eight_samples_on_the_reference_stream(oracle, name, shape):
+    """c3 / c4 at full batch size: the first 8 samples are the reference harness's own stream and are checked
+    against the fp64 oracle, with variable lengths on top (T_b, U_b of the checked samples span the range)."""
+    N, T, U, A = shape
+    dev = torch.device("cuda:0")
+    K = 8
+    x, head, labels = _ref_stream_batch(oracle, K, N, T, U, A, dev)
+    rng = np.random.default_rng(4)
+    tl = rng.integers(T // 2, T + 1, size=N).astype(np.int32)
+    ll = rng.integers((U - 1) // 2, U, size=N).astype(np.int32)
+    tl[0], ll[0] = T, U - 1
+    tl[1], ll[1] = T, (U - 1) // 2
+    tl[2], ll[2] = T // 2, U - 1
+    costs, grads = _gpu_call(x, labels, tl, ll)
+    oracle.lib().oracle_set_num_threads(8)
+    ref_c, ref_g = oracle.rnnt_logits(head.astype(np.float64), labels[:K], tl[:K], ll[:K])
+    got_c, got_g = costs[:K].double().numpy(), grads[:K].double().cpu().numpy()
+    assert np.abs(got_c - ref_c).max() <= 1e-4 * np.abs(ref_c).max()
+    assert np.abs(got_g - ref_g).max() < 1e-3
+    assert torch.isfinite(costs).all()
+    assert grads.sum(-1).abs().max().item() < 2e-4                     # every row of the logit gradient sums to 0
+
+
+def test_more_than_2_31_elements_on_one_gpu(oracle):
+    """BASELINE config 5 UNSHARDED: N=1024,T=200,U=41,A=1024 bf16 = 8.6e9 elements (the reference indexes with
+    32-bit int: include/detail/gpu_rnnt_kernel.h:7-8,161,174).  17.2 GB of logits + 17.2 GB of gradients on one
+    288 GB MI355X; oracle on samples {0, 511, 1023}; row sums and padding over the whole tensor."""
+    N, T, U, A = 1024, 200, 41, 1024
+    dev = torch.device("cuda:0")
+    free, _ = torch.cuda.mem_get_info(dev)
+    if free < 60e9:
+        pytest.skip("needs ~45 GB of free HBM")
+    from warprnnt_pytorch import warp_rnnt
+    g = torch.Generator(device=dev).manual_seed(8)
+    x = torch.empty((N, T, U, A), dtype=torch.bfloat16, device=dev)
+    for i in range(0, N, 64):                                          # generated slab by slab (no 34 GB fp32 temporary)
+        x[i:i + 64] = torch.rand((64, T, U, A), generator=g, device=dev).to(torch.bfloat16)
+    assert x.numel() > 2 ** 31
+    labels = torch.randint(1, A, (N, U - 1), generator=g, device=dev, dtype=torch.int32)
+    tl = torch.randint(T // 2, T + 1, (N,), generator=g, device=dev, dtype=torch.int32)
+    ll = torch.randint((U - 1) // 2, U, (N,), generator=g, device=dev, dtype=torch.int32)
+    tl[0], ll[0] = T, U - 1
+    tl[N - 1], ll[N - 1] = T, U - 1
+    costs = torch.zeros(N)
+    grads = torch.empty_like(x)
+    grads.view(torch.int16).fill_(0x4110)                              # 9.0 in bf16: every element must be overwritten
+    assert warp_rnnt.gpu_rnnt(x, labels, tl, ll, costs, grads, 0, 0) == 0
+    assert torch.isfinite(costs).all()
+    pick = [0, 511, 1023]
+    ref_c, ref_g = oracle.rnnt_logits(x[pick].double().cpu().numpy(), labels[pick].cpu().numpy(),
+                                      tl[pick].cpu().numpy(), ll[pick].cpu().numpy())
+    assert np.abs(costs[pick].double().numpy() - ref_c).max() <= 1e-4 * np.abs(ref_c).max()
+    assert np.abs(grads[pick].double().cpu().numpy() - ref_g).max() < 4e-3      # bf16 storage quantum (see module doc)
+    t_idx = torch.arange(T, device=dev).view(1, T, 1)
+    u_idx = torch.arange(U, device=dev).view(1, 1, U)
+    worst_row, worst_pad = 0.0, 0.0
+    for i in range(0, N, 64):
+        gs = grads[i:i + 64].float()
+        worst_row = max(worst_row, gs.sum(-1).abs().max().item())
+        pad = (t_idx >= tl[i:i + 64].view(-1, 1, 1)) | (u_idx > ll[i:i + 64].view(-1, 1, 1))
+        worst_pad = max(worst_pad, gs.abs().amax(-1)[pad].max().item())
+    assert worst_row < 0.35 and worst_pad == 0.0
+    # forward-only scoring of the same tensor: bit-equal costs
+    costs2 = torch.zeros(N)
+    assert warp_rnnt.gpu_rnnt(x, labels, tl, ll, costs2, torch.zeros(0, device=dev, dtype=torch.bfloat16), 0, 0) == 0
+    assert torch.equal(costs, costs2)
+
+
+@pytest.mark.parametrize("shape", [(1, 6, 600, 5),       # fp64, 10 wavefronts: lattice_kernel<double,16>
+                                   (2, 3, 1024, 4),      # fp64 at the maxU limit, 16 wavefronts
+                                   (1, 40, 513, 3),      # first size past the 8-wavefront instantiation
+                                   (2, 70, 320, 6)])     # fp64, 5 wavefronts (the c4 lattice width)
+def test_wide_lattices_fp64(oracle, shape):
+    N, T, U, A = shape
+    rng = np.random.default_rng(N * 7 + T * 5 + U * 3 + A)
+    acts = rng.standard_normal(shape) * 1.5
+    labels = rng.integers(1, A, size=(N, U - 1))
+    tl = rng.integers(max(1, T // 2), T + 1, size=N); tl[0] = T
+    ll = rng.integers((U - 1) // 2, U, size=N); ll[-1] = U - 1
+    ref_c, ref_g = oracle.rnnt_logits(acts, labels, tl, ll)
+    c64, g64 = run_gpu(acts, labels, tl, ll, dtype=torch.float64)
+    assert np.abs(c64 - ref_c).max() <= 1e-10 * max(1.0, np.abs(ref_c).max())
+    assert np.abs(g64 - ref_g).max() < 1e-9
+    c32, g32 = run_gpu(acts, labels, tl, ll)
+    r32c, r32g = oracle.rnnt_logits(acts.astype(np.float32).astype(np.float64), labels, tl, ll)
+    assert np.abs(c32 - r32c).max() <= 1e-4 * max(1.0, np.abs(r32c).max())
+    assert np.abs(g32 - r32g).max() < 2e-4
+
+
+def test_batch_size_limit(oracle):
+    """N = 65535 runs (and is right); N = 65536 and maxT*maxU >= 2^29 are reported as INVALID_VALUE -- limits of
+    this library, not of the reference."""
+    from warprnnt_pytorch import _lib
+    N, T, U, A = 65535, 2, 2, 3
+    rng = np.random.default_rng(65535)
+    acts = rng.standard_normal((N, T, U, A)).astype(np.float32)
+    labels = rng.integers(1, A, size=(N, U - 1))
+    tl, ll = np.full(N, T), rng.integers(0, U, size=N)
+    ref_c, ref_g = oracle.rnnt_logits(acts.astype(np.float64), labels, tl, ll)
+    costs, grads = run_gpu(acts, labels, tl, ll)
+    assert np.abs(costs - ref_c).max() < 1e-4 and np.abs(grads - ref_g).max() < 1e-4
+    lib = _lib.lib()
+    dev = torch.device("cuda:0")
+    x = torch.zeros(8, device=dev)
+    i = torch.ones(8, dtype=torch.int32, device=dev)
+    host = torch.zeros(8)
+    for kw, n in ((dict(maxT=2, maxU=2), 65536), (dict(maxT=1 << 20, maxU=512), 1), (dict(maxT=1 << 28, maxU=2), 1)):
+        opt = _lib.rnntOptions(loc=1, num_threads=0, stream=None, blank_label=0, batch_first=True, **kw)
+        st = lib.compute_rnnt_loss(x.data_ptr(), None, i.data_ptr(), i.data_ptr(), i.data_ptr(), 3, n, host.data_ptr(),
+                                   x.data_ptr(), opt)
+        assert st == 2, (kw, n, st)
+
+
+def test_device_side_lengths_are_validated(oracle):
+    """T_b > maxT / U_b > maxU / T_b < 1 on the DEVICE: the reference's GPU path reads garbage silently; its CPU
+    path has no check either, this library's CPU location returns INVALID_VALUE (csrc/rnnt_cpu.cpp).  The GPU
+    location now agrees: compute_rnnt_loss returns INVALID_VALUE (the sample's cost carries a marker NaN, every
+    kernel clamps the lengths, nothing is touched out of bounds), the asynchronous entries leave the NaN in the
+    device costs, and the other samples of the batch are unaffected."""
+    from warprnnt_pytorch import _lib, warp_rnnt
+    lib = _lib.lib()
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(5)
+    N, T, U, A = 4, 9, 5, 11
+    acts = rng.standard_normal((N, T, U, A)).astype(np.float32)
+    labels = rng.integers(1, A, size=(N, U - 1)).astype(np.int32)
+    good_tl, good_ll = np.array([T, 4, T, 6], np.int32), np.array([U - 1, 2, 0, U - 1], np.int32)
+    ref_c, ref_g = oracle.rnnt_logits(acts.astype(np.float64), labels, good_tl, good_ll)
+    x = torch.tensor(acts, device=dev)
+    lab = torch.tensor(labels, device=dev)
+    ws = torch.empty(_lib.workspace_bytes(T, U, N, True, 4), dtype=torch.uint8, device=dev)
+    opt = _lib.rnntOptions(loc=1, num_threads=0, stream=None, blank_label=0, maxT=T, maxU=U, batch_first=True)
+    for bad_b, bad_t, bad_l in ((1, T + 1, 2), (3, 6, U), (2, 0, 0), (0, 1 << 30, U - 1), (1, 4, -2)):
+        tl, ll = good_tl.copy(), good_ll.copy()
+        tl[bad_b], ll[bad_b] = bad_t, bad_l
+        ttl, tll = torch.tensor(tl, device=dev), torch.tensor(ll, device=dev)
+        grads = torch.zeros_like(x)
+        costs = torch.zeros(N)
+        st = lib.compute_rnnt_loss(x.data_ptr(), grads.data_ptr(), lab.data_ptr(), tll.data_ptr(), ttl.data_ptr(), A, N,
+                                   costs.data_ptr(), ws.data_ptr(), opt)
+        assert st == 2, (bad_b, bad_t, bad_l, st)
+        dcosts = torch.zeros(N, device=dev)
+        warp_rnnt.gpu_rnnt_async(x, lab, ttl, tll, dcosts, grads, 0, workspace=ws)
+        torch.cuda.synchronize()
+        dc = dcosts.cpu().numpy()
+        ok = [b for b in range(N) if b != bad_b]
+        assert np.isnan(dc[bad_b]) and np.abs(dc[ok] - ref_c[ok]).max() < 1e-4
+        assert np.abs(grads.cpu().numpy()[ok] - ref_g[ok]).max() < 1e-4
+    # and the valid batch still succeeds afterwards
+    costs = torch.zeros(N)
+    ttl, tll = torch.tensor(good_tl, device=dev), torch.tensor(good_ll, device=dev)
+    grads = torch.zeros_like(x)
+    assert lib.compute_rnnt_loss(x.data_ptr(), grads.data_ptr(), lab.data_ptr(), tll.data_ptr(), ttl.data_ptr(), A, N,
+                                 costs.data_ptr(), ws.data_ptr(), opt) == 0
+    assert np.abs(costs.numpy() - ref_c).max() < 1e-4

@@ -1,0 +1,106 @@
+"""-m gpu, >= 2 devices: the batch-sharded path with TWO ranks over RCCL (backend "nccl" on ROCm), one process per
+GPU -- the twin of tests/test_sharded_gloo.py on the real transport.  Every rank runs the HIP hot path on its slab
+(compute_rnnt_loss_fwd / _bwd), ONE all-reduce (or all-gather for 'none') carries the loss; losses and gradients
+must equal the unsharded single-GPU run.  Skipped on a 1-GPU box (RCCL refuses two ranks on one device).
+Also: `bench.py --gpus 2` launches its own two ranks and reports n_gpus = 2."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _batch(dev):
+    g = torch.Generator().manual_seed(11)
+    N, T, U, A = 6, 23, 9, 130
+    acts = torch.randn(N, T, U, A, generator=g)
+    labels = torch.randint(1, A, (N, U - 1), generator=g, dtype=torch.int32)
+    tl = torch.tensor([T, 9, T, T, 14, T], dtype=torch.int32)      # every shard contains the maxima
+    ll = torch.tensor([U - 1, 3, 0, U - 1, 5, 2], dtype=torch.int32)
+    return [t.to(dev) for t in (acts, labels, tl, ll)]
+
+
+def _worker(rank, world, port, reduction, q):
+    for p in (ROOT, os.path.join(ROOT, "warp-transducer_amd")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(rank)
+    dev = torch.device("cuda", rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    from warprnnt_pytorch.sharded import ShardedRNNTLoss
+    acts, labels, tl, ll = _batch(dev)
+    n = acts.shape[0] // world
+    sl = slice(rank * n, (rank + 1) * n)
+    x = acts[sl].clone().requires_grad_(True)
+    loss = ShardedRNNTLoss(blank=0, reduction=reduction)(x, labels[sl].contiguous(), tl[sl].contiguous(),
+                                                        ll[sl].contiguous())
+    w = torch.arange(1, loss.numel() + 1, dtype=loss.dtype, device=dev)
+    (loss * w).sum().backward()
+    torch.cuda.synchronize()
+    q.put((rank, loss.detach().cpu().numpy(), x.grad.cpu().numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("reduction", ["mean", "sum", "none"])
+def test_two_rccl_ranks_equal_single_gpu(reduction):
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs 2 GPUs (one RCCL rank per device)")
+    import torch.multiprocessing as mp
+    from warprnnt_pytorch import RNNTLoss
+    dev = torch.device("cuda:0")
+    acts, labels, tl, ll = _batch(dev)
+    x = acts.clone().requires_grad_(True)
+    ref = RNNTLoss(reduction=reduction)(x, labels, tl, ll)
+    w = torch.arange(1, ref.numel() + 1, dtype=ref.dtype, device=dev)
+    (ref * w).sum().backward()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, reduction, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted((q.get(timeout=300) for _ in procs), key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    n = acts.shape[0] // 2
+    for rank, loss, grad in got:
+        assert np.allclose(loss, ref.detach().cpu().numpy(), rtol=1e-5, atol=1e-5)     # global loss on every rank
+        assert np.allclose(grad, x.grad[rank * n:(rank + 1) * n].cpu().numpy(), atol=1e-6)
+
+
+def test_bench_self_launches_two_ranks():
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs 2 GPUs")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2"],
+                         capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["config"]["global_batch"] == 256 and line["dtype"] == "bf16"
+
+
+def test_bench_refuses_more_gpus_than_visible():
+    """`bench.py --gpus N` with fewer than N devices must fail loudly, never fall back to fewer GPUs."""
+    n = torch.cuda.device_count() + 1
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "1", "--warmup", "0"],
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 2
+    assert "refusing" in out.stderr and not out.stdout.strip()

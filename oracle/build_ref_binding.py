@@ -87,5 +87,11 @@ if __name__ == "__main__":
         print("reference checkout absent: keeping prebuilt oracle/_ref/binding_* (if any)")
         sys.exit(0)
     what = sys.argv[1] if len(sys.argv) > 1 else "all"
-    for k in (("cpu", "gpu") if what == "all" else (what,)):
-        build(k)
+    if what == "all":
+        # one process per module: torch's JIT builder renames the second module of the same name it builds in a
+        # process (warp_rnnt_v1), and both halves must be called warp_rnnt
+        import subprocess
+        for k in ("cpu", "gpu"):
+            subprocess.run([sys.executable, os.path.abspath(__file__), k], check=True)
+    else:
+        build(what)

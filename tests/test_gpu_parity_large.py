@@ -147,7 +147,7 @@ def test_wide_lattices_fp64(oracle, shape):
     c32, g32 = run_gpu(acts, labels, tl, ll)
     r32c, r32g = oracle.rnnt_logits(acts.astype(np.float32).astype(np.float64), labels, tl, ll)
     assert np.abs(c32 - r32c).max() <= 1e-4 * max(1.0, np.abs(r32c).max())
-    assert np.abs(g32 - r32g).max() < 2e-4
+    assert np.abs(g32 - r32g).max() < 5e-4            # ~1000 fp32 lattice steps (north_star: 1e-3)
 
 
 def test_batch_size_limit(oracle):

@@ -22,9 +22,11 @@ int main(int argc, char** argv) {
     CK(hipMemcpy(xlen, hx.data(), N * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(ylen, hy.data(), N * 4, hipMemcpyHostToDevice));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     auto launch = [&] {
-        if (W == 1) hipLaunchKernelGGL((lattice_kernel<float, 1>), dim3(N * 2), dim3(64), 0, 0, cells, alpha, beta, offa, offb, llf, llb, costs, xlen, ylen, T, U, Up, 2);
-        else if (W <= 8) hipLaunchKernelGGL((lattice_kernel<float, 8>), dim3(N * 2), dim3(Up), 0, 0, cells, alpha, beta, offa, offb, llf, llb, costs, xlen, ylen, T, U, Up, 2);
-        else hipLaunchKernelGGL((lattice_kernel<float, 16>), dim3(N * 2), dim3(Up), 0, 0, cells, alpha, beta, offa, offb, llf, llb, costs, xlen, ylen, T, U, Up, 2);
+        const int cols = argc > 4 ? atoi(argv[4]) : 2;          // columns per lane for U > 64
+        if (W == 1) hipLaunchKernelGGL((lattice_kernel<float, 1, 1>), dim3(N * 2), dim3(64), 0, 0, cells, alpha, beta, offa, offb, llf, llb, costs, xlen, ylen, T, U, Up, 2);
+        else if (cols == 1) hipLaunchKernelGGL((lattice_kernel<float, 8, 1>), dim3(N * 2), dim3(Up), 0, 0, cells, alpha, beta, offa, offb, llf, llb, costs, xlen, ylen, T, U, Up, 2);
+        else if (lat_waves(Up, 2) <= 4) hipLaunchKernelGGL((lattice_kernel<float, 4, 2>), dim3(N * 2), dim3(lat_waves(Up, 2) * 64), 0, 0, cells, alpha, beta, offa, offb, llf, llb, costs, xlen, ylen, T, U, Up, 2);
+        else hipLaunchKernelGGL((lattice_kernel<float, 8, 2>), dim3(N * 2), dim3(lat_waves(Up, 2) * 64), 0, 0, cells, alpha, beta, offa, offb, llf, llb, costs, xlen, ylen, T, U, Up, 2);
     };
     for (int i = 0; i < 3; ++i) launch();
     CK(hipDeviceSynchronize());
@@ -34,6 +36,6 @@ int main(int argc, char** argv) {
     CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
     float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= reps;
     float c0; CK(hipMemcpy(&c0, costs, 4, hipMemcpyDeviceToHost));
-    printf("N=%d T=%d U=%d: %.1f us, %.1f ns/diagonal (cost[0]=%.3f)\n", N, T, U, ms * 1e3, ms * 1e6 / (T + U - 2), c0);
+    printf("cols=%d N=%d T=%d U=%d: %.1f us, %.1f ns/diagonal (cost[0]=%.3f)\n", (U > 64 ? (argc > 4 ? atoi(argv[4]) : 2) : 1), N, T, U, ms * 1e3, ms * 1e6 / (T + U - 2), c0);
     return 0;
 }

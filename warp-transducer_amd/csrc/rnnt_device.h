@@ -174,40 +174,43 @@ template <typename T> __device__ __forceinline__ T log_zero();
 template <> __device__ __forceinline__ float log_zero<float>() { return -1.0e30f; }
 template <> __device__ __forceinline__ double log_zero<double>() { return -1.0e300; }
 
+// (-|a - b| instead of min - max: the negation and the absolute value are source modifiers of v_exp_f32,
+// one instruction less on the lattice's dependent chain)
 __device__ __forceinline__ float log2_add(float a, float b) {
-    const float hi = fmaxf(a, b), lo = fminf(a, b);
-    return hi + __builtin_amdgcn_logf(1.0f + __builtin_amdgcn_exp2f(lo - hi));
+    const float d = a - b, hi = fmaxf(a, b);
+    return hi + __builtin_amdgcn_logf(1.0f + __builtin_amdgcn_exp2f(-__builtin_fabsf(d)));
 }
 __device__ __forceinline__ double log2_add(double a, double b) {
-    const double hi = fmax(a, b), lo = fmin(a, b);
-    return hi + log2(1.0 + exp2(lo - hi));
+    const double d = a - b, hi = fmax(a, b);
+    return hi + log2(1.0 + exp2(-fabs(d)));
 }
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 __device__ __forceinline__ double fast_exp2(double x) { return exp2(x); }
 
 // ----------------------------------------------------------------------------- cross-lane
-// Whole-wave shift by one lane through DPP.  shr: lane i receives lane i-1 (lane 0 gets
-// `fill`); shl: lane i receives lane i+1 (lane 63 gets `fill`).
-__device__ __forceinline__ int dpp_shr1(int v, int fill) {
-    return __builtin_amdgcn_update_dpp(fill, v, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+// Whole-wave shift by one lane through DPP.  shr: lane i receives lane i-1; shl: lane i receives lane i+1.
+// The lane without a source (0 for shr, 63 for shl) KEEPS what `keep` holds there, so a caller that carries
+// `keep` from step to step (keep = wave_shr1(keep, v)) pays one v_mov_b32_dpp per shift and no re-initialisation.
+__device__ __forceinline__ int dpp_shr1(int keep, int v) {
+    return __builtin_amdgcn_update_dpp(keep, v, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
 }
-__device__ __forceinline__ int dpp_shl1(int v, int fill) {
-    return __builtin_amdgcn_update_dpp(fill, v, 0x130 /* wave_shl:1 */, 0xf, 0xf, false);
+__device__ __forceinline__ int dpp_shl1(int keep, int v) {
+    return __builtin_amdgcn_update_dpp(keep, v, 0x130 /* wave_shl:1 */, 0xf, 0xf, false);
 }
-__device__ __forceinline__ float wave_shr1(float v, float fill) {
-    return __int_as_float(dpp_shr1(__float_as_int(v), __float_as_int(fill)));
+__device__ __forceinline__ float wave_shr1(float keep, float v) {
+    return __int_as_float(dpp_shr1(__float_as_int(keep), __float_as_int(v)));
 }
-__device__ __forceinline__ float wave_shl1(float v, float fill) {
-    return __int_as_float(dpp_shl1(__float_as_int(v), __float_as_int(fill)));
+__device__ __forceinline__ float wave_shl1(float keep, float v) {
+    return __int_as_float(dpp_shl1(__float_as_int(keep), __float_as_int(v)));
 }
-__device__ __forceinline__ double wave_shr1(double v, double fill) {
-    int lo = dpp_shr1(__double2loint(v), __double2loint(fill));
-    int hi = dpp_shr1(__double2hiint(v), __double2hiint(fill));
+__device__ __forceinline__ double wave_shr1(double keep, double v) {
+    int lo = dpp_shr1(__double2loint(keep), __double2loint(v));
+    int hi = dpp_shr1(__double2hiint(keep), __double2hiint(v));
     return __hiloint2double(hi, lo);
 }
-__device__ __forceinline__ double wave_shl1(double v, double fill) {
-    int lo = dpp_shl1(__double2loint(v), __double2loint(fill));
-    int hi = dpp_shl1(__double2hiint(v), __double2hiint(fill));
+__device__ __forceinline__ double wave_shl1(double keep, double v) {
+    int lo = dpp_shl1(__double2loint(keep), __double2loint(v));
+    int hi = dpp_shl1(__double2hiint(keep), __double2hiint(v));
     return __hiloint2double(hi, lo);
 }
 
@@ -228,8 +231,20 @@ __device__ __forceinline__ double lane_get(double v, int k) {
     return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), k),
                             __builtin_amdgcn_readlane(__double2loint(v), k));
 }
-template <typename T> __device__ __forceinline__ T lane_set(T dst, T s, int k) {
-    return (static_cast<int>(threadIdx.x & 63) == k) ? s : dst;       // lowers to one v_cndmask with a constant mask
+// Write the wave-uniform scalar `s` into lane `k` (compile-time) of `dst`: one v_writelane_b32 per dword
+// (inline assembly: this compiler has the readlane builtin but no writelane one; as a select on the lane
+// index the compiler turned the boundary hand-off of the lattice kernel into a branch per step).
+__device__ __forceinline__ int lane_set_b32(int dst, int s, int k) {
+    asm("v_writelane_b32 %0, %1, %2" : "+v"(dst) : "s"(s), "n"(k));
+    return dst;
+}
+__device__ __forceinline__ float lane_set(float dst, float s, int k) {
+    return __int_as_float(lane_set_b32(__float_as_int(dst), __builtin_amdgcn_readfirstlane(__float_as_int(s)), k));
+}
+__device__ __forceinline__ double lane_set(double dst, double s, int k) {
+    const int lo = lane_set_b32(__double2loint(dst), __builtin_amdgcn_readfirstlane(__double2loint(s)), k);
+    const int hi = lane_set_b32(__double2hiint(dst), __builtin_amdgcn_readfirstlane(__double2hiint(s)), k);
+    return __hiloint2double(hi, lo);
 }
 // Wave-wide maximum through DPP only (no LDS round trips): quad swaps, row mirrors, then the
 // row broadcasts; the result is read from lane 63 and is wave-uniform.

@@ -102,10 +102,10 @@ static void prof_accumulate() {
 // blk = block-per-row statistics kernel for rows >= 12 KB on/off, jzs = vocabulary split of the Z kernel (1|4|8),
 // xcd = XCD-aware tile order of the short-row statistics kernel on/off, ctile = tiled coefficient kernel on/off,
 // pskip = the gradient kernel's skip-padded-rows form for rows >= 8 KB on/off, joh = one-hot df corrections in the
-// additive-joint DF kernel (-1: vocabularies <= 256), one = single-launch path for tiny problems on/off.
+// additive-joint DF kernel (-1: vocabularies <= 256), lat2 = two lattice columns per lane (-1: maxU > 256).
 struct Tune { int sw = 4, nta = 1, gmax = 4194304, rows = 0, tile = 1, tilekb = 52, ppt = 2;
               int jfnk = 0, jfpf = 1, jgnk = 0, jgpf = 1, blk = 1, jzs = 0, xcd = 1, ctile = 1, pskip = 1, joh = -1;
-              int one = 1, lat2 = 1; };
+              int lat2 = -1, xst = 0; };
 #ifdef RNNT_DEV
 static Tune read_tune() {
     Tune t;
@@ -115,7 +115,7 @@ static Tune read_tune() {
         {"sw", &t.sw}, {"nta", &t.nta}, {"gmax", &t.gmax}, {"rows", &t.rows}, {"tile", &t.tile},
         {"tilekb", &t.tilekb}, {"ppt", &t.ppt}, {"jfnk", &t.jfnk}, {"jfpf", &t.jfpf}, {"jgnk", &t.jgnk},
         {"jgpf", &t.jgpf}, {"blk", &t.blk}, {"jzs", &t.jzs}, {"xcd", &t.xcd}, {"ctile", &t.ctile},
-        {"pskip", &t.pskip}, {"joh", &t.joh}, {"one", &t.one}, {"lat2", &t.lat2}};
+        {"pskip", &t.pskip}, {"joh", &t.joh}, {"lat2", &t.lat2}, {"xst", &t.xst}};
     // tokens are separated by ',', a token is key=value with the WHOLE key compared
     for (const char* p = e; *p;) {
         const char* end = strchr(p, ',');
@@ -149,6 +149,8 @@ template <typename C> struct Plan {
     LogPair<C>* lp2; C *logz, *alpha, *beta; Cell<C>* rowtab;
     double *offa, *offb, *llf, *llb;
     float *rowmax, *wmat;
+    int lat_cols = 1;              // lattice columns per lane (1 | 2), its wavefronts per block ...
+    int lat_w = 1, lat_sh = 6;     // ... and the column -> wavefront shift (coefficient kernels)
     float fastemit = 0.0f;         // FastEmit lambda (extension entries only)
     const long long* offsets = nullptr;        // packed layout: cumulative row offsets (device, N+1 entries) ...
     unsigned long long packed_rows = 0;        // ... and the total number of rows (host)
@@ -167,6 +169,15 @@ static bool make_plan(Plan<C>& p, int A, int N, const rnntOptions& opt, void* wo
     if (static_cast<long long>(p.maxT) * p.maxU > 0x7fffffffLL / 4) return false;
     if (N > 65535) return false;
     p.Up = ((p.maxU + 63) / 64) * 64;
+    // one sample's skewed lp2 array is addressed through a buffer descriptor with a 32-bit size
+    if (lat_rows(p.maxT, p.maxU) * p.Up * sizeof(LogPair<C>) >= (1ull << 31)) return false;
+    // lattice kernel form: one wavefront for maxU <= 64; one column per lane while every wavefront of the block
+    // has a SIMD to itself (maxU <= 256), two columns per lane beyond (measured, ns per diagonal at T = 1500,
+    // one / two columns: U=128 79 / 97, U=192 93 / 111, U=256 120 / 117, U=301 148 / 139, U=512 205 / 188)
+    const int lat2 = tune().lat2 >= 0 ? tune().lat2 : (p.Up > 256 ? 1 : 0);
+    p.lat_cols = p.Up == 64 ? 1 : ((p.Up > 512 || lat2) ? 2 : 1);
+    p.lat_w = lat_waves(p.Up, p.lat_cols);
+    p.lat_sh = lat_col_shift(p.lat_cols);
     p.cells_per_sample = p.maxT * p.maxU;
     p.stream = reinterpret_cast<hipStream_t>(opt.stream);
     p.labels = labels; p.input_lengths = input_lengths; p.label_lengths = label_lengths;
@@ -208,7 +219,7 @@ static void launch_row_stats(Plan<typename Tag::comp>& p, const typename Tag::st
 #define RNNT_TILE(GG)                                                                                       \
     hipLaunchKernelGGL((row_stats_tile_kernel<Tag, GG>), dim3(xgrid), dim3(256), lds, p.stream, acts, p.labels, \
                        p.input_lengths, p.label_lengths, p.lp2, p.logz, Rall, p.maxT, p.maxU, p.Up,           \
-                       p.A, p.blank, tn.xcd, p.offsets, p.N)
+                       p.A, p.blank, tn.xcd | (tn.xst << 4), p.offsets, p.N)
             switch (G) {
                 case 1: RNNT_TILE(1); break;
                 case 2: RNNT_TILE(2); break;
@@ -253,13 +264,14 @@ static void launch_row_stats(Plan<typename Tag::comp>& p, const typename Tag::st
 // Stage 2: alpha (and, for gradients, beta) recursion; writes the costs.
 template <typename C> static void launch_lattice(Plan<C>& p, bool with_beta) {
     const int dirs = with_beta ? 2 : 1;
-#define RNNT_LATTICE(MW)                                                                                         \
-    hipLaunchKernelGGL((lattice_kernel<C, MW>), dim3(p.N * dirs), dim3(p.Up), 0, p.stream, p.lp2, p.alpha, p.beta, \
-                       p.offa, p.offb, p.llf, p.llb, p.costs_dev, p.input_lengths, p.label_lengths, p.maxT, p.maxU, \
-                       p.Up, dirs)
-    if (p.Up == 64) RNNT_LATTICE(1);
-    else if (p.Up <= 512) RNNT_LATTICE(8);
-    else RNNT_LATTICE(16);
+#define RNNT_LATTICE(MW, CC)                                                                                     \
+    hipLaunchKernelGGL((lattice_kernel<C, MW, CC>), dim3(p.N * dirs), dim3(p.lat_w * 64), 0, p.stream, p.lp2,          \
+                       p.alpha, p.beta, p.offa, p.offb, p.llf, p.llb, p.costs_dev, p.input_lengths, p.label_lengths,  \
+                       p.maxT, p.maxU, p.Up, dirs)
+    if (p.Up == 64) RNNT_LATTICE(1, 1);                            // one wavefront, no synchronisation
+    else if (p.lat_cols == 1) RNNT_LATTICE(8, 1);                  // maxU <= 512, one column per lane
+    else if (p.lat_w <= 4) RNNT_LATTICE(4, 2);                     // two columns per lane, one wavefront per SIMD
+    else RNNT_LATTICE(8, 2);                                       // maxU <= 1024 in at most 8 wavefronts
 #undef RNNT_LATTICE
     p.check();
 }
@@ -275,14 +287,14 @@ template <typename C> static void launch_coef(Plan<C>& p, bool joint = false, bo
         const dim3 cgrid(static_cast<unsigned>(((skew_cells + 255) / 256 + 7) / 8 * 8), p.N);   // multiple of 8: XCD-aware remap
         hipLaunchKernelGGL((coef_cell_kernel<C>), cgrid, dim3(256), 0, p.stream, p.lp2, p.logz, p.alpha, p.beta, p.offa,
                            p.offb, p.llf, p.labels, p.input_lengths, p.label_lengths, p.rowtab, p.maxT, p.maxU, p.Up,
-                           wmat, Upad, p.fastemit, planes, p.offsets);
+                           wmat, Upad, p.fastemit, planes, p.offsets, p.lat_w, p.lat_sh);
     } else {
         const int DN = sizeof(C) == 4 ? 32 : 16;           // diagonals per tile (coef_kernel)
         const int tilesU = (p.maxU + 63) / 64, tilesN = (p.maxT + p.maxU - 1 + DN - 1) / DN;
         const dim3 cgrid(static_cast<unsigned>(tilesU * tilesN), p.N);
         hipLaunchKernelGGL((coef_kernel<C>), cgrid, dim3(256), 0, p.stream, p.lp2, p.logz, p.alpha, p.beta, p.offa,
                            p.offb, p.llf, p.labels, p.input_lengths, p.label_lengths, p.rowtab, p.maxT, p.maxU, p.Up,
-                           wmat, Upad, tilesU, p.fastemit, planes, p.offsets);
+                           wmat, Upad, tilesU, p.fastemit, planes, p.offsets, p.lat_w, p.lat_sh);
     }
     p.check();
 }

@@ -371,7 +371,7 @@ __global__ __launch_bounds__(256) void row_stats_tile_kernel(
     // and leave as full lines (the scattered result stores are what bounds this kernel on c4).
     const unsigned ntile = static_cast<unsigned>((R + RT - 1) / RT);
     const unsigned per = (ntile + 7u) >> 3;
-    const unsigned tile_id = xcd_remap ? (blockIdx.x & 7u) * per + (blockIdx.x >> 3) : blockIdx.x;
+    const unsigned tile_id = (xcd_remap & 1) ? (blockIdx.x & 7u) * per + (blockIdx.x >> 3) : blockIdx.x;
     if (tile_id >= ntile) return;                          // grid is rounded up to a multiple of 8
     const unsigned long long r0 = static_cast<unsigned long long>(tile_id) * RT;
     const int nrows = static_cast<int>(R - r0 < static_cast<unsigned long long>(RT) ? R - r0 : RT);
@@ -504,6 +504,13 @@ __global__ __launch_bounds__(256) void row_stats_tile_kernel(
         rec.y = has_lab ? vmax((load1<Tag>(rowp + lab) - logZ) * C(kLog2e), log_zero<C>()) : log_zero<C>();
         // two scattered stores per row: they combine into full lines in the XCD's L2 (tile order above)
         const size_t idx = lat_index(b, t + u, u, maxT, maxU, Up);
+#ifdef RNNT_DEV
+        // development build only (RNNT_TUNE=xst=..): timing experiments on the result stores, results are WRONG
+        const int xst = xcd_remap >> 4;
+        if (xst == 1) { reinterpret_cast<Cell<C>*>(lp2)[idx] = Cell<C>{rec.x, rec.y, logZ, C(0)}; return; }   // one 16-byte record
+        if (xst == 2) { const size_t nat = r0 + rl; lp2[nat] = rec; logz[nat] = logZ; return; }              // natural order
+        if (xst == 3) { if (rec.x == C(12345)) logz[idx] = logZ; return; }                                   // no stores
+#endif
         lp2[idx] = rec;
         logz[idx] = logZ;
     }
@@ -539,63 +546,114 @@ __global__ __launch_bounds__(256) void row_stats_tile_kernel(
 //     neighbour produced in slot s-1 from a 2-deep LDS ring (converted between the two
 //     wavefronts' offsets), so the block synchronises once per C diagonals instead of once per
 //     diagonal (the reference barriers every diagonal: gpu_rnnt_kernel.h:26-40).
-// Chunk length by lattice type and block size (MAXW = wavefronts per block the instantiation is
-// bounded to: 1024-thread blocks only get 128 VGPRs, so they use shorter chunks).
-template <typename L, int MAXW> struct LatChunk {
-    static constexpr int C = (sizeof(L) == 4 ? 16 : 8) / (MAXW > 8 ? 2 : 1);
+//   * COLS lattice columns per lane.  A lattice up to 64 columns wide is one wavefront with one column per
+//     lane (no synchronisation at all).  Wider lattices give every lane TWO adjacent columns: half the
+//     wavefronts (U = 301: three instead of five, so no SIMD hosts two of them and sets the pace of the
+//     pipeline), one DPP shift per two cells (column 2l+1 takes its neighbour from the lane's own
+//     registers), two independent log2_add chains per lane to fill the issue slots a single dependent
+//     chain leaves empty, and 16-byte loads / 8-byte stores per lane.  maxU <= 1024 then needs at most
+//     eight wavefronts, so no 1024-thread instantiation (and its 128-register ceiling) exists.
+// Chunk length: 16 diagonals for an fp32 lattice, 8 for fp64; halved for two-column lanes in blocks of more
+// than four wavefronts (two wavefronts per SIMD: 256 registers per lane; the two chunk buffers and the result
+// history of a two-column lane are 10 values per diagonal).
+template <typename L, int MAXW, int COLS> struct LatChunk {
+    static constexpr int C = (sizeof(L) == 4 ? 16 : 8) / ((COLS > 1 && MAXW > 4) ? 2 : 1);
 };
 
 typedef unsigned int lat_u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int lat_u32x4 __attribute__((ext_vector_type(4)));
 
 // Row-addressed access to the skewed arrays through buffer instructions: the descriptor holds the
-// sample's base, `soff` is the scalar byte offset of a row, `voff` the lane's byte offset in it.
-template <typename L> struct LatIO;
-template <> struct LatIO<float> {
-    static __device__ __forceinline__ void load_xy(__amdgpu_buffer_rsrc_t r, int voff, int soff, float& x, float& y) {
+// sample's base, `soff` is the scalar byte offset of a row, `voff` the lane's byte offset in it (the only
+// part the hardware range-checks: a lane parked at kLatOob neither loads nor stores).
+constexpr int kLatOob = 0x7ffffff0;
+__device__ __forceinline__ float lat_clamp(float v) { return __builtin_amdgcn_fmed3f(v, log_zero<float>(), 0.0f); }
+__device__ __forceinline__ double lat_clamp(double v) { return fmin(fmax(v, log_zero<double>()), 0.0); }
+__device__ __forceinline__ double lat_f64(unsigned lo, unsigned hi) { return __hiloint2double(static_cast<int>(hi), static_cast<int>(lo)); }
+
+template <typename L, int COLS> struct LatIO;
+template <> struct LatIO<float, 1> {
+    static __device__ __forceinline__ void load_xy(__amdgpu_buffer_rsrc_t r, int voff, int soff, float* x, float* y) {
         const lat_u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
-        x = __builtin_amdgcn_fmed3f(__uint_as_float(v.x), log_zero<float>(), 0.0f);
-        y = __builtin_amdgcn_fmed3f(__uint_as_float(v.y), log_zero<float>(), 0.0f);
+        x[0] = lat_clamp(__uint_as_float(v.x)); y[0] = lat_clamp(__uint_as_float(v.y));
     }
-    static __device__ __forceinline__ void store(__amdgpu_buffer_rsrc_t r, int voff, int soff, float v) {
-        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, voff, soff, 0);
-    }
-    static __device__ __forceinline__ float load(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
-        return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+    static __device__ __forceinline__ void store(__amdgpu_buffer_rsrc_t r, int voff, int soff, const float* v) {
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[0]), r, voff, soff, 0);
     }
 };
-template <> struct LatIO<double> {
-    static __device__ __forceinline__ void load_xy(__amdgpu_buffer_rsrc_t r, int voff, int soff, double& x, double& y) {
+template <> struct LatIO<float, 2> {
+    static __device__ __forceinline__ void load_xy(__amdgpu_buffer_rsrc_t r, int voff, int soff, float* x, float* y) {
         const lat_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
-        x = fmin(fmax(__hiloint2double(static_cast<int>(v.y), static_cast<int>(v.x)), log_zero<double>()), 0.0);
-        y = fmin(fmax(__hiloint2double(static_cast<int>(v.w), static_cast<int>(v.z)), log_zero<double>()), 0.0);
+        x[0] = lat_clamp(__uint_as_float(v.x)); y[0] = lat_clamp(__uint_as_float(v.y));
+        x[1] = lat_clamp(__uint_as_float(v.z)); y[1] = lat_clamp(__uint_as_float(v.w));
     }
-    static __device__ __forceinline__ void store(__amdgpu_buffer_rsrc_t r, int voff, int soff, double v) {
-        const lat_u32x2 w = {static_cast<unsigned>(__double2loint(v)), static_cast<unsigned>(__double2hiint(v))};
+    static __device__ __forceinline__ void store(__amdgpu_buffer_rsrc_t r, int voff, int soff, const float* v) {
+        const lat_u32x2 w = {__float_as_uint(v[0]), __float_as_uint(v[1])};
         __builtin_amdgcn_raw_buffer_store_b64(w, r, voff, soff, 0);
     }
-    static __device__ __forceinline__ double load(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
-        const lat_u32x2 w = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
-        return __hiloint2double(static_cast<int>(w.y), static_cast<int>(w.x));
+};
+template <> struct LatIO<double, 1> {
+    static __device__ __forceinline__ void load_xy(__amdgpu_buffer_rsrc_t r, int voff, int soff, double* x, double* y) {
+        const lat_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+        x[0] = lat_clamp(lat_f64(v.x, v.y)); y[0] = lat_clamp(lat_f64(v.z, v.w));
+    }
+    static __device__ __forceinline__ void store(__amdgpu_buffer_rsrc_t r, int voff, int soff, const double* v) {
+        const lat_u32x2 w = {static_cast<unsigned>(__double2loint(v[0])), static_cast<unsigned>(__double2hiint(v[0]))};
+        __builtin_amdgcn_raw_buffer_store_b64(w, r, voff, soff, 0);
     }
 };
+template <> struct LatIO<double, 2> {
+    static __device__ __forceinline__ void load_xy(__amdgpu_buffer_rsrc_t r, int voff, int soff, double* x, double* y) {
+        const lat_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+        const lat_u32x4 w = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff + 16, 0);
+        x[0] = lat_clamp(lat_f64(v.x, v.y)); y[0] = lat_clamp(lat_f64(v.z, v.w));
+        x[1] = lat_clamp(lat_f64(w.x, w.y)); y[1] = lat_clamp(lat_f64(w.z, w.w));
+    }
+    static __device__ __forceinline__ void store(__amdgpu_buffer_rsrc_t r, int voff, int soff, const double* v) {
+        const lat_u32x4 w = {static_cast<unsigned>(__double2loint(v[0])), static_cast<unsigned>(__double2hiint(v[0])),
+                             static_cast<unsigned>(__double2loint(v[1])), static_cast<unsigned>(__double2hiint(v[1]))};
+        __builtin_amdgcn_raw_buffer_store_b128(w, r, voff, soff, 0);
+    }
+};
+// Single elements (the corner cells), addressed by their column's byte offset.
+__device__ __forceinline__ float lat_load1(__amdgpu_buffer_rsrc_t r, int voff, int soff, float) {
+    return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+}
+__device__ __forceinline__ double lat_load1(__amdgpu_buffer_rsrc_t r, int voff, int soff, double) {
+    const lat_u32x2 w = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
+    return lat_f64(w.x, w.y);
+}
+__device__ __forceinline__ void lat_store1(__amdgpu_buffer_rsrc_t r, int voff, int soff, float v) {
+    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, voff, soff, 0);
+}
+__device__ __forceinline__ void lat_store1(__amdgpu_buffer_rsrc_t r, int voff, int soff, double v) {
+    const lat_u32x2 w = {static_cast<unsigned>(__double2loint(v)), static_cast<unsigned>(__double2hiint(v))};
+    __builtin_amdgcn_raw_buffer_store_b64(w, r, voff, soff, 0);
+}
 
-template <typename L, int MAXW>
+// Wavefronts per block of the lattice kernel for a row stride Up and `cols` columns per lane, and the shift that
+// maps a column to its wavefront (the per-wavefront offsets off[b][wave][n] are indexed by it; the coefficient
+// kernels get both numbers from the host).
+__host__ __device__ inline int lat_waves(int Up, int cols) { return (Up + 64 * cols - 1) / (64 * cols); }
+__host__ __device__ inline int lat_col_shift(int cols) { return cols == 2 ? 7 : 6; }
+
+template <typename L, int MAXW, int COLS>
 __global__ __launch_bounds__(MAXW * 64) void lattice_kernel(
         const LogPair<L>* __restrict__ lp2, L* __restrict__ alpha, L* __restrict__ beta,
         double* __restrict__ offa, double* __restrict__ offb, double* __restrict__ ll_fwd,
         double* __restrict__ ll_bwd, L* __restrict__ costs_dev, const int* __restrict__ xlen,
         const int* __restrict__ ylen, int maxT, int maxU, int Up, int dirs) {
-    constexpr int C = LatChunk<L, MAXW>::C;
+    constexpr int C = LatChunk<L, MAXW, COLS>::C;
     constexpr bool MULTI = MAXW > 1;
-    using IO = LatIO<L>;
-    __shared__ L ring[16][2][C];
-    __shared__ double ringoff[16][2];
+    using IO = LatIO<L, COLS>;
+    __shared__ L ring[MAXW][2][C];
+    __shared__ double ringoff[MAXW][2];
     const int b = blockIdx.x / dirs;
     const int dir = blockIdx.x - b * dirs;
-    const int u = threadIdx.x;
-    const int lane = u & 63;
-    const int wave = uniform(u >> 6);
+    const int tid = threadIdx.x;
+    const int u0 = tid * COLS;                       // first of this lane's COLS adjacent columns
+    const int lane = tid & 63;
+    const int wave = uniform(tid >> 6);
     const int W = blockDim.x >> 6;
     // Lengths live on the device, so the host cannot validate them (the CPU location does: rnnt_cpu.cpp).  A
     // sample whose lengths do not fit the tensor is run on clamped lengths (memory-safe) and its cost becomes
@@ -614,25 +672,35 @@ __global__ __launch_bounds__(MAXW * 64) void lattice_kernel(
         const_cast<LogPair<L>*>(lp2) + sample0, 0, static_cast<int>(Dp * cell_row), 0x00020000);
     const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(
         (dir == 0 ? alpha : beta) + sample0, 0, static_cast<int>(Dp * beta_row), 0x00020000);
-    const int vc = u * static_cast<int>(sizeof(LogPair<L>));          // lane offset of column u in an lp2 row
-    const int vb = u * static_cast<int>(sizeof(L));                   // ... in an alpha / beta row
+    // lane offsets of column u0 in an lp2 row / an alpha-beta row; lanes past the row (COLS = 2 rounds the
+    // block up to whole wavefronts) are parked out of range: they load zeros and store nothing
+    const bool in_row = u0 < Up;
+    const int vc = in_row ? u0 * static_cast<int>(sizeof(LogPair<L>)) : kLatOob;
+    const int vb = in_row ? u0 * static_cast<int>(sizeof(L)) : kLatOob;
     double* off = (dir == 0 ? offa : offb) + (static_cast<size_t>(b) * W + wave) * Dp + kLatPad;
     const L NEG = log_zero<L>();
-    const unsigned Tb_eff = (u < Ub) ? static_cast<unsigned>(Tb) : 0u;   // cell (n-u,u) in the lattice <=> (unsigned)(n-u) < Tb_eff
+    unsigned Tb_eff[COLS];                           // cell (n-u,u) in the lattice <=> (unsigned)(n-u) < Tb_eff
+#pragma unroll
+    for (int c = 0; c < COLS; ++c) Tb_eff[c] = (u0 + c < Ub) ? static_cast<unsigned>(Tb) : 0u;
     const int nsteps = Db - 1;
     const int nchunks = (nsteps + C - 1) / C;
     const int nslots = nchunks + (MULTI ? W - 1 : 0);
     (void)ring; (void)ringoff;
     double Coff = 0.0, Cused = 0.0;
-    L bufA_b[C], bufA_l[C], bufB_b[C], bufB_l[C], hist[C];
+    L bufA_b[C][COLS], bufA_l[C][COLS], bufB_b[C][COLS], bufB_l[C][COLS], hist[C][COLS];
     int jprev = -1;                      // chunk whose results are still in `hist`
+    const int ulast = Ub - 1;            // the column of the terminal cell, its owner lane and slot
+    const bool own_last = (ulast / COLS) == tid;
 
     if (dir == 0) {
         // ------------------------------- alpha -------------------------------
-        L a = (u == 0) ? L(0) : NEG;
-        if (u == 0) IO::store(rb, vb, kLatPad * beta_row, L(0));
+        L a[COLS];
+#pragma unroll
+        for (int c = 0; c < COLS; ++c) a[c] = (u0 + c == 0) ? L(0) : NEG;
+        L up = NEG;                                  // shifted neighbour values; lane 0 stays "zero" (see the step)
+        if (tid == 0) lat_store1(rb, 0, kLatPad * beta_row, L(0));
         if (lane == 0) off[0] = 0.0;
-        auto fetch = [&](int j, L* xb, L* xl) {     // chunk j: diagonals j*C+1 .. j*C+C read SOURCE rows j*C .. j*C+C-1
+        auto fetch = [&](int j, L (*xb)[COLS], L (*xl)[COLS]) {     // chunk j: diagonals j*C+1 .. j*C+C read SOURCE rows j*C .. j*C+C-1
 #pragma unroll
             for (int k = 0; k < C; ++k) IO::load_xy(rc, vc, (j * C + k + kLatPad) * cell_row, xb[k], xl[k]);
         };
@@ -641,7 +709,7 @@ __global__ __launch_bounds__(MAXW * 64) void lattice_kernel(
             for (int k = 0; k < C; ++k) IO::store(rb, vb, (jprev * C + 1 + k + kLatPad) * beta_row, hist[k]);
             if (lane < C) off[jprev * C + 1 + lane] = Cused;
         };
-        auto chunk = [&](int s, int j, const L* pb, const L* pl, L* nb, L* nl) {
+        auto chunk = [&](int s, int j, const L (*pb)[COLS], const L (*pl)[COLS], L (*nb)[COLS], L (*nl)[COLS]) {
             if (jprev >= 0) flush();
             fetch(j + 1 < nchunks ? j + 1 : j, nb, nl);       // (stay inside the back padding)
             L inv = NEG;
@@ -655,15 +723,22 @@ __global__ __launch_bounds__(MAXW * 64) void lattice_kernel(
             L outv = NEG;
 #pragma unroll
             for (int k = 0; k < C; ++k) {
-                const L stay = a + pb[k];
-                const L emit = a + pl[k];
-                L up = wave_shr1(emit, NEG);
+                L stay[COLS], emit[COLS];
+#pragma unroll
+                for (int c = 0; c < COLS; ++c) { stay[c] = a[c] + pb[k][c]; emit[c] = a[c] + pl[k][c]; }
+                // the left neighbour of column u0 is the previous lane's last column; lane 0 of `up` is never
+                // written by the shift (it keeps the "zero" it started with) or takes the neighbouring
+                // wavefront's boundary value: one readlane + one writelane, no branch
+                up = wave_shr1(up, emit[COLS - 1]);
                 if constexpr (MULTI) {
-                    up = (lane == 0) ? lane_get(inv, k) : up;
-                    outv = lane_set(outv, lane_get(emit, 63), k);
+                    up = lane_set(up, lane_get(inv, k), 0);
+                    outv = lane_set(outv, lane_get(emit[COLS - 1], 63), k);
                 }
-                a = log2_add(stay, up);
-                hist[k] = a;
+                a[0] = log2_add(stay[0], up);
+#pragma unroll
+                for (int c = 1; c < COLS; ++c) a[c] = log2_add(stay[c], emit[c - 1]);
+#pragma unroll
+                for (int c = 0; c < COLS; ++c) hist[k][c] = a[c];
             }
             jprev = j;
             Cused = Coff;
@@ -672,11 +747,18 @@ __global__ __launch_bounds__(MAXW * 64) void lattice_kernel(
                 if (lane == 0) ringoff[wave][s & 1] = Coff;
             }
             if (j + 1 < nchunks) {                       // re-centre (not after the final diagonal)
-                // maximum over the lanes that are INSIDE the lattice on this diagonal only: whatever
+                // maximum over the cells that are INSIDE the lattice on this diagonal only: whatever
                 // sits in the others must not steer the offset
-                const bool inside = static_cast<unsigned>(j * C + C - u) < Tb_eff;
-                const L m = wave_max_dpp(inside ? a : NEG);
-                if (m > NEG * L(0.5)) { a -= m; Coff += static_cast<double>(m); }   // skip all-"zero" waves
+                L mine = NEG;
+#pragma unroll
+                for (int c = 0; c < COLS; ++c)
+                    mine = vmax(mine, static_cast<unsigned>(j * C + C - (u0 + c)) < Tb_eff[c] ? a[c] : NEG);
+                const L m = wave_max_dpp(mine);
+                if (m > NEG * L(0.5)) {                  // skip all-"zero" waves
+#pragma unroll
+                    for (int c = 0; c < COLS; ++c) a[c] -= m;
+                    Coff += static_cast<double>(m);
+                }
             }
         };
         fetch(0, bufA_b, bufA_l);
@@ -697,27 +779,32 @@ __global__ __launch_bounds__(MAXW * 64) void lattice_kernel(
             }
         }
         if (jprev >= 0) flush();
-        if (u == Ub - 1) {
-            // alpha(T-1,U-1) of this column: read it back (same thread wrote it), with the offset
-            // that was current when its diagonal was stored
-            const L a_last = (nsteps == 0) ? L(0) : IO::load(rb, vb, (Db - 1 + kLatPad) * beta_row);
+        if (own_last) {
+            // alpha(T-1,U-1): read it back (this thread wrote it), with the offset that was current when its
+            // diagonal was stored
+            const int vb1 = ulast * static_cast<int>(sizeof(L)), vc1 = ulast * static_cast<int>(sizeof(LogPair<L>));
+            const L a_last = (nsteps == 0) ? L(0) : lat_load1(rb, vb1, (Db - 1 + kLatPad) * beta_row, L(0));
             const double o_last = (nsteps == 0) ? 0.0 : Cused;   // the last chunk is never re-centred
-            L xl_, xb_;
-            IO::load_xy(rc, vc, (Db - 1 + kLatPad) * cell_row, xb_, xl_);
+            const L xb_ = lat_clamp(lat_load1(rc, vc1, (Db - 1 + kLatPad) * cell_row, L(0)));
             const double ll2 = static_cast<double>(a_last) + o_last + static_cast<double>(xb_);
             ll_fwd[b] = ll2;                                  // base 2, for the coefficient kernel
             costs_dev[b] = bad_len ? cost_invalid<L>() : static_cast<L>(-ll2 * kLn2);
         }
     } else {
         // ------------------------------- beta -------------------------------
-        L bv = NEG;
-        if (u == Ub - 1) {
-            L xl_;
-            IO::load_xy(rc, vc, (Db - 1 + kLatPad) * cell_row, bv, xl_);
-            IO::store(rb, vb, (Db - 1 + kLatPad) * beta_row, bv);
+        L bv[COLS];
+#pragma unroll
+        for (int c = 0; c < COLS; ++c) bv[c] = NEG;
+        if (own_last) {
+            const int vb1 = ulast * static_cast<int>(sizeof(L)), vc1 = ulast * static_cast<int>(sizeof(LogPair<L>));
+            const L x = lat_clamp(lat_load1(rc, vc1, (Db - 1 + kLatPad) * cell_row, L(0)));
+#pragma unroll
+            for (int c = 0; c < COLS; ++c) bv[c] = (u0 + c == ulast) ? x : bv[c];
+            lat_store1(rb, vb1, (Db - 1 + kLatPad) * beta_row, x);
         }
+        L right = NEG;                               // shifted neighbour values; lane 63 stays "zero"
         if (lane == 0) off[Db - 1] = 0.0;
-        auto fetch = [&](int j, L* xb, L* xl) {     // chunk j: steps i = j*C .. j*C+C-1, TARGET rows n = Db-2-i
+        auto fetch = [&](int j, L (*xb)[COLS], L (*xl)[COLS]) {     // chunk j: steps i = j*C .. j*C+C-1, TARGET rows n = Db-2-i
 #pragma unroll
             for (int k = 0; k < C; ++k) IO::load_xy(rc, vc, (Db - 2 - (j * C + k) + kLatPad) * cell_row, xb[k], xl[k]);
         };
@@ -726,7 +813,7 @@ __global__ __launch_bounds__(MAXW * 64) void lattice_kernel(
             for (int k = 0; k < C; ++k) IO::store(rb, vb, (Db - 2 - (jprev * C + k) + kLatPad) * beta_row, hist[k]);
             if (lane < C) off[Db - 2 - (jprev * C + lane)] = Cused;
         };
-        auto chunk = [&](int s, int j, const L* pb, const L* pl, L* nb, L* nl) {
+        auto chunk = [&](int s, int j, const L (*pb)[COLS], const L (*pl)[COLS], L (*nb)[COLS], L (*nl)[COLS]) {
             if (jprev >= 0) flush();
             fetch(j + 1 < nchunks ? j + 1 : j, nb, nl);      // (no rows below the front padding)
             L inv = NEG;
@@ -740,15 +827,22 @@ __global__ __launch_bounds__(MAXW * 64) void lattice_kernel(
             L outv = NEG;
 #pragma unroll
             for (int k = 0; k < C; ++k) {
-                L right = wave_shl1(bv, NEG);
+                // the right neighbour of the lane's last column is the next lane's first; lane 63 of `right`
+                // keeps its "zero" or takes the neighbouring wavefront's boundary value
+                right = wave_shl1(right, bv[0]);
                 if constexpr (MULTI) {
-                    right = (lane == 63) ? lane_get(inv, k) : right;
-                    outv = lane_set(outv, lane_get(bv, 0), k);
+                    right = lane_set(right, lane_get(inv, k), 63);
+                    outv = lane_set(outv, lane_get(bv[0], 0), k);
                 }
-                const L stay = bv + pb[k];
-                const L emit = right + pl[k];
-                bv = log2_add(stay, emit);
-                hist[k] = bv;
+                L nv[COLS];
+#pragma unroll
+                for (int c = 0; c < COLS; ++c) {
+                    const L stay = bv[c] + pb[k][c];
+                    const L emit = (c + 1 < COLS ? bv[c + 1 < COLS ? c + 1 : c] : right) + pl[k][c];
+                    nv[c] = log2_add(stay, emit);
+                }
+#pragma unroll
+                for (int c = 0; c < COLS; ++c) { bv[c] = nv[c]; hist[k][c] = nv[c]; }
             }
             jprev = j;
             Cused = Coff;
@@ -757,9 +851,16 @@ __global__ __launch_bounds__(MAXW * 64) void lattice_kernel(
                 if (lane == 0) ringoff[wave][s & 1] = Coff;
             }
             if (j + 1 < nchunks) {
-                const bool inside = static_cast<unsigned>(Db - 2 - (j * C + C - 1) - u) < Tb_eff;
-                const L m = wave_max_dpp(inside ? bv : NEG);
-                if (m > NEG * L(0.5)) { bv -= m; Coff += static_cast<double>(m); }
+                L mine = NEG;
+#pragma unroll
+                for (int c = 0; c < COLS; ++c)
+                    mine = vmax(mine, static_cast<unsigned>(Db - 2 - (j * C + C - 1) - (u0 + c)) < Tb_eff[c] ? bv[c] : NEG);
+                const L m = wave_max_dpp(mine);
+                if (m > NEG * L(0.5)) {
+#pragma unroll
+                    for (int c = 0; c < COLS; ++c) bv[c] -= m;
+                    Coff += static_cast<double>(m);
+                }
             }
         };
         fetch(0, bufA_b, bufA_l);
@@ -780,8 +881,8 @@ __global__ __launch_bounds__(MAXW * 64) void lattice_kernel(
             }
         }
         if (jprev >= 0) flush();
-        if (u == 0) {
-            const L b0 = IO::load(rb, vb, kLatPad * beta_row);
+        if (tid == 0) {
+            const L b0 = lat_load1(rb, 0, kLatPad * beta_row, L(0));
             ll_bwd[b] = (static_cast<double>(b0) + (nsteps == 0 ? 0.0 : Cused)) * kLn2;
         }
     }
@@ -802,50 +903,68 @@ constexpr int kPadded = -2;
 // 4 = the plane of c replaces the records (it must fit their memory: ceil8(maxU) <= 4 maxU), else 3.
 __host__ __device__ inline int joint_planes_onehot(int maxU) { return joint_upad(maxU) <= 4 * maxU ? 4 : 3; }
 
-// The record of one lattice cell (b, t, u) on diagonal n = t + u (the caller guarantees that the cell is a
-// row of the tensor).  Padded cells: c = "log zero" (exp(x + c) = 0 for any x), no corrections, flagged.
+// Everything the record of one lattice cell needs from memory.  coef_fetch() issues all of it UNCONDITIONALLY
+// from addresses that are valid for any (n, u) of the skewed index space (clamped label index; the neighbour
+// rows n+1 lie in the back padding at worst; `beta` carries Up+64 elements of slack), so the loads of a cell --
+// and, in the tiled kernel, of all the cells a wavefront works on -- are ONE memory round trip.  Behind the
+// `last_t` / `last_u` branches they were three dependent round trips per cell, and the tiled kernel on the c4
+// lattice was bound by exactly that latency (block lifetime 24 us = 8 cells x 3 round trips per wavefront).
+template <typename L> struct CoefRaw {
+    LogPair<L> p; L lz, al, b0, b1, b2;
+    double oa, ob, ob1, obr;
+    int lab;
+};
+
 template <typename L>
-__device__ __forceinline__ Cell<L> coef_cell(
+__device__ __forceinline__ CoefRaw<L> coef_fetch(
         const LogPair<L>* __restrict__ lp2, const L* __restrict__ logz, const L* __restrict__ alpha_arr,
         const L* __restrict__ beta, const double* __restrict__ offa, const double* __restrict__ offb,
-        const double* __restrict__ ll_fwd, const int* __restrict__ labels, int b, int n, int t, int u, int Tb,
-        int Ub, int maxT, int maxU, int Up, float fastemit) {
+        const int* __restrict__ labels, int b, int n, int u, int maxT, int maxU, int Up, int lw, int lsh) {
+    CoefRaw<L> r;
+    const size_t Dp = lat_rows(maxT, maxU);
+    const size_t idx = lat_index(b, n, u, maxT, maxU, Up);
+    r.p = lp2[idx];
+    r.lz = logz[idx];
+    r.al = alpha_arr[idx];
+    const L* bp = beta + idx;
+    r.b0 = bp[0]; r.b1 = bp[Up]; r.b2 = bp[Up + 1];
+    // offsets are per wavefront of the lattice block: column u belongs to wave u >> lsh
+    const double* oa = offa + (static_cast<size_t>(b) * lw + (u >> lsh)) * Dp + kLatPad;
+    const double* ob = offb + (static_cast<size_t>(b) * lw + (u >> lsh)) * Dp + kLatPad;
+    const double* ob_r = offb + (static_cast<size_t>(b) * lw + ((u + 1) >> lsh)) * Dp + kLatPad;   // column u+1
+    r.oa = oa[n]; r.ob = ob[n]; r.ob1 = ob[n + 1]; r.obr = ob_r[n + 1];
+    r.lab = maxU > 1 ? labels[static_cast<size_t>(b) * (maxU - 1) + (u < maxU - 1 ? u : maxU - 2)] : 0;
+    return r;
+}
+
+// The record of lattice cell (t, u) from its fetched operands; ll2 = log2 P(y|x) of the sample.  Padded cells
+// (t >= T_b or u >= U_b): c = "log zero" (exp(x + c) = 0 for any x), no corrections, flagged.
+template <typename L>
+__device__ __forceinline__ Cell<L> coef_eval(const CoefRaw<L>& r, double ll2, int t, int u, int Tb, int Ub, float fastemit) {
     Cell<L> o;
     o.x = log_zero<L>(); o.y = 0; o.z = 0; o.w = static_cast<L>(kPadded);
     if (t < Tb && u < Ub) {
-        const size_t Dp = lat_rows(maxT, maxU);
-        const int W = Up >> 6;
-        const size_t idx = lat_index(b, n, u, maxT, maxU, Up);
-        Cell<L> r;
-        {
-            const LogPair<L> p = lp2[idx];
-            r.x = p.x; r.y = p.y; r.z = logz[idx]; r.w = alpha_arr[idx];
-        }
-        const L* bp = beta + idx;
-        // offsets are per wavefront of the lattice block: column u belongs to wave u/64
-        const double* oa = offa + (static_cast<size_t>(b) * W + (u >> 6)) * Dp + kLatPad;
-        const double* ob = offb + (static_cast<size_t>(b) * W + (u >> 6)) * Dp + kLatPad;
-        const double* ob_r = offb + (static_cast<size_t>(b) * W + ((u + 1) >> 6)) * Dp + kLatPad;   // column u+1
         // everything below is in base-2 logs until the final conversion
-        const double alpha = static_cast<double>(r.w) + oa[n] - ll_fwd[b];     // log2 alpha(t,u) - log2 P(y|x)
+        const double alpha = static_cast<double>(r.al) + r.oa - ll2;         // log2 alpha(t,u) - log2 P(y|x)
         const bool last_t = (t == Tb - 1), last_u = (u == Ub - 1);
-        o.x = static_cast<L>((alpha + static_cast<double>(bp[0]) + ob[n]) * kLn2 - static_cast<double>(r.z));
+        const double occ = alpha + static_cast<double>(r.b0) + r.ob;         // log2 of the cell's occupancy
+        o.x = static_cast<L>(occ * kLn2 - static_cast<double>(r.lz));
         if (!last_t)
-            o.y = fast_exp2(static_cast<L>(alpha + static_cast<double>(r.x) + static_cast<double>(bp[Up]) + ob[n + 1]));
+            o.y = fast_exp2(static_cast<L>(alpha + static_cast<double>(r.p.x) + static_cast<double>(r.b1) + r.ob1));
         else if (last_u)
-            o.y = fast_exp2(static_cast<L>(alpha + static_cast<double>(r.x)));
+            o.y = fast_exp2(static_cast<L>(alpha + static_cast<double>(r.p.x)));
         int lab = -1;
         if (!last_u) {
-            const double arg_l = alpha + static_cast<double>(r.y) + static_cast<double>(bp[Up + 1]) + ob_r[n + 1];
+            const double arg_l = alpha + static_cast<double>(r.p.y) + static_cast<double>(r.b2) + r.obr;
             o.z = fast_exp2(static_cast<L>(arg_l));
-            lab = labels[static_cast<size_t>(b) * (maxU - 1) + u];
+            lab = r.lab;
             if (fastemit != 0.0f) {
                 // FastEmit (Yu et al. 2021, the form NVIDIA NeMo's RNN-T loss uses): the label
                 // transition's log-prob gradient is scaled by (1 + lambda).  In the record form
                 //   g_v = p_v (gamma + lambda cl) - [v=blank] cb - [v=label] (1 + lambda) cl,   gamma = exp(alpha+beta-ll)
                 // so c grows by log(1 + lambda cl/gamma) (cl/gamma <= 1, formed from the two exponents) and cl
                 // by the factor (1 + lambda); the gradient kernel is unchanged.
-                const double ratio = exp2(arg_l - (alpha + static_cast<double>(bp[0]) + ob[n]));
+                const double ratio = exp2(arg_l - occ);
                 o.x += static_cast<L>(log1p(static_cast<double>(fastemit) * (ratio < 1.0 ? ratio : 1.0)));
                 o.z *= static_cast<L>(1.0f + fastemit);
             }
@@ -869,7 +988,7 @@ __global__ __launch_bounds__(256) void coef_cell_kernel(
         const double* __restrict__ offb, const double* __restrict__ ll_fwd,
         const int* __restrict__ labels, const int* __restrict__ xlen, const int* __restrict__ ylen,
         Cell<L>* __restrict__ rowtab, int maxT, int maxU, int Up, float* __restrict__ wmat, int Upad, float fastemit,
-        int planes, const long long* __restrict__ offsets) {   // offsets: packed row order (see row_stats_kernel)   // planes: 1 = W only; 3 = W, CB, CL (one-hot df corrections); 4 = W, CB, CL and a plane of c
+        int planes, const long long* __restrict__ offsets, int lw, int lsh) {   // offsets: packed row order (see row_stats_kernel)   // planes: 1 = W only; 3 = W, CB, CL (one-hot df corrections); 4 = W, CB, CL and a plane of c
                         // that is written INTO the record table's memory (stride Upad <= 4 maxU floats) instead of
                         // the records -- with the one-hot DF nothing reads cb / cl / label per record any more,
                         // and 16 instead of 28 bytes leave per cell
@@ -885,8 +1004,8 @@ __global__ __launch_bounds__(256) void coef_cell_kernel(
     const size_t plane = static_cast<size_t>(gridDim.y) * maxT * Upad;      // gridDim.y = N
     if (u >= maxU || t < 0 || t >= maxT) return;              // not a row of the tensor
     const int Tb = clamp_len(xlen[b], maxT), Ub = clamp_len(ylen[b] + 1, maxU);
-    const Cell<L> o = coef_cell<L>(lp2, logz, alpha_arr, beta, offa, offb, ll_fwd, labels, b, n, t, u, Tb, Ub, maxT, maxU,
-                                   Up, fastemit);
+    const CoefRaw<L> raw = coef_fetch<L>(lp2, logz, alpha_arr, beta, offa, offb, labels, b, n, u, maxT, maxU, Up, lw, lsh);
+    const Cell<L> o = coef_eval<L>(raw, ll_fwd[b], t, u, Tb, Ub, fastemit);
     if (offsets != nullptr) {
         if (t < Tb && u < Ub) rowtab[static_cast<size_t>(offsets[b]) + static_cast<size_t>(t) * Ub + u] = o;
     } else if (planes != 4) {
@@ -921,7 +1040,7 @@ __global__ __launch_bounds__(256) void coef_kernel(
         const double* __restrict__ offb, const double* __restrict__ ll_fwd,
         const int* __restrict__ labels, const int* __restrict__ xlen, const int* __restrict__ ylen,
         Cell<L>* __restrict__ rowtab, int maxT, int maxU, int Up, float* __restrict__ wmat, int Upad, int tilesU,
-        float fastemit, int planes, const long long* __restrict__ offsets) {
+        float fastemit, int planes, const long long* __restrict__ offsets, int lw, int lsh) {
     constexpr int DN = sizeof(L) == 4 ? 32 : 16;           // diagonals per tile (LDS: DN * 64 records)
     __shared__ Cell<L> recs[DN][64];
     const int b = blockIdx.y;
@@ -931,16 +1050,25 @@ __global__ __launch_bounds__(256) void coef_kernel(
     const int D = maxT + maxU - 1;
     const int Tb = clamp_len(xlen[b], maxT), Ub = clamp_len(ylen[b] + 1, maxU);
 
-    // ---- compute, skewed order
+    // ---- compute, skewed order: all operands of the wavefront's DN/4 cells are requested first (one round trip)
     {
+        constexpr int K = DN / 4;                          // diagonals per wavefront
         const int u = u0 + lane;
-#pragma unroll 2
-        for (int dn = wave; dn < DN; dn += 4) {
+        const int uc = u < maxU ? u : maxU - 1;            // columns past the lattice fetch a valid one, their record is padding
+        const double ll2 = ll_fwd[b];
+        CoefRaw<L> raw[K];
+#pragma unroll
+        for (int i = 0; i < K; ++i) {
+            const int n = n0 + wave + 4 * i;
+            raw[i] = coef_fetch<L>(lp2, logz, alpha_arr, beta, offa, offb, labels, b, n < D ? n : D - 1, uc, maxT, maxU, Up, lw, lsh);
+        }
+#pragma unroll
+        for (int i = 0; i < K; ++i) {
+            const int dn = wave + 4 * i;
             const int n = n0 + dn, t = n - u;
             Cell<L> o;
             o.x = log_zero<L>(); o.y = 0; o.z = 0; o.w = static_cast<L>(kPadded);
-            if (n < D && u < maxU && t >= 0 && t < maxT)
-                o = coef_cell<L>(lp2, logz, alpha_arr, beta, offa, offb, ll_fwd, labels, b, n, t, u, Tb, Ub, maxT, maxU, Up, fastemit);
+            if (n < D && u < maxU && t >= 0 && t < maxT) o = coef_eval<L>(raw[i], ll2, t, u, Tb, Ub, fastemit);
             recs[dn][lane] = o;
         }
     }

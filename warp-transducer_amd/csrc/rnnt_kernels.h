@@ -919,7 +919,7 @@ template <typename L>
 __device__ __forceinline__ CoefRaw<L> coef_fetch(
         const LogPair<L>* __restrict__ lp2, const L* __restrict__ logz, const L* __restrict__ alpha_arr,
         const L* __restrict__ beta, const double* __restrict__ offa, const double* __restrict__ offb,
-        const int* __restrict__ labels, int b, int n, int u, int maxT, int maxU, int Up, int lw, int lsh) {
+        const int* __restrict__ labels, int b, int n, int u, int maxT, int maxU, int Up, int lw, int lsh, int wu) {
     CoefRaw<L> r;
     const size_t Dp = lat_rows(maxT, maxU);
     const size_t idx = lat_index(b, n, u, maxT, maxU, Up);
@@ -928,9 +928,12 @@ __device__ __forceinline__ CoefRaw<L> coef_fetch(
     r.al = alpha_arr[idx];
     const L* bp = beta + idx;
     r.b0 = bp[0]; r.b1 = bp[Up]; r.b2 = bp[Up + 1];
-    // offsets are per wavefront of the lattice block: column u belongs to wave u >> lsh
-    const double* oa = offa + (static_cast<size_t>(b) * lw + (u >> lsh)) * Dp + kLatPad;
-    const double* ob = offb + (static_cast<size_t>(b) * lw + (u >> lsh)) * Dp + kLatPad;
+    // offsets are per wavefront of the lattice block: column u belongs to wave u >> lsh.  `wu` is that index
+    // for the columns of THIS wavefront when they share it (the kernels below: 64 consecutive columns starting
+    // at a multiple of 64, n wave-uniform): the three offsets are then scalar loads into SGPRs; -1 = per lane.
+    const int wi = wu >= 0 ? wu : (u >> lsh);
+    const double* oa = offa + (static_cast<size_t>(b) * lw + wi) * Dp + kLatPad;
+    const double* ob = offb + (static_cast<size_t>(b) * lw + wi) * Dp + kLatPad;
     const double* ob_r = offb + (static_cast<size_t>(b) * lw + ((u + 1) >> lsh)) * Dp + kLatPad;   // column u+1
     r.oa = oa[n]; r.ob = ob[n]; r.ob1 = ob[n + 1]; r.obr = ob_r[n + 1];
     r.lab = maxU > 1 ? labels[static_cast<size_t>(b) * (maxU - 1) + (u < maxU - 1 ? u : maxU - 2)] : 0;
@@ -1004,7 +1007,8 @@ __global__ __launch_bounds__(256) void coef_cell_kernel(
     const size_t plane = static_cast<size_t>(gridDim.y) * maxT * Upad;      // gridDim.y = N
     if (u >= maxU || t < 0 || t >= maxT) return;              // not a row of the tensor
     const int Tb = clamp_len(xlen[b], maxT), Ub = clamp_len(ylen[b] + 1, maxU);
-    const CoefRaw<L> raw = coef_fetch<L>(lp2, logz, alpha_arr, beta, offa, offb, labels, b, n, u, maxT, maxU, Up, lw, lsh);
+    const int wu = uniform(static_cast<int>(i0 - static_cast<long long>(n) * Up) >> lsh);    // this wavefront's 64 columns share it
+    const CoefRaw<L> raw = coef_fetch<L>(lp2, logz, alpha_arr, beta, offa, offb, labels, b, n, u, maxT, maxU, Up, lw, lsh, wu);
     const Cell<L> o = coef_eval<L>(raw, ll_fwd[b], t, u, Tb, Ub, fastemit);
     if (offsets != nullptr) {
         if (t < Tb && u < Ub) rowtab[static_cast<size_t>(offsets[b]) + static_cast<size_t>(t) * Ub + u] = o;
@@ -1060,7 +1064,8 @@ __global__ __launch_bounds__(256) void coef_kernel(
 #pragma unroll
         for (int i = 0; i < K; ++i) {
             const int n = n0 + wave + 4 * i;
-            raw[i] = coef_fetch<L>(lp2, logz, alpha_arr, beta, offa, offb, labels, b, n < D ? n : D - 1, uc, maxT, maxU, Up, lw, lsh);
+            raw[i] = coef_fetch<L>(lp2, logz, alpha_arr, beta, offa, offb, labels, b, n < D ? n : D - 1, uc, maxT, maxU, Up, lw, lsh,
+                                   u0 >> lsh);
         }
 #pragma unroll
         for (int i = 0; i < K; ++i) {

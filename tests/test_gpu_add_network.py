@@ -267,3 +267,28 @@ def test_validation_errors():
         rnnt_loss_add(f.cpu(), g.cpu(), lab.cpu(), tl.cpu(), ll.cpu())
     with pytest.raises(ValueError):
         rnnt_loss_add(f, g, lab, torch.tensor([3, 3], dtype=torch.int32, device=dev), ll)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("shape", [(3, 20, 9, 40), (2, 33, 21, 257), (2, 40, 35, 2048)])
+def test_sixteen_bit_activations(oracle, dtype, shape):
+    """bfloat16 / float16 activations (staged through float32 inside `rnnt_loss_add`): the loss against the oracle on
+    the ROUNDED inputs, the gradients in the activations' dtype within that dtype's rounding of the fp32 result."""
+    from warprnnt_pytorch.add_network import RNNTLossAdd
+    f, g, labels, tl, ll, blank = problem(shape, sum(shape) + 3)
+    dev = torch.device("cuda:0")
+    tf = torch.tensor(f, device=dev).to(dtype).requires_grad_(True)
+    tg = torch.tensor(g, device=dev).to(dtype).requires_grad_(True)
+    args = (torch.tensor(labels, device=dev), torch.tensor(tl, device=dev), torch.tensor(ll, device=dev))
+    loss = RNNTLossAdd(blank=blank, reduction="none")(tf, tg, *args)
+    loss.sum().backward()
+    assert loss.dtype == torch.float32 and tf.grad.dtype == dtype and tg.grad.dtype == dtype
+    fr, gr = tf.detach().double().cpu().numpy(), tg.detach().double().cpu().numpy()
+    z = fr[:, :, None, :] + gr[:, None, :, :]
+    ref_c, ref_gz = oracle.rnnt_logits(z, labels, tl, ll, blank)
+    assert np.abs(loss.double().cpu().numpy() - ref_c).max() <= 1e-4 * max(1.0, np.abs(ref_c).max())
+    rdf, rdg = ref_gz.sum(axis=2), ref_gz.sum(axis=1)
+    ulp = 2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11          # half an ulp of the STORED gradient, relative
+    N, T, U, A = shape
+    assert (np.abs(tf.grad.double().cpu().numpy() - rdf) <= 2e-4 * max(1.0, U / 32) + ulp * np.abs(rdf) + 1e-6).all()
+    assert (np.abs(tg.grad.double().cpu().numpy() - rdg) <= 2e-4 * max(1.0, T / 32) + ulp * np.abs(rdg) + 1e-6).all()

@@ -219,6 +219,27 @@ def test_pytorch_binding_on_gpu(monkeypatch, async_entry):
         assert np.allclose(m.item(), cost / n, rtol=1e-5)
 
 
+def test_pinned_host_costs_are_written_directly():
+    """Host costs in pinned memory take the direct-write route (no staged D2H copy): same values, bit for bit, as
+    pageable costs; an invalid device-side length is still reported."""
+    from warprnnt_pytorch import warp_rnnt
+    acts, labels, tl, ll, blank = case_inputs("var_a40")
+    dev = torch.device("cuda:0")
+    x = torch.tensor(acts, dtype=torch.float32, device=dev)
+    lab, tlen, llen = (torch.tensor(a, device=dev) for a in (labels, tl, ll))
+    outs = []
+    for pinned in (False, True):
+        costs = torch.full((x.shape[0],), 7.0, pin_memory=pinned)
+        grads = torch.zeros_like(x)
+        assert warp_rnnt.gpu_rnnt(x, lab, tlen, llen, costs, grads, blank, 0) == 0
+        outs.append((costs.clone(), grads.cpu()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    assert np.abs(outs[1][0].numpy() - FIX["var_a40/costs64"]).max() <= 1e-4 * np.abs(FIX["var_a40/costs64"]).max()
+    bad = tlen.clone(); bad[0] = x.shape[1] + 3
+    with pytest.raises(RuntimeError, match="invalid value"):
+        warp_rnnt.gpu_rnnt(x, lab, bad, llen, torch.zeros(x.shape[0], pin_memory=True), torch.zeros_like(x), blank, 0)
+
+
 def test_determinism():
     acts, labels, tl, ll, blank = case_inputs("wide_u70")
     a = run_gpu(acts, labels, tl, ll, blank)

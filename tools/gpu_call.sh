@@ -1,5 +1,6 @@
 set -x
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-export WARP_RNNT_PATH=$GRAFT_REPO_ROOT/warp-transducer_amd/lib/dev
-( for t in xst=0 xst=0 ; do RNNT_TUNE=$t python tools/stage_times.py c4; done; python tools/stage_times.py c5 c2 c3 ) > gpurun_out/r02i_stage_times.log 2>&1
+( timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -15 ) > gpurun_out/pytest_gpu.log
+( for f in "" "--pinned-costs"; do for w in c2 c5 c3; do python bench.py --workload $w --steps 50 --warmup 5 --no-cpu-baseline $f | python -c "
+import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['config']['workload'][:60], '| value', d['value'], '| median', d['step_ms']['median'], '| plain', d['plain_step_ms'])"; done; done ) > gpurun_out/r02j_pinned.log 2>&1

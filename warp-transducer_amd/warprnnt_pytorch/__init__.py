@@ -61,7 +61,9 @@ class _RNNT(Function):
             # zero-fill is needed (the reference allocates zeros_like: __init__.py:24).
             grads = torch.empty_like(acts) if acts.requires_grad else torch.zeros(0).to(acts)
             loss_func = warp_rnnt.gpu_rnnt if is_cuda else warp_rnnt.cpu_rnnt
-            costs = torch.zeros(minibatch_size, dtype=cost_dtype)   # host, as the C-ABI requires
+            # host, as the C-ABI requires; pinned for the GPU location (the library then writes it from the
+            # lattice kernel instead of staging a pageable copy)
+            costs = torch.zeros(minibatch_size, dtype=cost_dtype, pin_memory=bool(is_cuda))
             # cpu_rnnt / gpu_rnnt keep the reference extension module's behaviour for an unsupported dtype
             # (a line on stderr and -1, binding.cpp:46-81,111-153), which the reference wrapper ignores and
             # then returns a zero loss with zero gradients; here nothing would have been written at all, so

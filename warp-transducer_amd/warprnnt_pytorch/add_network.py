@@ -10,7 +10,10 @@ transducer, whose joint logits are ``trans_acts[:, :, None] + pred_acts[:, None]
 
 but it binds ``compute_rnnt_loss_add`` of include/rnnt.h: exp(f+g) = exp(f) exp(g), so the partition
 function and d(trans_acts) = sum_u, d(pred_acts) = sum_t (docs/rnnt_notes.tex:147-153) are three
-small GEMMs per sample on the fp32 matrix cores (csrc/rnnt_joint_kernels.h).  GPU, float32.
+small GEMMs per sample on the fp32 matrix cores (csrc/rnnt_joint_kernels.h).  GPU.  The kernels are float32;
+bfloat16 / float16 activations are accepted and staged through float32 copies here (the two activations are
+(B,T,V) and (B,U+1,V), not (B,T,U,V): the staging passes are small next to what the fusion saves), their gradients
+come back in the activations' dtype.
 """
 import torch
 from torch.autograd import Function
@@ -36,7 +39,7 @@ def _certify(trans_acts, pred_acts, labels, act_lens, label_lens):
     if not (trans_acts.is_cuda and pred_acts.is_cuda):
         raise ValueError("the additive-joint loss runs on the GPU only")
     if trans_acts.dtype is not torch.float32 or pred_acts.dtype is not torch.float32:
-        raise TypeError("trans_acts and pred_acts must be torch.float32")
+        raise TypeError("trans_acts and pred_acts must be torch.float32 (rnnt_loss_add stages 16-bit inputs)")
     B, T, V = trans_acts.shape
     if pred_acts.shape[0] != B or pred_acts.shape[2] != V:
         raise ValueError("trans_acts (B,T,V) and pred_acts (B,U+1,V) disagree")
@@ -110,7 +113,14 @@ class _RNNTAdd(Function):
 def rnnt_loss_add(trans_acts, pred_acts, labels, act_lens, label_lens, blank=0, reduction="mean",
                   fastemit_lambda=0.0):
     """RNN-T loss of the additive joint ``trans_acts[:, :, None] + pred_acts[:, None]`` without
-    forming it.  Arguments as `rnnt_loss`, with the two activations instead of the joint tensor."""
+    forming it.  Arguments as `rnnt_loss`, with the two activations instead of the joint tensor.
+    float32, or bfloat16 / float16 (staged through float32; the loss is float32, the gradients arrive in the
+    activations' dtype through autograd's cast)."""
+    half = (torch.bfloat16, torch.float16)
+    if trans_acts.dtype in half or pred_acts.dtype in half:
+        if trans_acts.dtype != pred_acts.dtype:
+            raise TypeError("trans_acts and pred_acts must have the same dtype")
+        trans_acts, pred_acts = trans_acts.float(), pred_acts.float()      # differentiable: grads are cast back
     return _RNNTAdd.apply(trans_acts, pred_acts, labels, act_lens, label_lens, blank, reduction, fastemit_lambda)
 
 

@@ -286,7 +286,7 @@ def test_sixteen_bit_activations(oracle, dtype, shape):
     fr, gr = tf.detach().double().cpu().numpy(), tg.detach().double().cpu().numpy()
     z = fr[:, :, None, :] + gr[:, None, :, :]
     ref_c, ref_gz = oracle.rnnt_logits(z, labels, tl, ll, blank)
-    assert np.abs(loss.double().cpu().numpy() - ref_c).max() <= 1e-4 * max(1.0, np.abs(ref_c).max())
+    assert np.abs(loss.detach().double().cpu().numpy() - ref_c).max() <= 1e-4 * max(1.0, np.abs(ref_c).max())
     rdf, rdg = ref_gz.sum(axis=2), ref_gz.sum(axis=1)
     ulp = 2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11          # half an ulp of the STORED gradient, relative
     N, T, U, A = shape

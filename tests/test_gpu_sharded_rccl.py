@@ -35,15 +35,20 @@ def _batch(dev):
     return [t.to(dev) for t in (acts, labels, tl, ll)]
 
 
-def _worker(rank, world, port, reduction, q):
+def _worker(rank, world, port, reduction, q, backend="nccl"):
     for p in (ROOT, os.path.join(ROOT, "warp-transducer_amd")):
         if p not in sys.path:
             sys.path.insert(0, p)
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
-    torch.cuda.set_device(rank)
-    dev = torch.device("cuda", rank)
-    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    if backend == "nccl":
+        torch.cuda.set_device(rank)
+        dev = torch.device("cuda", rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    else:                                   # both ranks on device 0, collectives over gloo (staged through the host)
+        torch.cuda.set_device(0)
+        dev = torch.device("cuda", 0)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     from warprnnt_pytorch.sharded import ShardedRNNTLoss
     acts, labels, tl, ll = _batch(dev)
     n = acts.shape[0] // world
@@ -84,6 +89,35 @@ def test_two_rccl_ranks_equal_single_gpu(reduction):
     n = acts.shape[0] // 2
     for rank, loss, grad in got:
         assert np.allclose(loss, ref.detach().cpu().numpy(), rtol=1e-5, atol=1e-5)     # global loss on every rank
+        assert np.allclose(grad, x.grad[rank * n:(rank + 1) * n].cpu().numpy(), atol=1e-6)
+
+
+@pytest.mark.parametrize("reduction", ["mean", "sum", "none"])
+def test_two_ranks_sharing_one_gpu_over_gloo(reduction):
+    """What a 1-GPU box can exercise of the sharded DEVICE path at world_size 2: two processes, both on cuda:0, each
+    running the HIP hot path (compute_rnnt_loss_fwd / _bwd) on its shard of the batch, the one collective over gloo
+    on the device tensors (RCCL refuses two ranks on one device).  Losses and gradients equal the unsharded run."""
+    import torch.multiprocessing as mp
+    from warprnnt_pytorch import RNNTLoss
+    dev = torch.device("cuda:0")
+    acts, labels, tl, ll = _batch(dev)
+    x = acts.clone().requires_grad_(True)
+    ref = RNNTLoss(reduction=reduction)(x, labels, tl, ll)
+    w = torch.arange(1, ref.numel() + 1, dtype=ref.dtype, device=dev)
+    (ref * w).sum().backward()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, reduction, q, "gloo")) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted((q.get(timeout=300) for _ in procs), key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    n = acts.shape[0] // 2
+    for rank, loss, grad in got:
+        assert np.allclose(loss, ref.detach().cpu().numpy(), rtol=1e-5, atol=1e-5)
         assert np.allclose(grad, x.grad[rank * n:(rank + 1) * n].cpu().numpy(), atol=1e-6)
 
 

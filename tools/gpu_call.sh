@@ -1,5 +1,4 @@
 set -x
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-( timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -15 ) > gpurun_out/pytest_gpu.log
-python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/smoke.log 2>&1
+( timeout 900 python -m pytest tests/test_gpu_sharded_rccl.py -m gpu -x -q 2>&1 | tail -25 ) > gpurun_out/pytest_gpu.log

@@ -15,6 +15,13 @@ libwarprnnt.so -- the drop-in claim of INTEGRATION.md 1-2 as a test.
                                   binding.cpp with INTEGRATION.md 2's three edits (cross-built into
                                   oracle/_ref/binding_gpu/, which travels to the GPU box) under this repo's
                                   wrapper: gpu_rnnt of the reference binding on the MI355X library.
+  test_reference_test_gpu_cu (-m gpu)
+                                  /root/reference/tests/test_gpu.cu UNMODIFIED (oracle/build_ref_gpu_tests.sh maps its
+                                  nine CUDA runtime names to HIP on the compiler command line) -> small_test,
+                                  options_test, inf_test and the finite-difference grad_check of the reference's own GPU
+                                  test program against this library on the MI355X: "Tests pass" (tests/test_gpu.cu:476-500)
+  test_reference_test_time_cu (-m gpu)
+                                  the reference's timing harness tests/test_time.cu, same build, one small run.
 The first two need /root/reference (absent on the GPU box: skipped there)."""
 import glob
 import importlib.util
@@ -118,3 +125,27 @@ def test_reference_gpu_binding(monkeypatch, oracle):
                                 torch.tensor(ll, device=dev), costs, grads, 0, 0) == 0
         assert np.abs(costs.double().numpy() - ref_c).max() <= tol * max(1.0, np.abs(ref_c).max())
         assert np.abs(grads.double().cpu().numpy() - ref_g).max() <= tol
+
+
+def _ref_binary(name):
+    path = os.path.join(ROOT, "oracle", "_ref", name)
+    if not os.path.exists(path):
+        pytest.skip("oracle/_ref/%s was not built (oracle/build_ref_gpu_tests.sh)" % name)
+    return path
+
+
+@pytest.mark.gpu
+def test_reference_test_gpu_cu():
+    out = subprocess.run([_ref_binary("ref_test_gpu")], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert "Tests pass" in out.stdout, out.stdout[-2000:]
+    for name in ("small_test 1", "options_test 1", "inf_test 1"):
+        assert "finish " + name in out.stdout, out.stdout[-2000:]
+
+
+@pytest.mark.gpu
+def test_reference_test_time_cu():
+    """tests/test_time.cu: `test_time B T L A` (README row T=150, L=40, A=28, N=16): ten timed calls, it prints their mean."""
+    out = subprocess.run([_ref_binary("ref_test_time"), "16", "150", "40", "28"], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert "average 10 time cost" in out.stdout, out.stdout[-2000:]

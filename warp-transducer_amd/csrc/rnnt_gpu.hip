@@ -26,7 +26,7 @@ constexpr size_t kAlign = 256;
 static inline size_t align_up(size_t x) { return (x + kAlign - 1) / kAlign * kAlign; }
 
 struct Layout {
-    size_t lp2, logz, alpha, rowtab, beta, offa, offb, llf, llb, costs, rowmax, wmat, total;
+    size_t lp2, logz, alpha, rowtab, beta, offa, offb, llf, llb, costs, rowmax, side, side_bytes, wmat, total;
 };
 
 // lat = bytes of one lattice value (4: fp32 lattice for 16/32-bit activations, 8: fp64).
@@ -50,9 +50,13 @@ static Layout make_layout(int maxT, int maxU, int N, size_t lat, bool joint) {
     l.llb = o;   o = align_up(o + N * sizeof(double));
     l.costs = o; o = align_up(o + N * sizeof(double));
     // additive joint only: row maxima of f and g, dense matrices W, CB, CL (row stride = maxU rounded up to 8)
-    l.rowmax = o; l.wmat = o;
+    l.rowmax = o; l.wmat = o; l.side = o; l.side_bytes = 0;
     if (joint) {
         o = align_up(o + ((static_cast<size_t>(maxT) + maxU) * N + 1) * sizeof(float));   // + the +inf sentinel
+        // correction sums for the GEMM epilogues: sfb[N*maxT] | sgb[N*maxU] | sgl[N*maxU] floats | far flags[N] ints
+        l.side = o;
+        l.side_bytes = ((static_cast<size_t>(maxT) + 2 * static_cast<size_t>(maxU)) * N + N) * sizeof(float);
+        o = align_up(o + l.side_bytes);
         l.wmat = o;   o = align_up(o + 3 * static_cast<size_t>(maxT) * joint_upad(maxU) * N * sizeof(float));   // W | CB | CL
     }
     l.total = o + kAlign;                       // slack to align the caller's base pointer
@@ -148,7 +152,8 @@ template <typename C> struct Plan {
     const int *labels, *input_lengths, *label_lengths;
     LogPair<C>* lp2; C *logz, *alpha, *beta; Cell<C>* rowtab;
     double *offa, *offb, *llf, *llb;
-    float *rowmax, *wmat;
+    float *rowmax, *wmat, *side;
+    size_t side_bytes = 0;
     int lat_cols = 1;              // lattice columns per lane (1 | 2), its wavefronts per block ...
     int lat_w = 1, lat_sh = 6;     // ... and the column -> wavefront shift (coefficient kernels)
     float fastemit = 0.0f;         // FastEmit lambda (extension entries only)
@@ -194,6 +199,8 @@ static bool make_plan(Plan<C>& p, int A, int N, const rnntOptions& opt, void* wo
     p.llb = reinterpret_cast<double*>(ws + lay.llb);
     p.rowmax = reinterpret_cast<float*>(ws + lay.rowmax);
     p.wmat = reinterpret_cast<float*>(ws + lay.wmat);
+    p.side = reinterpret_cast<float*>(ws + lay.side);
+    p.side_bytes = lay.side_bytes;
     p.costs_dev = costs_device_out ? costs_device_out : reinterpret_cast<C*>(ws + lay.costs);
     return true;
 }
@@ -280,7 +287,9 @@ template <typename C> static void launch_lattice(Plan<C>& p, bool with_beta) {
 template <typename C> static void launch_coef(Plan<C>& p, bool joint = false, bool onehot = false) {
     float* wmat = joint ? p.wmat : nullptr;
     const int Upad = joint_upad(p.maxU);
-    const int planes = onehot ? joint_planes_onehot(p.maxU) : 1;
+    // additive joint: W and CL planes always (the DF kernel takes its label corrections from CL); small
+    // vocabularies add CB and replace the records by a plane of c
+    const int planes = onehot ? joint_planes_onehot(p.maxU) : (joint ? 2 : 1);
     if (p.maxU <= 48 || !tune().ctile) {
         // small lattices: one thread per skewed cell, scattered record store
         const long long skew_cells = static_cast<long long>(p.maxT + p.maxU - 1) * p.Up;
@@ -471,7 +480,8 @@ static rnntStatus_t run_gpu_joint(const float* f, const float* g, float* df, flo
         const dim3 rgrid(static_cast<unsigned>(per_block ? rows : (rows + 3) / 4));
 #define RNNT_JMAX(VV, WW)                                                                                      \
     hipLaunchKernelGGL((joint_rowmax_kernel<VV, WW>), rgrid, dim3(256), 0, p.stream, f, g, input_lengths,       \
-                       label_lengths, p.rowmax, maxT, maxU, A, N)
+                       label_lengths, p.rowmax, maxT, maxU, A, N, training ? p.side : nullptr,                  \
+                       static_cast<unsigned>(p.side_bytes / sizeof(float)))
         if (per_block) { if (vec) RNNT_JMAX(true, 4); else RNNT_JMAX(false, 4); }
         else { if (vec) RNNT_JMAX(true, 1); else RNNT_JMAX(false, 1); }
 #undef RNNT_JMAX
@@ -502,10 +512,23 @@ static rnntStatus_t run_gpu_joint(const float* f, const float* g, float* df, flo
     // small vocabularies: the df corrections ride along in the DF GEMM as one-hot operands (3x its
     // contraction) instead of one global atomic per lattice cell in the fix-up kernel
     const bool onehot = tune().joh >= 0 ? tune().joh != 0 : A <= 256;
-    if (do_fwd && training) launch_coef(p, /*joint=*/true, onehot);
+    // correction sums (fp32 side vectors in the workspace) for the epilogues of the gradient GEMMs
+    float* sfb = p.side;
+    float* sgb = sfb + static_cast<size_t>(N) * maxT;
+    float* sgl = sgb + static_cast<size_t>(N) * maxU;
+    int* farflag = reinterpret_cast<int*>(sgl + static_cast<size_t>(N) * maxU);
+    const float* cplanes = onehot && joint_planes_onehot(maxU) == 4 ? p.wmat : nullptr;   // c / cb / cl as dense planes
+    const dim3 fixgrid((maxU + 63) / 64, (maxT + kJointFixT - 1) / kJointFixT, N);
+    if (do_fwd && training) {
+        launch_coef(p, /*joint=*/true, onehot);
+        hipLaunchKernelGGL(joint_sums_kernel, fixgrid, dim3(256), 0, p.stream, p.rowtab, input_lengths, label_lengths, sfb,
+                           sgb, sgl, farflag, maxT, maxU, N, cplanes, joint_upad(maxU));
+        p.check();
+    }
     mark(3);
     if (do_bwd) {
-        // gradient GEMMs (plain stores of every element, padding included), then the corrections.
+        // gradient GEMMs with the corrections in their epilogues (plain stores of every element, padding
+        // included), then the far cells (rare).
         // NK adjacent columns per lane = the widest vector the vocabulary size and alignment allow.
         const int Upad = joint_upad(maxU);
         const uintptr_t all4 = reinterpret_cast<uintptr_t>(f) | reinterpret_cast<uintptr_t>(g) |
@@ -518,11 +541,11 @@ static rnntStatus_t run_gpu_joint(const float* f, const float* g, float* df, flo
 #define RNNT_JDF(NN, PP, OO)                                                                                     \
     hipLaunchKernelGGL((joint_df_kernel<NN, PP, OO>), dim3((A + 128 * NN - 1) / (128 * NN), tilesT, N), dim3(256), 0, \
                        p.stream, f, g, p.rowmax, p.wmat, grad_scale, labels, input_lengths, label_lengths, df, maxT,  \
-                       maxU, Upad, A, N, p.blank)
+                       maxU, Upad, A, N, p.blank, sfb)
 #define RNNT_JDG(NN, PP)                                                                                         \
     hipLaunchKernelGGL((joint_dg_kernel<NN, PP>), dim3((A + 128 * NN - 1) / (128 * NN), tilesU, N), dim3(256), 0, \
                        p.stream, f, g, p.rowmax, p.wmat, grad_scale, input_lengths, label_lengths, dg, maxT,     \
-                       maxU, Upad, A, N)
+                       maxU, Upad, A, N, labels, p.blank, sgb, sgl)
         if (onehot)       { if (NKf == 4) RNNT_JDF(4, true, true); else if (NKf == 2) RNNT_JDF(2, true, true); else RNNT_JDF(1, true, true); }
         else if (tn.jfpf) { if (NKf == 4) RNNT_JDF(4, true, false); else if (NKf == 2) RNNT_JDF(2, true, false); else RNNT_JDF(1, true, false); }
         else              { if (NKf == 4) RNNT_JDF(4, false, false); else if (NKf == 2) RNNT_JDF(2, false, false); else RNNT_JDF(1, false, false); }
@@ -531,10 +554,8 @@ static rnntStatus_t run_gpu_joint(const float* f, const float* g, float* df, flo
 #undef RNNT_JDF
 #undef RNNT_JDG
         p.check();
-        hipLaunchKernelGGL(joint_fix_kernel, dim3((maxU + 63) / 64, (maxT + kJointFixT - 1) / kJointFixT, N),
-                           dim3(256), 0, p.stream, f, g, p.rowmax, p.rowtab, labels, grad_scale, input_lengths,
-                           label_lengths, df, dg, maxT, maxU, A, p.blank, N, onehot ? 1 : 0,
-                           onehot && joint_planes_onehot(maxU) == 4 ? p.wmat : nullptr, Upad);
+        hipLaunchKernelGGL(joint_far_kernel, fixgrid, dim3(256), 0, p.stream, f, g, p.rowmax, p.rowtab, grad_scale,
+                           input_lengths, label_lengths, farflag, df, dg, maxT, maxU, A, N, cplanes, Upad);
         p.check();
     }
     mark(4);

@@ -21,12 +21,14 @@
 //    the RELATIVE value log Z[t,u], which makes the coefficient record's c equal to log W[t,u],
 //    and coef_kernel also writes the dense matrix W)
 //   joint_df_kernel / joint_dg_kernel   the two gradient GEMMs with the exp(f) / exp(g) epilogue
-//   joint_fix_kernel     blank / label corrections (two columns per cell) and the far cells
+//   joint_sums_kernel    row / column sums of the blank and label corrections (small fp32 side vectors), subtracted
+//                        in the epilogues of the two GEMMs: no atomics on the outputs
+//   joint_far_kernel     the far cells (rare), after the GEMMs
 //
 // Range: ef, eg are in (0,1], so Z[t,u] >= exp(-(separation of the two rows' peaks)).  A cell
 // whose GEMM sum falls below kJointFlagZ (the rows peak at different symbols, > 41 nats apart) is
 // recomputed in place with a direct log-sum-exp over k, and a cell whose log W exceeds kJointFarC
-// is left out of the gradient GEMMs and added by joint_fix_kernel from exp(f + g + c) directly,
+// is left out of the gradient GEMMs and added by joint_far_kernel from exp(f + g + c) directly,
 // so any finite logit range is handled exactly; ordinary inputs never take either branch.
 // fp32 only in this round.
 #pragma once
@@ -38,7 +40,7 @@ namespace rnnt {
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 
 constexpr float kJointFlagZ = 0x1p-60f;   // GEMM sums below this are recomputed directly
-// kJointFarC (rnnt_kernels.h): log W above this -> the cell is handled by joint_fix_kernel
+// kJointFarC (rnnt_kernels.h): log W above this -> the cell is handled by joint_far_kernel
 constexpr float kJointMinMax = -3.0e38f;  // row maxima are clamped to a finite value
 
 // C/D fragment of the 32x32 MFMA: register r of lane l holds row (r&3) + 8*(r>>2) + 4*(l>>5),
@@ -61,8 +63,15 @@ __device__ __forceinline__ float joint_exp(float x, float m2) {
 template <bool VEC, int WPR>
 __global__ __launch_bounds__(256) void joint_rowmax_kernel(
         const float* __restrict__ f, const float* __restrict__ g, const int* __restrict__ xlen,
-        const int* __restrict__ ylen, float* __restrict__ rowmax, int maxT, int maxU, int A, int N) {
+        const int* __restrict__ ylen, float* __restrict__ rowmax, int maxT, int maxU, int A, int N,
+        float* __restrict__ side, unsigned nside) {
     __shared__ float red[4];
+    // the correction sums of joint_sums_kernel (N*(maxT + 2 maxU) floats + N flags) start at zero: the grid has at
+    // least 64 threads per row of f and g, more than that many words
+    {
+        const unsigned long long gid = static_cast<unsigned long long>(blockIdx.x) * 256 + threadIdx.x;
+        if (side != nullptr && gid < nside) side[gid] = 0.0f;
+    }
     // one extra entry after the maxima holds +inf: operand loads of the gradient GEMMs point masked
     // rows at it, which makes their exp() exactly 0 without a select on loaded data
     if (blockIdx.x == 0 && threadIdx.x == 0) rowmax[static_cast<size_t>(N) * (maxT + maxU)] = -neg_inf<float>();
@@ -548,7 +557,7 @@ __global__ __launch_bounds__(256) void joint_z_small_kernel(
 // requested before the loop starts.  Epilogue: multiply by ef, store; rows of the padding are
 // written as zeros.  The four wavefronts of a block take adjacent column groups of the same time
 // rows.  grid = (ceil(A / (128 NK)), ceil(maxT/32), N), block = 256.
-template <int NK> struct JointOperands { float w[4], m[4], x[4][NK], cb[4], cl[4]; int lab[4]; };
+template <int NK> struct JointOperands { float w[4], m[4], x[4][NK], cb[4], cl[4]; int lab[4]; };   // (DG uses w, m, x only)
 
 template <int NK>
 __device__ __forceinline__ void joint_mma(const JointOperands<NK>& s, f32x16 (&acc)[NK]) {
@@ -562,7 +571,7 @@ __device__ __forceinline__ void joint_mma(const JointOperands<NK>& s, f32x16 (&a
 // OH (small vocabularies): the blank / label corrections of df are accumulated here as well,
 //     acc2 += CB[t][u] * [k == blank] + CL[t][u] * [k == y_u]       (two more MFMAs per step, one-hot B operands),
 // from the dense CB / CL planes the coefficient kernel writes next to W.  It replaces one global atomic per
-// lattice cell in joint_fix_kernel, which all land on the few cache lines of a short df row (c4 shape,
+// lattice cell (the first version's fix-up kernel), which all land on the few cache lines of a short df row (c4 shape,
 // A = 50: 340 us of atomics against ~100 us of extra matrix work); above a few hundred symbols the atomics
 // are cheaper than the 3x contraction and the host keeps them.
 template <int NK, bool PF, bool OH>   // PF: operand ping-pong + epilogue values requested before the loop (more registers)
@@ -570,7 +579,7 @@ __global__ __launch_bounds__(256) void joint_df_kernel(
         const float* __restrict__ f, const float* __restrict__ g, const float* __restrict__ rowmax,
         const float* __restrict__ wmat, const float* __restrict__ scale, const int* __restrict__ labels,
         const int* __restrict__ xlen, const int* __restrict__ ylen, float* __restrict__ df, int maxT, int maxU,
-        int Upad, int A, int N, int blank) {
+        int Upad, int A, int N, int blank, const float* __restrict__ sfb) {
     const int b = blockIdx.z;
     const int lane = threadIdx.x & 63, wave = uniform(threadIdx.x >> 6), half = lane >> 5, col = lane & 31;
     const int k0 = (static_cast<int>(blockIdx.x) * 4 + wave) * (32 * NK);
@@ -641,7 +650,9 @@ __global__ __launch_bounds__(256) void joint_df_kernel(
             if constexpr (OH) s.lab[i] = labels[labs0 + (u < maxU - 1 ? u : (maxU > 1 ? maxU - 2 : 0))];
         }
     };
-    auto corr = [&](const JointOperands<NK>& s) {          // OH: acc2 += CB [k == blank] + CL [k == y_u]
+    // OH (small vocabularies: nearly every label lies in the wavefront's columns): the corrections of df ride along in
+    // the contraction as one-hot B operands,  acc2 += CB[t][u] * [k == blank] + CL[t][u] * [k == y_u].
+    auto corr = [&](const JointOperands<NK>& s) {
         if constexpr (OH) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -694,17 +705,85 @@ __global__ __launch_bounds__(256) void joint_df_kernel(
         load_f();
     }
 
+    // ---- epilogue: df = ef * (W Eg) - corrections, finished IN the accumulator registers, then stored.  No atomics
+    //      on the output.  OH: the corrections are in acc2.  Otherwise:
+    //        df[t, y_u]   -= cl(t,u)         once the accumulators hold ef * (W Eg), the same one-hot MFMA with -CL as
+    //                                        its A operand subtracts straight into them -- issued only for a label that
+    //                                        falls into THIS wavefront's 128 NK columns (a ballot per label: about
+    //                                        U * 128 NK / A of them hit), so the contraction loop above is untouched;
+    //        df[t, blank] -= sum_u cb(t,u)   the row sum from joint_sums_kernel (sfb), in the lane that owns the column.
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const bool live = t0 + mfma_row(r, lane) < Tb;
+#pragma unroll
+        for (int n = 0; n < NK; ++n) {
+            float o = live ? joint_exp(fv[r][n], mt[r]) * acc[n][r] : 0.0f;
+            if constexpr (OH) o = live ? o - acc2[n][r] : 0.0f;
+            acc[n][r] = o;
+        }
+    }
+    if constexpr (!OH) {
+        // (requesting these operands BEFORE the contraction loop hid their round trip but cost 32 live registers there:
+        // c3 shape 186 -> 252 us for this kernel -- it is that sensitive to occupancy; they stay here)
+        constexpr int CH = 4;                              // steps (of eight label rows) whose operands are requested together
+        for (int u0c = 0; u0c < Ub; u0c += 8 * CH) {
+            float cl[CH][4];
+            int lab[CH][4];
+#pragma unroll
+            for (int j = 0; j < CH; ++j) {
+                // (steps past the sample read the last step's operands again -- in range, Upad is a multiple of 8 -- and
+                // are skipped below; a lane whose A-operand row lies past the sample reads row T_b - 1: forced to zero)
+                const int u2 = u0c + 8 * j < Ub ? u0c + 8 * j : ((Ub - 1) & ~7);
+                const int ub = u2 + 4 * half;
+                const float4 l4 = *reinterpret_cast<const float4*>(wrow + 2 * plane + ub);   // zero outside the sample
+                cl[j][0] = tin ? l4.x : 0.0f; cl[j][1] = tin ? l4.y : 0.0f; cl[j][2] = tin ? l4.z : 0.0f; cl[j][3] = tin ? l4.w : 0.0f;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int u = ub + i;
+                    const int l = labels[labs0 + (u < maxU - 1 ? u : (maxU > 1 ? maxU - 2 : 0))];
+                    lab[j][i] = l < 0 ? 0 : (l >= A ? A - 1 : l);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < CH; ++j) {
+                if (u0c + 8 * j >= Ub) break;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    // the lane's label is the one-hot position of ITS half's contraction slot; a step is issued when either
+                    // half's label lies in the wavefront's columns (cl of a row without a label transition is zero)
+                    if (__ballot(static_cast<unsigned>(lab[j][i] - k0) < static_cast<unsigned>(32 * NK)) != 0) {
+#pragma unroll
+                        for (int n = 0; n < NK; ++n)
+                            acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(-cl[j][i], kc + n == lab[j][i] ? 1.0f : 0.0f, acc[n], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        const unsigned dblank = static_cast<unsigned>(blank - kc);        // < NK: the blank column is one of this lane's
+        if (dblank < static_cast<unsigned>(NK)) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int t = t0 + mfma_row(r, lane);
+                if (t < Tb) {
+                    const float vb = sfb[static_cast<size_t>(b) * maxT + t];
+#pragma unroll
+                    for (int n = 0; n < NK; ++n) acc[n][r] -= (dblank == static_cast<unsigned>(n)) ? vb : 0.0f;
+                }
+            }
+        }
+    }
     if (!kin) return;
+#pragma unroll
+    for (int n = 0; n < NK; ++n)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[n][r] *= sc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int t = t0 + mfma_row(r, lane);
         if (t >= maxT) continue;
         float o[NK];
 #pragma unroll
-        for (int n = 0; n < NK; ++n) {
-            o[n] = t < Tb ? joint_exp(fv[r][n], mt[r]) * (acc[n][r] * sc) : 0.0f;
-            if constexpr (OH) o[n] = t < Tb ? o[n] - acc2[n][r] * sc : 0.0f;
-        }
+        for (int n = 0; n < NK; ++n) o[n] = acc[n][r];
         joint_storev<NK>(dfb + static_cast<size_t>(t) * A, o);
     }
 }
@@ -718,7 +797,8 @@ template <int NK, bool PF>
 __global__ __launch_bounds__(256) void joint_dg_kernel(
         const float* __restrict__ f, const float* __restrict__ g, const float* __restrict__ rowmax,
         const float* __restrict__ wmat, const float* __restrict__ scale, const int* __restrict__ xlen,
-        const int* __restrict__ ylen, float* __restrict__ dg, int maxT, int maxU, int Upad, int A, int N) {
+        const int* __restrict__ ylen, float* __restrict__ dg, int maxT, int maxU, int Upad, int A, int N,
+        const int* __restrict__ labels, int blank, const float* __restrict__ sgb, const float* __restrict__ sgl) {
     const int b = blockIdx.z;
     const int lane = threadIdx.x & 63, wave = uniform(threadIdx.x >> 6), half = lane >> 5, col = lane & 31;
     const int k0 = (static_cast<int>(blockIdx.x) * 4 + wave) * (32 * NK);
@@ -790,8 +870,22 @@ __global__ __launch_bounds__(256) void joint_dg_kernel(
         if (u < Ub) {
             const float mu = mg[u];
             joint_loadv<NK>(g + at, o);
+            // corrections without atomics: dg[u, blank] -= sum_t cb(t,u), dg[u, y_u] -= sum_t cl(t,u); both column
+            // sums come from joint_sums_kernel, and row u has ONE label
+            const float cb = sgb[static_cast<size_t>(b) * maxU + u] * sc;
+            int lab = -1;
+            float cl = 0.0f;
+            if (u + 1 < Ub) {
+                lab = labels[static_cast<size_t>(b) * (maxU - 1) + u];
+                lab = lab < 0 ? 0 : (lab >= A ? A - 1 : lab);
+                cl = sgl[static_cast<size_t>(b) * maxU + u] * sc;
+            }
 #pragma unroll
-            for (int n = 0; n < NK; ++n) o[n] = joint_exp(o[n], mu) * (acc[n][r] * sc);
+            for (int n = 0; n < NK; ++n) {
+                o[n] = joint_exp(o[n], mu) * (acc[n][r] * sc);
+                o[n] -= (kc + n == blank) ? cb : 0.0f;
+                o[n] -= (kc + n == lab) ? cl : 0.0f;
+            }
         } else {
 #pragma unroll
             for (int n = 0; n < NK; ++n) o[n] = 0.0f;
@@ -801,21 +895,37 @@ __global__ __launch_bounds__(256) void joint_dg_kernel(
 }
 
 // ------------------------------------------------------------------------------------------
-// Corrections on top of the two GEMM results (runs after them on the same stream):
-//     df[t,blank] -= sum_u cb(t,u)     df[t,y_u] -= cl(t,u)
-//     dg[u,blank] -= sum_t cb(t,u)     dg[u,y_u] -= sum_t cl(t,u)
-// and the far cells' exp(f + g + c) terms.  A block owns 64 label rows (one per lane) x kJointFixT
-// time rows of one sample; wavefront w walks the time rows w, w+4, ...: the df terms go out as
-// atomics (labels repeat), the dg terms accumulate in two registers per lane and leave as one
-// atomic per (u, column) and block.  grid = (ceil(maxU/64), ceil(maxT/kJointFixT), N), block = 256.
+// Row and column sums of the correction terms, for the epilogues of the two gradient GEMMs (runs in the forward
+// phase, right after the coefficient kernel):
+//     sfb[b][t] = sum_u cb(t,u)        sgb[b][u] = sum_t cb(t,u)        sgl[b][u] = sum_t cl(t,u)
+// (fp32 side vectors in the workspace, zeroed by the host) and one flag per sample: "has far cells" (log W above
+// kJointFarC: joint_far_kernel handles them after the GEMMs).  Nothing here touches df / dg -- the first version
+// applied every correction as an atomic on the outputs, one per lattice cell for the label terms.
+// A block owns 64 label rows (one per lane) x kJointFixT time rows of one sample; wavefront w walks the time rows
+// w, w+4, ...  grid = (ceil(maxU/64), ceil(maxT/kJointFixT), N), block = 256.
 constexpr int kJointFixT = 32;
 
-__global__ __launch_bounds__(256) void joint_fix_kernel(
-        const float* __restrict__ f, const float* __restrict__ g, const float* __restrict__ rowmax,
-        const Cell<float>* __restrict__ rowtab, const int* __restrict__ labels,
-        const float* __restrict__ scale, const int* __restrict__ xlen, const int* __restrict__ ylen,
-        float* __restrict__ df, float* __restrict__ dg, int maxT, int maxU, int A, int blank, int N, int skip_df,
-        const float* __restrict__ planes, int Upad) {     // planes != nullptr: c / cb / cl come from the dense planes
+// the {c, cb, cl} of cell (t, u): from the record table, or (coefficient kernels with planes == 4) from the dense planes
+__device__ __forceinline__ Cell<float> joint_cell(const Cell<float>* __restrict__ rowtab, const float* __restrict__ planes,
+                                                  int b, int t, int u, int maxT, int maxU, int Upad, int N) {
+    Cell<float> rec;
+    if (planes != nullptr) {
+        const size_t plane = static_cast<size_t>(N) * maxT * Upad;
+        const size_t at = (static_cast<size_t>(b) * maxT + t) * Upad + u;
+        rec.x = reinterpret_cast<const float*>(rowtab)[at];
+        rec.y = planes[plane + at];
+        rec.z = planes[2 * plane + at];
+        rec.w = 0.0f;
+    } else {
+        rec = rowtab[(static_cast<size_t>(b) * maxT + t) * maxU + u];
+    }
+    return rec;
+}
+
+__global__ __launch_bounds__(256) void joint_sums_kernel(
+        const Cell<float>* __restrict__ rowtab, const int* __restrict__ xlen, const int* __restrict__ ylen,
+        float* __restrict__ sfb, float* __restrict__ sgb, float* __restrict__ sgl, int* __restrict__ farflag,
+        int maxT, int maxU, int N, const float* __restrict__ planes, int Upad) {
     __shared__ float red[2][4][64];
     const int b = blockIdx.z;
     const int lane = threadIdx.x & 63, wave = uniform(threadIdx.x >> 6);
@@ -823,47 +933,60 @@ __global__ __launch_bounds__(256) void joint_fix_kernel(
     const int Tb = clamp_len(xlen[b], maxT), Ub = clamp_len(ylen[b] + 1, maxU);
     if (tb0 >= Tb || ub0 >= Ub) return;                    // block-uniform
     const int u = ub0 + lane;
-    const bool uin = u < Ub, has_lab = u < Ub - 1;
-    int lab = 0;
-    if (has_lab) {
-        lab = labels[static_cast<size_t>(b) * (maxU - 1) + u];
-        lab = lab < 0 ? 0 : (lab >= A ? A - 1 : lab);
+    const bool uin = u < Ub;
+    const int tend = tb0 + kJointFixT < Tb ? tb0 + kJointFixT : Tb;
+    float dgb = 0.0f, dgl = 0.0f;
+    bool any_far = false;
+    for (int t = tb0 + wave; t < tend; t += 4) {
+        Cell<float> rec;
+        rec.x = log_zero<float>(); rec.y = 0.0f; rec.z = 0.0f; rec.w = 0.0f;
+        if (uin) rec = joint_cell(rowtab, planes, b, t, u, maxT, maxU, Upad, N);
+        dgb += rec.y;
+        dgl += rec.z;
+        const float rs = wave_sum(rec.y);
+        if (lane == 0) unsafeAtomicAdd(sfb + static_cast<size_t>(b) * maxT + t, rs);
+        any_far |= uin && rec.x > kJointFarC;
     }
+    if (__ballot(any_far) != 0 && lane == 0) farflag[b] = 1;
+    red[0][wave][lane] = dgb;
+    red[1][wave][lane] = dgl;
+    __syncthreads();
+    if (wave == 0 && uin) {
+        unsafeAtomicAdd(sgb + static_cast<size_t>(b) * maxU + u, red[0][0][lane] + red[0][1][lane] + red[0][2][lane] + red[0][3][lane]);
+        unsafeAtomicAdd(sgl + static_cast<size_t>(b) * maxU + u, red[1][0][lane] + red[1][1][lane] + red[1][2][lane] + red[1][3][lane]);
+    }
+}
+
+// The far cells (log W above kJointFarC: their weight was left out of the gradient GEMMs): exp(f + g + c) added to
+// the df row and the dg row of the cell directly.  Runs after the GEMMs; a sample without far cells -- every
+// ordinary input -- costs one flag read per block.  Same grid as joint_sums_kernel.
+__global__ __launch_bounds__(256) void joint_far_kernel(
+        const float* __restrict__ f, const float* __restrict__ g, const float* __restrict__ rowmax,
+        const Cell<float>* __restrict__ rowtab, const float* __restrict__ scale, const int* __restrict__ xlen,
+        const int* __restrict__ ylen, const int* __restrict__ farflag, float* __restrict__ df, float* __restrict__ dg,
+        int maxT, int maxU, int A, int N, const float* __restrict__ planes, int Upad) {
+    const int b = blockIdx.z;
+    if (farflag[b] == 0) return;
+    const int lane = threadIdx.x & 63, wave = uniform(threadIdx.x >> 6);
+    const int ub0 = blockIdx.x * 64, tb0 = blockIdx.y * kJointFixT;
+    const int Tb = clamp_len(xlen[b], maxT), Ub = clamp_len(ylen[b] + 1, maxU);
+    if (tb0 >= Tb || ub0 >= Ub) return;
+    const int u = ub0 + lane;
+    const bool uin = u < Ub;
     const float* mf = rowmax + static_cast<size_t>(b) * maxT;
     const float* mg = rowmax + static_cast<size_t>(N) * maxT + static_cast<size_t>(b) * maxU;
     const float sc = scale != nullptr ? scale[b] : 1.0f;
     const int tend = tb0 + kJointFixT < Tb ? tb0 + kJointFixT : Tb;
-    float dgb = 0.0f, dgl = 0.0f;
     for (int t = tb0 + wave; t < tend; t += 4) {
-        Cell<float> rec;
-        rec.x = log_zero<float>(); rec.y = 0.0f; rec.z = 0.0f; rec.w = 0.0f;
-        if (planes != nullptr) {                           // (coef kernels, planes == 4: no records were written)
-            if (uin) {
-                const size_t plane = static_cast<size_t>(N) * maxT * Upad;
-                const size_t at = (static_cast<size_t>(b) * maxT + t) * Upad + u;
-                rec.x = reinterpret_cast<const float*>(rowtab)[at];
-                rec.y = planes[plane + at];
-                rec.z = planes[2 * plane + at];
-            }
-        } else if (uin) {
-            rec = rowtab[(static_cast<size_t>(b) * maxT + t) * maxU + u];
-        }
-        rec.y *= sc;
-        rec.z *= sc;
-        dgb += rec.y;
-        dgl += rec.z;
+        float c = log_zero<float>();
+        if (uin) c = joint_cell(rowtab, planes, b, t, u, maxT, maxU, Upad, N).x;
         float* dfrow = df + (static_cast<size_t>(b) * maxT + t) * A;
-        const float rs = wave_sum(rec.y);
-        if (!skip_df) {                                    // (done inside joint_df_kernel<.., OH> for small vocabularies)
-            if (lane == 0) unsafeAtomicAdd(dfrow + blank, -rs);
-            if (has_lab && rec.z != 0.0f) unsafeAtomicAdd(dfrow + lab, -rec.z);
-        }
-        unsigned long long far = __ballot(uin && rec.x > kJointFarC);
-        while (far) {                                      // never taken for ordinary logits
+        unsigned long long far = __ballot(uin && c > kJointFarC);
+        while (far) {
             const int src = __ffsll(static_cast<long long>(far)) - 1;
             far &= far - 1;
             const int uu = ub0 + src;
-            const float shift = lane_get(rec.x, src) - (mf[t] + mg[uu]) * static_cast<float>(kLn2);
+            const float shift = lane_get(c, src) - (mf[t] + mg[uu]) * static_cast<float>(kLn2);
             const float* fr = f + (static_cast<size_t>(b) * maxT + t) * A;
             const float* gr = g + (static_cast<size_t>(b) * maxU + uu) * A;
             float* dgrow = dg + (static_cast<size_t>(b) * maxU + uu) * A;
@@ -873,16 +996,6 @@ __global__ __launch_bounds__(256) void joint_fix_kernel(
                 unsafeAtomicAdd(dgrow + k, p);
             }
         }
-    }
-    red[0][wave][lane] = dgb;
-    red[1][wave][lane] = dgl;
-    __syncthreads();
-    if (wave == 0 && uin) {
-        const float sb = red[0][0][lane] + red[0][1][lane] + red[0][2][lane] + red[0][3][lane];
-        const float sl = red[1][0][lane] + red[1][1][lane] + red[1][2][lane] + red[1][3][lane];
-        float* dgrow = dg + (static_cast<size_t>(b) * maxU + u) * A;
-        unsafeAtomicAdd(dgrow + blank, -sb);
-        if (has_lab) unsafeAtomicAdd(dgrow + lab, -sl);
     }
 }
 

@@ -991,7 +991,7 @@ __global__ __launch_bounds__(256) void coef_cell_kernel(
         const double* __restrict__ offb, const double* __restrict__ ll_fwd,
         const int* __restrict__ labels, const int* __restrict__ xlen, const int* __restrict__ ylen,
         Cell<L>* __restrict__ rowtab, int maxT, int maxU, int Up, float* __restrict__ wmat, int Upad, float fastemit,
-        int planes, const long long* __restrict__ offsets, int lw, int lsh) {   // offsets: packed row order (see row_stats_kernel)   // planes: 1 = W only; 3 = W, CB, CL (one-hot df corrections); 4 = W, CB, CL and a plane of c
+        int planes, const long long* __restrict__ offsets, int lw, int lsh) {   // offsets: packed row order (see row_stats_kernel)   // planes: 1 = W only; 2 = W and CL (third plane); 3 = W, CB, CL (one-hot df corrections); 4 = W, CB, CL and a plane of c
                         // that is written INTO the record table's memory (stride Upad <= 4 maxU floats) instead of
                         // the records -- with the one-hot DF nothing reads cb / cl / label per record any more,
                         // and 16 instead of 28 bytes leave per cell
@@ -1019,11 +1019,13 @@ __global__ __launch_bounds__(256) void coef_cell_kernel(
         const float c = static_cast<float>(o.x);
         const size_t at = (static_cast<size_t>(b) * maxT + t) * Upad + u;
         wmat[at] = c > kJointFarC ? 0.0f : fast_exp(c);
-        if (planes >= 3) { wmat[plane + at] = static_cast<float>(o.y); wmat[2 * plane + at] = static_cast<float>(o.z); }
+        if (planes >= 3) wmat[plane + at] = static_cast<float>(o.y);
+            if (planes >= 2) wmat[2 * plane + at] = static_cast<float>(o.z);
         if (planes == 4) reinterpret_cast<float*>(rowtab)[at] = c;   // plane of c in place of the records
         if (u == maxU - 1)                                    // the row's pad columns [maxU, Upad) are zero
             for (int k = 1; k <= Upad - maxU; ++k)
-                for (int pl = 0; pl < (planes < 3 ? planes : 3); ++pl) wmat[pl * plane + at + k] = 0.0f;
+                for (int pl = 0; pl < 3; ++pl)
+                        if (pl == 0 || planes >= 3 || (pl == 2 && planes == 2)) wmat[pl * plane + at + k] = 0.0f;
     }
 }
 
@@ -1099,11 +1101,13 @@ __global__ __launch_bounds__(256) void coef_kernel(
             const float cc = static_cast<float>(o.x);
             const size_t at = (static_cast<size_t>(b) * maxT + t) * Upad + u;
             wmat[at] = cc > kJointFarC ? 0.0f : fast_exp(cc);
-            if (planes >= 3) { wmat[plane + at] = static_cast<float>(o.y); wmat[2 * plane + at] = static_cast<float>(o.z); }
+            if (planes >= 3) wmat[plane + at] = static_cast<float>(o.y);
+            if (planes >= 2) wmat[2 * plane + at] = static_cast<float>(o.z);
             if (planes == 4) reinterpret_cast<float*>(rowtab)[at] = cc;   // plane of c in place of the records
             if (u == maxU - 1)                             // the row's pad columns [maxU, Upad) are zero
                 for (int k = 1; k <= Upad - maxU; ++k)
-                    for (int pl = 0; pl < (planes < 3 ? planes : 3); ++pl) wmat[pl * plane + at + k] = 0.0f;
+                    for (int pl = 0; pl < 3; ++pl)
+                        if (pl == 0 || planes >= 3 || (pl == 2 && planes == 2)) wmat[pl * plane + at + k] = 0.0f;
         }
     }
 }

@@ -298,7 +298,7 @@ rnntStatus_t compute_rnnt_loss_packed_bwd(const void* activations,
 /* Additive joint ("add network", the reference's add_network branch: README.md:4,
  * docs/rnnt_notes.tex:56-59,147-153, pytorch_binding/test/test_time.py:51-77).  The joint logits
  * are h(k,t,u) = trans_acts[b,t,k] + pred_acts[b,u,k]; the (B,T,U,V) tensor is never formed.
- * trans_acts (B,maxT,V) and pred_acts (B,maxU,V) are dense fp32 DEVICE tensors; trans_grads /
+ * trans_acts (B,maxT,V) and pred_acts (B,maxU,V) are dense fp32 DEVICE tensors (bf16 / fp16: the _dt entries below); trans_grads /
  * pred_grads receive dL/d(trans_acts) = sum_u dL/dh and dL/d(pred_acts) = sum_t dL/dh (both NULL:
  * score only).  Same conventions as compute_rnnt_loss_async: `costs_device` is a DEVICE array of
  * `minibatch` floats, the call only enqueues on options.stream; size the workspace with
@@ -367,6 +367,38 @@ rnntStatus_t compute_rnnt_loss_add_bwd(const float* const trans_acts,
                                        int minibatch,
                                        void* workspace,
                                        rnntOptions options);
+
+/* The two-phase additive-joint entries with the STORAGE type of the activations as an argument:
+ * dtype_code 0 = fp32 (identical to compute_rnnt_loss_add_fwd_fastemit / compute_rnnt_loss_add_bwd),
+ * 2 = bf16, 3 = fp16 (raw 16-bit storage of trans_acts, pred_acts and both gradients; every kernel
+ * computes in fp32; costs and grad_scale stay float).  Same workspace query, same conventions. */
+rnntStatus_t compute_rnnt_loss_add_fwd_dt(const void* trans_acts,
+                                          const void* pred_acts,
+                                          const int* const flat_labels,
+                                          const int* const label_lengths,
+                                          const int* const input_lengths,
+                                          int alphabet_size,
+                                          int minibatch,
+                                          float* costs_device,
+                                          void* workspace,
+                                          rnntOptions options,
+                                          int dtype_code,
+                                          int prepare_backward,
+                                          float fastemit_lambda);
+
+rnntStatus_t compute_rnnt_loss_add_bwd_dt(const void* trans_acts,
+                                          const void* pred_acts,
+                                          void* trans_grads,
+                                          void* pred_grads,
+                                          const float* grad_scale_device,
+                                          const int* const flat_labels,
+                                          const int* const label_lengths,
+                                          const int* const input_lengths,
+                                          int alphabet_size,
+                                          int minibatch,
+                                          void* workspace,
+                                          rnntOptions options,
+                                          int dtype_code);
 
 /* Stage timing for benchmarks.  rnnt_profile_enable(1) makes every following
  * GPU call record HIP events around its kernels on options.stream (no extra

@@ -270,25 +270,60 @@ def test_validation_errors():
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
-@pytest.mark.parametrize("shape", [(3, 20, 9, 40), (2, 33, 21, 257), (2, 40, 35, 2048)])
+@pytest.mark.parametrize("shape", [(3, 20, 9, 40), (2, 33, 21, 257), (2, 40, 35, 2048), (2, 9, 300, 7), (1, 34, 5, 5000),
+                                   (2, 40, 70, 57), (2, 65, 34, 56), (1, 1, 1, 9), (2, 31, 70, 1030), (3, 65, 33, 100)])
 def test_sixteen_bit_activations(oracle, dtype, shape):
-    """bfloat16 / float16 activations (staged through float32 inside `rnnt_loss_add`): the loss against the oracle on
-    the ROUNDED inputs, the gradients in the activations' dtype within that dtype's rounding of the fp32 result."""
+    """bfloat16 / float16 STORAGE of both activations and both gradients (compute_rnnt_loss_add_fwd_dt / _bwd_dt: the
+    kernels read and write the 16-bit tensors directly and compute in fp32): the loss against the oracle on the
+    ROUNDED inputs, the gradients within that dtype's rounding of the exact result.  Shapes: every Z kernel (small
+    vocabulary, 1 / 4 / 8 wavefronts per tile), one-hot and conditional label corrections, odd vocabularies
+    (scalar loads), wide lattices."""
     from warprnnt_pytorch.add_network import RNNTLossAdd
     f, g, labels, tl, ll, blank = problem(shape, sum(shape) + 3)
     dev = torch.device("cuda:0")
     tf = torch.tensor(f, device=dev).to(dtype).requires_grad_(True)
     tg = torch.tensor(g, device=dev).to(dtype).requires_grad_(True)
-    args = (torch.tensor(labels, device=dev), torch.tensor(tl, device=dev), torch.tensor(ll, device=dev))
+    lab = torch.tensor(labels, device=dev) if labels.size else torch.zeros((f.shape[0], 0), dtype=torch.int32, device=dev)
+    args = (lab, torch.tensor(tl, device=dev), torch.tensor(ll, device=dev))
     loss = RNNTLossAdd(blank=blank, reduction="none")(tf, tg, *args)
     loss.sum().backward()
     assert loss.dtype == torch.float32 and tf.grad.dtype == dtype and tg.grad.dtype == dtype
     fr, gr = tf.detach().double().cpu().numpy(), tg.detach().double().cpu().numpy()
     z = fr[:, :, None, :] + gr[:, None, :, :]
-    ref_c, ref_gz = oracle.rnnt_logits(z, labels, tl, ll, blank)
+    ref_c, ref_gz = oracle.rnnt_logits(z, labels if labels.size else np.zeros((shape[0], 1), dtype=np.int32)[:, :0], tl, ll, blank)
     assert np.abs(loss.detach().double().cpu().numpy() - ref_c).max() <= 1e-4 * max(1.0, np.abs(ref_c).max())
     rdf, rdg = ref_gz.sum(axis=2), ref_gz.sum(axis=1)
     ulp = 2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11          # half an ulp of the STORED gradient, relative
     N, T, U, A = shape
     assert (np.abs(tf.grad.double().cpu().numpy() - rdf) <= 2e-4 * max(1.0, U / 32) + ulp * np.abs(rdf) + 1e-6).all()
     assert (np.abs(tg.grad.double().cpu().numpy() - rdg) <= 2e-4 * max(1.0, T / 32) + ulp * np.abs(rdg) + 1e-6).all()
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_sixteen_bit_far_cells_and_scale(oracle, dtype):
+    """16-bit storage on the rare paths: rows peaking ~70 nats apart (direct log-sum-exp in the Z epilogue, far cells
+    added through the compare-and-swap atomic), with a per-sample grad_output."""
+    from warprnnt_pytorch.add_network import RNNTLossAdd
+    rng = np.random.default_rng(77)
+    N, T, U, A = 2, 6, 4, 50
+    f = (rng.standard_normal((N, T, A)) * 0.5).astype(np.float32)
+    g = (rng.standard_normal((N, U, A)) * 0.5).astype(np.float32)
+    f[:, :, 3] += 70.0
+    g[:, :, 11] += 70.0
+    labels = rng.integers(1, A, size=(N, U - 1)).astype(np.int32)
+    tl, ll = np.array([T, 4], np.int32), np.array([U - 1, 2], np.int32)
+    dev = torch.device("cuda:0")
+    tf = torch.tensor(f, device=dev).to(dtype).requires_grad_(True)
+    tg = torch.tensor(g, device=dev).to(dtype).requires_grad_(True)
+    loss = RNNTLossAdd(blank=0, reduction="none")(tf, tg, torch.tensor(labels, device=dev), torch.tensor(tl, device=dev),
+                                                  torch.tensor(ll, device=dev))
+    w = torch.tensor([0.5, -2.0], device=dev)
+    (loss * w).sum().backward()
+    fr, gr = tf.detach().double().cpu().numpy(), tg.detach().double().cpu().numpy()
+    ref_c, ref_gz = oracle.rnnt_logits(fr[:, :, None, :] + gr[:, None, :, :], labels, tl, ll, 0)
+    ref_gz = ref_gz * w.cpu().numpy()[:, None, None, None]
+    assert np.abs(loss.detach().double().cpu().numpy() - ref_c).max() <= 1e-4 * max(1.0, np.abs(ref_c).max())
+    ulp = 2.0 ** -7 if dtype == torch.bfloat16 else 2.0 ** -10          # a few roundings of the stored value (atomic adds)
+    rdf, rdg = ref_gz.sum(axis=2), ref_gz.sum(axis=1)
+    assert (np.abs(tf.grad.double().cpu().numpy() - rdf) <= 1e-3 + ulp * (np.abs(rdf) + 1.0)).all()
+    assert (np.abs(tg.grad.double().cpu().numpy() - rdg) <= 1e-3 + ulp * (np.abs(rdg) + 1.0)).all()

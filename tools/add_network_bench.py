@@ -5,7 +5,8 @@
                  -> df = grads.sum(2), dg = grads.sum(1)  (torch)   [what a user of the reference does]
   step         : RNNTLossAdd(reduction='mean') forward + backward through autograd (two-phase entry,
                  1/N and grad_output folded into the gradient kernels)
-Usage: python tools/add_network_bench.py [--fused-only] [c2 c3 c4 c5f32]   (--fused-only: skip the materialised comparison)"""
+Usage: python tools/add_network_bench.py [--fused-only] [--bf16|--fp16] [c2 c3 c4 c5f32]
+  --fused-only: skip the materialised comparison; --bf16 / --fp16: 16-bit storage of f, g, df, dg (fused path only)"""
 import ctypes as C
 import os
 import sys
@@ -20,12 +21,15 @@ from warprnnt_pytorch import _lib, warp_rnnt
 SHAPES = {"c2": (16, 150, 41, 28), "c3": (128, 150, 21, 5000), "c4": (64, 1500, 301, 50), "c5f32": (128, 200, 41, 1024)}
 dev = torch.device("cuda:0")
 lib = _lib.lib()
-FUSED_ONLY = "--fused-only" in sys.argv
+HALF = torch.bfloat16 if "--bf16" in sys.argv else (torch.float16 if "--fp16" in sys.argv else None)
+FUSED_ONLY = "--fused-only" in sys.argv or HALF is not None
 for name in [a for a in sys.argv[1:] if not a.startswith("--")] or ["c3"]:
     N, T, U, A = SHAPES[name]
     g0 = torch.Generator(device=dev); g0.manual_seed(1)
     f = torch.rand((N, T, A), generator=g0, device=dev)
     g = torch.rand((N, U, A), generator=g0, device=dev)
+    if HALF is not None:
+        f, g = f.to(HALF), g.to(HALF)
     labels = torch.randint(1, A, (N, U - 1), generator=g0, device=dev, dtype=torch.int32)
     tl = torch.full((N,), T, dtype=torch.int32, device=dev)
     ll = torch.full((N,), U - 1, dtype=torch.int32, device=dev)
@@ -35,9 +39,19 @@ for name in [a for a in sys.argv[1:] if not a.startswith("--")] or ["c3"]:
     opt = _lib.rnntOptions(loc=1, num_threads=0, stream=torch.cuda.current_stream().cuda_stream, blank_label=0,
                            maxT=T, maxU=U, batch_first=True)
 
+    code = {None: _lib.DT_F32, torch.bfloat16: _lib.DT_BF16, torch.float16: _lib.DT_F16}[HALF]
+
     def fused():
-        st = lib.compute_rnnt_loss_add(f.data_ptr(), g.data_ptr(), df.data_ptr(), dg.data_ptr(), labels.data_ptr(),
-                                       ll.data_ptr(), tl.data_ptr(), A, N, costs.data_ptr(), ws.data_ptr(), opt)
+        if HALF is None:
+            st = lib.compute_rnnt_loss_add(f.data_ptr(), g.data_ptr(), df.data_ptr(), dg.data_ptr(), labels.data_ptr(),
+                                           ll.data_ptr(), tl.data_ptr(), A, N, costs.data_ptr(), ws.data_ptr(), opt)
+            assert st == 0
+            return
+        st = lib.compute_rnnt_loss_add_fwd_dt(f.data_ptr(), g.data_ptr(), labels.data_ptr(), ll.data_ptr(), tl.data_ptr(), A, N,
+                                              costs.data_ptr(), ws.data_ptr(), opt, code, 1, 0.0)
+        assert st == 0
+        st = lib.compute_rnnt_loss_add_bwd_dt(f.data_ptr(), g.data_ptr(), df.data_ptr(), dg.data_ptr(), None, labels.data_ptr(),
+                                              ll.data_ptr(), tl.data_ptr(), A, N, ws.data_ptr(), opt, code)
         assert st == 0
 
     grads = None if FUSED_ONLY else torch.empty((N, T, U, A), device=dev)
@@ -81,8 +95,8 @@ for name in [a for a in sys.argv[1:] if not a.startswith("--")] or ["c3"]:
     step_ms = (time.perf_counter() - t0) * 1e2
     c_f = costs.clone(); fused(); torch.cuda.synchronize()
     if FUSED_ONLY:
-        print("%s N=%d T=%d U=%d A=%d: fused %.3f ms (stages stats/lattice/coef/grad/span %s) | autograd step (mean) %.3f ms"
-              % (name, N, T, U, A, out["fused"][0], out["fused"][1], step_ms))
+        print("%s%s N=%d T=%d U=%d A=%d: fused %.3f ms (stages stats/lattice/coef/grad/span %s) | autograd step (mean) %.3f ms"
+              % (name, "" if HALF is None else " " + str(HALF).replace("torch.", ""), N, T, U, A, out["fused"][0], out["fused"][1], step_ms))
         continue
     print("%s N=%d T=%d U=%d A=%d: fused %.3f ms (stages stats/lattice/coef/grad/span %s) | materialised %.3f ms "
           "(library stages %s) | speed-up x%.1f | autograd step (mean) %.3f ms"

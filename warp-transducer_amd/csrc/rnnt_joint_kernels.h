@@ -30,7 +30,7 @@
 // recomputed in place with a direct log-sum-exp over k, and a cell whose log W exceeds kJointFarC
 // is left out of the gradient GEMMs and added by joint_far_kernel from exp(f + g + c) directly,
 // so any finite logit range is handled exactly; ordinary inputs never take either branch.
-// fp32 only in this round.
+// Storage of f, g, df, dg: fp32, bf16 or fp16 (template tag); every kernel computes in fp32 (fp32 MFMA).
 #pragma once
 
 #include "rnnt_kernels.h"
@@ -60,9 +60,9 @@ __device__ __forceinline__ float joint_exp(float x, float m2) {
 // WPR wavefronts share a row (1: wavefront per row; 4: the whole block, for rows >= 12 KB, so that the
 // rows in flight form one contiguous window -- see row_stats_block_kernel); rows of the padding
 // (t >= T_b, u > U_b) are skipped.  grid = ceil(rows * WPR / 4), block = 256.
-template <bool VEC, int WPR>
+template <typename Tag, bool VEC, int WPR>
 __global__ __launch_bounds__(256) void joint_rowmax_kernel(
-        const float* __restrict__ f, const float* __restrict__ g, const int* __restrict__ xlen,
+        const typename Tag::store* __restrict__ f, const typename Tag::store* __restrict__ g, const int* __restrict__ xlen,
         const int* __restrict__ ylen, float* __restrict__ rowmax, int maxT, int maxU, int A, int N,
         float* __restrict__ side, unsigned nside) {
     __shared__ float red[4];
@@ -82,7 +82,7 @@ __global__ __launch_bounds__(256) void joint_rowmax_kernel(
     const long long rows_f = static_cast<long long>(N) * maxT;
     if (row >= rows_f + static_cast<long long>(N) * maxU) return;
     const int tid = WPR == 4 ? static_cast<int>(threadIdx.x) : static_cast<int>(threadIdx.x & 63);
-    const float* p;
+    const typename Tag::store* p;
     if (row < rows_f) {
         const int b = static_cast<int>(row / maxT);
         if (static_cast<int>(row - static_cast<long long>(b) * maxT) >= xlen[b]) return;   // uniform per row
@@ -94,15 +94,17 @@ __global__ __launch_bounds__(256) void joint_rowmax_kernel(
         p = g + r * A;
     }
     float m = neg_inf<float>();
-    if constexpr (VEC) {
+    if constexpr (VEC) {                                   // rows are whole 16-byte packets
+        constexpr int VN = Vec<Tag>::N;
         const u32x4* p4 = reinterpret_cast<const u32x4*>(p);
-        for (int i = tid; i < (A >> 2); i += TPR) {
-            float v[4];
-            unpack<F32>(load_packet<true>(p4 + i), v);
-            m = fmaxf(fmaxf(m, fmaxf(v[0], v[1])), fmaxf(v[2], v[3]));
+        for (int i = tid; i < A / VN; i += TPR) {
+            float v[VN];
+            unpack<Tag>(load_packet<true>(p4 + i), v);
+#pragma unroll
+            for (int j = 0; j < VN; ++j) m = fmaxf(m, v[j]);
         }
     } else {
-        for (int i = tid; i < A; i += TPR) m = fmaxf(m, p[i]);
+        for (int i = tid; i < A; i += TPR) m = fmaxf(m, load1<Tag>(p + i));
     }
     m = wave_max(m);
     if constexpr (WPR == 4) {
@@ -113,38 +115,68 @@ __global__ __launch_bounds__(256) void joint_rowmax_kernel(
     if (tid == 0) rowmax[row] = fmaxf(m, kJointMinMax) * static_cast<float>(kLog2e);
 }
 
-// Up to four consecutive floats as one 4/8/16-byte access (the address is NK*4-byte aligned).
-template <int NK> __device__ __forceinline__ void joint_loadv(const float* __restrict__ p, float (&v)[NK]) {
-    if constexpr (NK == 4) {
-        const float4 t = *reinterpret_cast<const float4*>(p);
-        v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
-    } else if constexpr (NK == 2) {
-        const float2 t = *reinterpret_cast<const float2*>(p);
-        v[0] = t.x; v[1] = t.y;
+// Up to four consecutive elements as ONE access (the address is NK-element aligned): 4/8/16 bytes for fp32
+// storage, 2/4/8 bytes for 16-bit storage; values in fp32.
+template <typename Tag, int NK>
+__device__ __forceinline__ void joint_loadv(const typename Tag::store* __restrict__ p, float (&v)[NK]) {
+    if constexpr (sizeof(typename Tag::store) == 4) {
+        if constexpr (NK == 4) {
+            const float4 t = *reinterpret_cast<const float4*>(p);
+            v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+        } else if constexpr (NK == 2) {
+            const float2 t = *reinterpret_cast<const float2*>(p);
+            v[0] = t.x; v[1] = t.y;
+        } else {
+            v[0] = p[0];
+        }
     } else {
-        v[0] = p[0];
+        if constexpr (NK == 4) {
+            unpack_half<Tag>(*reinterpret_cast<const uint2*>(p), v);
+        } else if constexpr (NK == 2) {
+            float w[4];
+            unpack_half<Tag>(make_uint2(*reinterpret_cast<const uint32_t*>(p), 0u), w);
+            v[0] = w[0]; v[1] = w[1];
+        } else {
+            v[0] = load1<Tag>(p);
+        }
     }
 }
-template <int NK> __device__ __forceinline__ void joint_storev(float* __restrict__ p, const float (&v)[NK]) {
-    if constexpr (NK == 4) *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
-    else if constexpr (NK == 2) *reinterpret_cast<float2*>(p) = make_float2(v[0], v[1]);
-    else p[0] = v[0];
+template <typename Tag, int NK>
+__device__ __forceinline__ void joint_storev(typename Tag::store* __restrict__ p, const float (&v)[NK]) {
+    if constexpr (sizeof(typename Tag::store) == 4) {
+        if constexpr (NK == 4) *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+        else if constexpr (NK == 2) *reinterpret_cast<float2*>(p) = make_float2(v[0], v[1]);
+        else p[0] = v[0];
+    } else {
+        if constexpr (NK == 1) {
+            store1<Tag>(p, v[0]);
+        } else {
+            float w[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+            for (int i = 0; i < NK; ++i) w[i] = v[i];
+            const uint4 q = pack<Tag>(w);                  // two values per 32-bit word
+            if constexpr (NK == 4) *reinterpret_cast<uint2*>(p) = make_uint2(q.x, q.y);
+            else *reinterpret_cast<uint32_t*>(p) = q.x;
+        }
+    }
 }
 
 // Four consecutive columns k..k+3 of a row, loaded UNCONDITIONALLY: a column past the end is read from a
-// valid one instead (VEC: the whole 16-byte packet from the last packet, A % 4 == 0 and rows 16-byte
-// aligned; scalar form: each element from column A-1) and the CALLER cancels it (row maximum +inf ->
+// valid one instead (VEC: the whole 4-element packet from the last packet, A % 4 == 0 and rows aligned to
+// it; scalar form: each element from column A-1) and the CALLER cancels it (row maximum +inf ->
 // exp(x - inf) = 0).  With guards instead, every scalar load sat in its own exec-masked branch.
-template <bool VEC>
-__device__ __forceinline__ float4 joint_load4(const float* __restrict__ row, int k, int A) {
+template <typename Tag, bool VEC>
+__device__ __forceinline__ float4 joint_load4(const typename Tag::store* __restrict__ row, int k, int A) {
     if constexpr (VEC) {
-        return *reinterpret_cast<const float4*>(row + (k < A ? k : A - 4));
+        float v[4];
+        joint_loadv<Tag, 4>(row + (k < A ? k : A - 4), v);
+        return make_float4(v[0], v[1], v[2], v[3]);
     } else {
         float4 v;
-        v.x = row[k < A ? k : A - 1];
-        v.y = row[k + 1 < A ? k + 1 : A - 1];
-        v.z = row[k + 2 < A ? k + 2 : A - 1];
-        v.w = row[k + 3 < A ? k + 3 : A - 1];
+        v.x = load1<Tag>(row + (k < A ? k : A - 1));
+        v.y = load1<Tag>(row + (k + 1 < A ? k + 1 : A - 1));
+        v.z = load1<Tag>(row + (k + 2 < A ? k + 2 : A - 1));
+        v.w = load1<Tag>(row + (k + 3 < A ? k + 3 : A - 1));
         return v;
     }
 }
@@ -165,9 +197,9 @@ __device__ __forceinline__ float4 joint_load4(const float* __restrict__ row, int
 constexpr int kJointZPad = 36;                              // LDS row stride in floats (conflict-free b128)
 constexpr int kJointZSlice = 2 * 32 * kJointZPad;           // floats per wavefront: ef piece + eg piece
 
-template <int S, bool VEC>
+template <typename Tag, int S, bool VEC>
 __global__ __launch_bounds__(S == 1 ? 256 : S * 64) void joint_z_kernel(
-        const float* __restrict__ f, const float* __restrict__ g, const float* __restrict__ rowmax,
+        const typename Tag::store* __restrict__ f, const typename Tag::store* __restrict__ g, const float* __restrict__ rowmax,
         const int* __restrict__ labels, const int* __restrict__ xlen, const int* __restrict__ ylen,
         LogPair<float>* __restrict__ lp2, float* __restrict__ logz, int maxT, int maxU, int Up, int A,
         int blank, int tilesU, int tiles, int N) {
@@ -191,8 +223,9 @@ __global__ __launch_bounds__(S == 1 ? 256 : S * 64) void joint_z_kernel(
 
     // loader role: lane l moves columns 4*(l&7).. of rows (l>>3) + 8i, i = 0..3
     const int lrow = lane >> 3, lcol = (lane & 7) * 4;
-    const float* frow[4];
-    const float* grow4[4];
+    using ST = typename Tag::store;
+    const ST* frow[4];
+    const ST* grow4[4];
     float mfr[4], mgr[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -214,8 +247,8 @@ __global__ __launch_bounds__(S == 1 ? 256 : S * 64) void joint_z_kernel(
     auto load = [&](float4 (&fv)[4], float4 (&gv)[4], int cc) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            fv[i] = joint_load4<VEC>(frow[i], cc * 32 + lcol, A);
-            gv[i] = joint_load4<VEC>(grow4[i], cc * 32 + lcol, A);
+            fv[i] = joint_load4<Tag, VEC>(frow[i], cc * 32 + lcol, A);
+            gv[i] = joint_load4<Tag, VEC>(grow4[i], cc * 32 + lcol, A);
         }
     };
     auto compute = [&](const float4 (&fv)[4], const float4 (&gv)[4], int cc) {
@@ -279,10 +312,10 @@ __global__ __launch_bounds__(S == 1 ? 256 : S * 64) void joint_z_kernel(
         lab = labels[static_cast<size_t>(b) * (maxU - 1) + u];
         lab = lab < 0 ? 0 : (lab >= A ? A - 1 : lab);
     }
-    const float* gu = g + (static_cast<size_t>(b) * maxU + ui) * A;
+    const ST* gu = g + (static_cast<size_t>(b) * maxU + ui) * A;
     const float mgu = mg[ui];
     const float l2e = static_cast<float>(kLog2e), ln2 = static_cast<float>(kLn2);
-    const float gbl = __builtin_fmaf(gu[blank], l2e, -mgu), glab = __builtin_fmaf(gu[lab], l2e, -mgu);   // base 2
+    const float gbl = __builtin_fmaf(load1<Tag>(gu + blank), l2e, -mgu), glab = __builtin_fmaf(load1<Tag>(gu + lab), l2e, -mgu);   // base 2
 
     // The per-cell gathers f[t,blank], f[t,label] and mf[t] of the registers this wavefront finishes are
     // requested together, BEFORE the cell loop: inside it they were sixteen dependent memory round trips
@@ -295,9 +328,9 @@ __global__ __launch_bounds__(S == 1 ? 256 : S * 64) void joint_z_kernel(
     for (int i = 0; i < PER; ++i) {
         const int t = t0 + mfma_row(rbase + i, lane);
         const int tc = t < Tb ? t : Tb - 1;
-        const float* ft = f + (static_cast<size_t>(b) * maxT + tc) * A;
-        fbl[i] = ft[blank];
-        flb[i] = ft[lab];
+        const ST* ft = f + (static_cast<size_t>(b) * maxT + tc) * A;
+        fbl[i] = load1<Tag>(ft + blank);
+        flb[i] = load1<Tag>(ft + lab);
         mtv[i] = mf[tc];
     }
 
@@ -313,13 +346,13 @@ __global__ __launch_bounds__(S == 1 ? 256 : S * 64) void joint_z_kernel(
             const int src = __ffsll(static_cast<long long>(bad)) - 1;
             bad &= bad - 1;
             const int tt = t0 + mfma_row(r, src), uu = u0 + (src & 31);
-            const float* fr = f + (static_cast<size_t>(b) * maxT + tt) * A;
-            const float* gr = g + (static_cast<size_t>(b) * maxU + uu) * A;
+            const typename Tag::store* fr = f + (static_cast<size_t>(b) * maxT + tt) * A;
+            const typename Tag::store* gr = g + (static_cast<size_t>(b) * maxU + uu) * A;
             float m = neg_inf<float>();
-            for (int k = lane; k < A; k += 64) m = fmaxf(m, fr[k] + gr[k]);
+            for (int k = lane; k < A; k += 64) m = fmaxf(m, load1<Tag>(fr + k) + load1<Tag>(gr + k));
             m = fmaxf(wave_max(m), kJointMinMax);
             float s = 0.0f;
-            for (int k = lane; k < A; k += 64) s += fast_exp(fr[k] + gr[k] - m);
+            for (int k = lane; k < A; k += 64) s += fast_exp(load1<Tag>(fr + k) + load1<Tag>(gr + k) - m);
             s = wave_sum(s);
             const float v = (m - (mf[tt] + mg[uu]) * ln2) + acc_log(s);
             if (lane == src) lz = v;
@@ -377,8 +410,9 @@ constexpr int kJointZSmallOp = 32 * (kJointZSmallA + 1);   // floats per operand
 constexpr int kJointZSmallSlice = 2 * kJointZSmallOp + 64; // per wavefront (>= 3 * 32 * kJointZOutPad); 4 slices < 64 KB
 static_assert(kJointZSmallSlice >= 3 * 32 * kJointZOutPad && 4 * kJointZSmallSlice * 4 <= 65536, "LDS budget");
 
+template <typename Tag>
 __global__ __launch_bounds__(256) void joint_z_small_kernel(
-        const float* __restrict__ f, const float* __restrict__ g, const float* __restrict__ rowmax,
+        const typename Tag::store* __restrict__ f, const typename Tag::store* __restrict__ g, const float* __restrict__ rowmax,
         const int* __restrict__ labels, const int* __restrict__ xlen, const int* __restrict__ ylen,
         LogPair<float>* __restrict__ lp2, float* __restrict__ logz, int maxT, int maxU, int Up, int A,
         int blank, int tilesU, int tiles, int N) {
@@ -406,15 +440,24 @@ __global__ __launch_bounds__(256) void joint_z_small_kernel(
 
     // ---- every global load of the tile is requested here, before anything waits
     const int nf = (Tb - t0 < 32 ? Tb - t0 : 32) * A, ng = (Ub - u0 < 32 ? Ub - u0 : 32) * A;   // valid flat elements
+    using ST = typename Tag::store;
+    constexpr int ES = static_cast<int>(sizeof(ST));
     const __amdgpu_buffer_rsrc_t rf = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(f) + (static_cast<size_t>(b) * maxT + t0) * A, 0, nf * 4, 0x00020000);
+        const_cast<ST*>(f) + (static_cast<size_t>(b) * maxT + t0) * A, 0, nf * ES, 0x00020000);
     const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(g) + (static_cast<size_t>(b) * maxU + u0) * A, 0, ng * 4, 0x00020000);
+        const_cast<ST*>(g) + (static_cast<size_t>(b) * maxU + u0) * A, 0, ng * ES, 0x00020000);
     float fv[IT], gv[IT];
 #pragma unroll
     for (int i = 0; i < IT; ++i) {                         // past the valid rows: 0
-        fv[i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rf, lane * 4, i * 256, 0));
-        gv[i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rg, lane * 4, i * 256, 0));
+        if constexpr (ES == 4) {
+            fv[i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rf, lane * 4, i * 256, 0));
+            gv[i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rg, lane * 4, i * 256, 0));
+        } else {                                           // one 16-bit element per lane, 128 contiguous bytes per load
+            const uint16_t hf = static_cast<uint16_t>(__builtin_amdgcn_raw_buffer_load_b16(rf, lane * 2, i * 128, 0));
+            const uint16_t hg = static_cast<uint16_t>(__builtin_amdgcn_raw_buffer_load_b16(rg, lane * 2, i * 128, 0));
+            fv[i] = load1<Tag>(&hf);
+            gv[i] = load1<Tag>(&hg);
+        }
     }
     const float ma = *(t0 + col < Tb ? mf + t0 + col : sentinel);   // this lane's row of f as MFMA operand
     const float mb = *(u0 + col < Ub ? mg + u0 + col : sentinel);   // ... of g; also the label row of its cells
@@ -510,13 +553,13 @@ __global__ __launch_bounds__(256) void joint_z_small_kernel(
             const int src = __ffsll(static_cast<long long>(bad)) - 1;
             bad &= bad - 1;
             const int tt = t0 + mfma_row(i, src), uu = u0 + (src & 31);
-            const float* fr = f + (static_cast<size_t>(b) * maxT + tt) * A;
-            const float* gr = g + (static_cast<size_t>(b) * maxU + uu) * A;
+            const typename Tag::store* fr = f + (static_cast<size_t>(b) * maxT + tt) * A;
+            const typename Tag::store* gr = g + (static_cast<size_t>(b) * maxU + uu) * A;
             float m = neg_inf<float>();
-            for (int k = lane; k < A; k += 64) m = fmaxf(m, fr[k] + gr[k]);
+            for (int k = lane; k < A; k += 64) m = fmaxf(m, load1<Tag>(fr + k) + load1<Tag>(gr + k));
             m = fmaxf(wave_max(m), kJointMinMax);
             float sum = 0.0f;
-            for (int k = lane; k < A; k += 64) sum += fast_exp(fr[k] + gr[k] - m);
+            for (int k = lane; k < A; k += 64) sum += fast_exp(load1<Tag>(fr + k) + load1<Tag>(gr + k) - m);
             sum = wave_sum(sum);
             const float v = (m - (mf[tt] + mg[uu]) * ln2) + acc_log(sum);
             if (lane == src) lz = v;
@@ -574,11 +617,11 @@ __device__ __forceinline__ void joint_mma(const JointOperands<NK>& s, f32x16 (&a
 // lattice cell (the first version's fix-up kernel), which all land on the few cache lines of a short df row (c4 shape,
 // A = 50: 340 us of atomics against ~100 us of extra matrix work); above a few hundred symbols the atomics
 // are cheaper than the 3x contraction and the host keeps them.
-template <int NK, bool PF, bool OH>   // PF: operand ping-pong + epilogue values requested before the loop (more registers)
+template <typename Tag, int NK, bool PF, bool OH>   // PF: operand ping-pong + epilogue values requested before the loop (more registers)
 __global__ __launch_bounds__(256) void joint_df_kernel(
-        const float* __restrict__ f, const float* __restrict__ g, const float* __restrict__ rowmax,
+        const typename Tag::store* __restrict__ f, const typename Tag::store* __restrict__ g, const float* __restrict__ rowmax,
         const float* __restrict__ wmat, const float* __restrict__ scale, const int* __restrict__ labels,
-        const int* __restrict__ xlen, const int* __restrict__ ylen, float* __restrict__ df, int maxT, int maxU,
+        const int* __restrict__ xlen, const int* __restrict__ ylen, typename Tag::store* __restrict__ df, int maxT, int maxU,
         int Upad, int A, int N, int blank, const float* __restrict__ sfb) {
     const int b = blockIdx.z;
     const int lane = threadIdx.x & 63, wave = uniform(threadIdx.x >> 6), half = lane >> 5, col = lane & 31;
@@ -589,8 +632,9 @@ __global__ __launch_bounds__(256) void joint_df_kernel(
     const int t0 = blockIdx.y * 32;
     const int Tb = clamp_len(xlen[b], maxT), Ub = clamp_len(ylen[b] + 1, maxU);
     const float* mf = rowmax + static_cast<size_t>(b) * maxT;
-    const float* fb = f + static_cast<size_t>(b) * maxT * A + (kin ? kc : A - NK);   // lanes past the vocabulary read a valid column
-    float* dfb = df + static_cast<size_t>(b) * maxT * A + kc;
+    using ST = typename Tag::store;
+    const ST* fb = f + static_cast<size_t>(b) * maxT * A + (kin ? kc : A - NK);   // lanes past the vocabulary read a valid column
+    ST* dfb = df + static_cast<size_t>(b) * maxT * A + kc;
     f32x16 acc[NK];
 #pragma unroll
     for (int n = 0; n < NK; ++n)
@@ -610,7 +654,7 @@ __global__ __launch_bounds__(256) void joint_df_kernel(
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int t = t0 + mfma_row(r, lane);
-            if (t < maxT) joint_storev<NK>(dfb + static_cast<size_t>(t) * A, z);
+            if (t < maxT) joint_storev<Tag, NK>(dfb + static_cast<size_t>(t) * A, z);
         }
         return;
     }
@@ -625,7 +669,7 @@ __global__ __launch_bounds__(256) void joint_df_kernel(
     // zero in the padding, zero in the pad columns, <= e^40 elsewhere); time rows past the sample and
     // lanes past the vocabulary compute on a valid neighbour and store nothing.
     const float* wrow = wmat + (static_cast<size_t>(b) * maxT + (tin ? t0 + col : Tb - 1)) * Upad;
-    const float* gb = g + static_cast<size_t>(b) * maxU * A + (kin ? kc : A - NK);
+    const ST* gb = g + static_cast<size_t>(b) * maxU * A + (kin ? kc : A - NK);
     const unsigned Au = static_cast<unsigned>(A);          // maxU * A < 2^31 (host check): 32-bit offsets
     const unsigned mg0 = static_cast<unsigned>(N) * maxT + static_cast<unsigned>(b) * maxU;
     const unsigned sentinel = static_cast<unsigned>(N) * (maxT + maxU);
@@ -646,7 +690,7 @@ __global__ __launch_bounds__(256) void joint_df_kernel(
             const int u = ub + i;
             const bool uin = u < Ub;
             s.m[i] = rowmax[uin ? mg0 + u : sentinel];
-            joint_loadv<NK>(gb + static_cast<unsigned>(uin ? u : Ub - 1) * Au, s.x[i]);
+            joint_loadv<Tag, NK>(gb + static_cast<unsigned>(uin ? u : Ub - 1) * Au, s.x[i]);
             if constexpr (OH) s.lab[i] = labels[labs0 + (u < maxU - 1 ? u : (maxU > 1 ? maxU - 2 : 0))];
         }
     };
@@ -673,7 +717,7 @@ __global__ __launch_bounds__(256) void joint_df_kernel(
             const int t = t0 + mfma_row(r, lane);
             const int ts = t < Tb ? t : Tb - 1;
             mt[r] = mf[ts];
-            joint_loadv<NK>(fb + static_cast<unsigned>(ts) * Au, fv[r]);
+            joint_loadv<Tag, NK>(fb + static_cast<unsigned>(ts) * Au, fv[r]);
         }
     };
     if constexpr (PF) {
@@ -711,14 +755,23 @@ __global__ __launch_bounds__(256) void joint_df_kernel(
     //                                        its A operand subtracts straight into them -- issued only for a label that
     //                                        falls into THIS wavefront's 128 NK columns (a ballot per label: about
     //                                        U * 128 NK / A of them hit), so the contraction loop above is untouched;
-    //        df[t, blank] -= sum_u cb(t,u)   the row sum from joint_sums_kernel (sfb), in the lane that owns the column.
+    //        df[t, blank] -= sum_u cb(t,u)   the row sum from joint_sums_kernel (sfb), in the lane that owns the column,
+    //                                        folded into the scaling loop (as a loop of its own BEHIND the label
+    //                                        MFMAs it sent the register allocator of the NK = 2 instantiation to
+    //                                        256 VGPRs + 256 AGPRs + scratch, from 130 + 32).
+    const unsigned dblank = static_cast<unsigned>(blank - kc);            // < NK: the blank column is one of this lane's
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-        const bool live = t0 + mfma_row(r, lane) < Tb;
+        const int t = t0 + mfma_row(r, lane);
+        const bool live = t < Tb;
+        float vb = 0.0f;                                                  // (not OH) the blank column's row sum
+        if constexpr (!OH)
+            if (live && dblank < static_cast<unsigned>(NK)) vb = sfb[static_cast<size_t>(b) * maxT + t];
 #pragma unroll
         for (int n = 0; n < NK; ++n) {
             float o = live ? joint_exp(fv[r][n], mt[r]) * acc[n][r] : 0.0f;
             if constexpr (OH) o = live ? o - acc2[n][r] : 0.0f;
+            else o -= (dblank == static_cast<unsigned>(n)) ? vb : 0.0f;
             acc[n][r] = o;
         }
     }
@@ -759,18 +812,6 @@ __global__ __launch_bounds__(256) void joint_df_kernel(
                 }
             }
         }
-        const unsigned dblank = static_cast<unsigned>(blank - kc);        // < NK: the blank column is one of this lane's
-        if (dblank < static_cast<unsigned>(NK)) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int t = t0 + mfma_row(r, lane);
-                if (t < Tb) {
-                    const float vb = sfb[static_cast<size_t>(b) * maxT + t];
-#pragma unroll
-                    for (int n = 0; n < NK; ++n) acc[n][r] -= (dblank == static_cast<unsigned>(n)) ? vb : 0.0f;
-                }
-            }
-        }
     }
     if (!kin) return;
 #pragma unroll
@@ -784,7 +825,7 @@ __global__ __launch_bounds__(256) void joint_df_kernel(
         float o[NK];
 #pragma unroll
         for (int n = 0; n < NK; ++n) o[n] = acc[n][r];
-        joint_storev<NK>(dfb + static_cast<size_t>(t) * A, o);
+        joint_storev<Tag, NK>(dfb + static_cast<size_t>(t) * A, o);
     }
 }
 
@@ -793,11 +834,11 @@ __global__ __launch_bounds__(256) void joint_df_kernel(
 // A operand = W[t][u0+col] (coalesced along u), B operand = exp(f[t,k] - mf[t]), the streaming
 // read of f, again with two alternating operand sets.
 // grid = (ceil(A / (128 NK)), ceil(maxU/32), N), block = 256.
-template <int NK, bool PF>
+template <typename Tag, int NK, bool PF>
 __global__ __launch_bounds__(256) void joint_dg_kernel(
-        const float* __restrict__ f, const float* __restrict__ g, const float* __restrict__ rowmax,
+        const typename Tag::store* __restrict__ f, const typename Tag::store* __restrict__ g, const float* __restrict__ rowmax,
         const float* __restrict__ wmat, const float* __restrict__ scale, const int* __restrict__ xlen,
-        const int* __restrict__ ylen, float* __restrict__ dg, int maxT, int maxU, int Upad, int A, int N,
+        const int* __restrict__ ylen, typename Tag::store* __restrict__ dg, int maxT, int maxU, int Upad, int A, int N,
         const int* __restrict__ labels, int blank, const float* __restrict__ sgb, const float* __restrict__ sgl) {
     const int b = blockIdx.z;
     const int lane = threadIdx.x & 63, wave = uniform(threadIdx.x >> 6), half = lane >> 5, col = lane & 31;
@@ -818,7 +859,7 @@ __global__ __launch_bounds__(256) void joint_dg_kernel(
         // unconditional operand loads, masking through the +inf sentinel (see joint_df_kernel); label
         // rows past the sample read column 0 and produce accumulator rows nobody stores
         const float* wcol = wmat + static_cast<size_t>(b) * maxT * Upad + (u0 + col < Ub ? u0 + col : 0);
-        const float* fb = f + static_cast<size_t>(b) * maxT * A + (kin ? kc : A - NK);
+        const typename Tag::store* fb = f + static_cast<size_t>(b) * maxT * A + (kin ? kc : A - NK);
         const unsigned Au = static_cast<unsigned>(A), Upu = static_cast<unsigned>(Upad);   // 32-bit offsets (host check)
         const unsigned mf0 = static_cast<unsigned>(b) * maxT;
         const unsigned sentinel = static_cast<unsigned>(N) * (maxT + maxU);
@@ -830,7 +871,7 @@ __global__ __launch_bounds__(256) void joint_dg_kernel(
                 const unsigned ts = static_cast<unsigned>(tin ? t : Tb - 1);
                 s.w[i] = wcol[ts * Upu];
                 s.m[i] = rowmax[tin ? mf0 + t : sentinel];
-                joint_loadv<NK>(fb + ts * Au, s.x[i]);
+                joint_loadv<Tag, NK>(fb + ts * Au, s.x[i]);
             }
         };
         if constexpr (PF) {
@@ -869,7 +910,7 @@ __global__ __launch_bounds__(256) void joint_dg_kernel(
         float o[NK];
         if (u < Ub) {
             const float mu = mg[u];
-            joint_loadv<NK>(g + at, o);
+            joint_loadv<Tag, NK>(g + at, o);
             // corrections without atomics: dg[u, blank] -= sum_t cb(t,u), dg[u, y_u] -= sum_t cl(t,u); both column
             // sums come from joint_sums_kernel, and row u has ONE label
             const float cb = sgb[static_cast<size_t>(b) * maxU + u] * sc;
@@ -890,7 +931,7 @@ __global__ __launch_bounds__(256) void joint_dg_kernel(
 #pragma unroll
             for (int n = 0; n < NK; ++n) o[n] = 0.0f;
         }
-        joint_storev<NK>(dg + at, o);
+        joint_storev<Tag, NK>(dg + at, o);
     }
 }
 
@@ -960,10 +1001,33 @@ __global__ __launch_bounds__(256) void joint_sums_kernel(
 // The far cells (log W above kJointFarC: their weight was left out of the gradient GEMMs): exp(f + g + c) added to
 // the df row and the dg row of the cell directly.  Runs after the GEMMs; a sample without far cells -- every
 // ordinary input -- costs one flag read per block.  Same grid as joint_sums_kernel.
+// fp32 outputs take the hardware float atomic; 16-bit outputs a compare-and-swap on the 32-bit word that holds the
+// element (rare path: correctness, not speed).
+template <typename Tag>
+__device__ __forceinline__ void joint_atomic_add(typename Tag::store* p, float v) {
+    if constexpr (sizeof(typename Tag::store) == 4) {
+        unsafeAtomicAdd(p, v);
+    } else {
+        const uintptr_t a = reinterpret_cast<uintptr_t>(p);
+        unsigned int* w = reinterpret_cast<unsigned int*>(a & ~static_cast<uintptr_t>(3));
+        const int sh = (a & 2u) ? 16 : 0;
+        unsigned int old = *w, seen;
+        do {
+            seen = old;
+            const uint16_t cur = static_cast<uint16_t>(seen >> sh);
+            uint16_t nxt;
+            store1<Tag>(&nxt, load1<Tag>(&cur) + v);
+            old = atomicCAS(w, seen, (seen & ~(0xffffu << sh)) | (static_cast<unsigned int>(nxt) << sh));
+        } while (old != seen);
+    }
+}
+
+template <typename Tag>
 __global__ __launch_bounds__(256) void joint_far_kernel(
-        const float* __restrict__ f, const float* __restrict__ g, const float* __restrict__ rowmax,
+        const typename Tag::store* __restrict__ f, const typename Tag::store* __restrict__ g, const float* __restrict__ rowmax,
         const Cell<float>* __restrict__ rowtab, const float* __restrict__ scale, const int* __restrict__ xlen,
-        const int* __restrict__ ylen, const int* __restrict__ farflag, float* __restrict__ df, float* __restrict__ dg,
+        const int* __restrict__ ylen, const int* __restrict__ farflag, typename Tag::store* __restrict__ df,
+        typename Tag::store* __restrict__ dg,
         int maxT, int maxU, int A, int N, const float* __restrict__ planes, int Upad) {
     const int b = blockIdx.z;
     if (farflag[b] == 0) return;
@@ -980,20 +1044,20 @@ __global__ __launch_bounds__(256) void joint_far_kernel(
     for (int t = tb0 + wave; t < tend; t += 4) {
         float c = log_zero<float>();
         if (uin) c = joint_cell(rowtab, planes, b, t, u, maxT, maxU, Upad, N).x;
-        float* dfrow = df + (static_cast<size_t>(b) * maxT + t) * A;
+        typename Tag::store* dfrow = df + (static_cast<size_t>(b) * maxT + t) * A;
         unsigned long long far = __ballot(uin && c > kJointFarC);
         while (far) {
             const int src = __ffsll(static_cast<long long>(far)) - 1;
             far &= far - 1;
             const int uu = ub0 + src;
             const float shift = lane_get(c, src) - (mf[t] + mg[uu]) * static_cast<float>(kLn2);
-            const float* fr = f + (static_cast<size_t>(b) * maxT + t) * A;
-            const float* gr = g + (static_cast<size_t>(b) * maxU + uu) * A;
-            float* dgrow = dg + (static_cast<size_t>(b) * maxU + uu) * A;
+            const typename Tag::store* fr = f + (static_cast<size_t>(b) * maxT + t) * A;
+            const typename Tag::store* gr = g + (static_cast<size_t>(b) * maxU + uu) * A;
+            typename Tag::store* dgrow = dg + (static_cast<size_t>(b) * maxU + uu) * A;
             for (int k = lane; k < A; k += 64) {
-                const float p = fast_exp(fr[k] + gr[k] + shift) * sc;
-                unsafeAtomicAdd(dfrow + k, p);
-                unsafeAtomicAdd(dgrow + k, p);
+                const float p = fast_exp(load1<Tag>(fr + k) + load1<Tag>(gr + k) + shift) * sc;
+                joint_atomic_add<Tag>(dfrow + k, p);
+                joint_atomic_add<Tag>(dgrow + k, p);
             }
         }
     }

@@ -61,6 +61,10 @@ EXPORTS = {
                                                      rnntOptions, C.c_int, C.c_float]),
     "compute_rnnt_loss_add_bwd": (C.c_int, [_PTR, _PTR, _PTR, _PTR, _PTR, _PTR, _PTR, _PTR, C.c_int, C.c_int, _PTR,
                                             rnntOptions]),
+    "compute_rnnt_loss_add_fwd_dt": (C.c_int, [_PTR, _PTR, _PTR, _PTR, _PTR, C.c_int, C.c_int, _PTR, _PTR, rnntOptions,
+                                               C.c_int, C.c_int, C.c_float]),
+    "compute_rnnt_loss_add_bwd_dt": (C.c_int, [_PTR, _PTR, _PTR, _PTR, _PTR, _PTR, _PTR, _PTR, C.c_int, C.c_int, _PTR,
+                                               rnntOptions, C.c_int]),
     "rnnt_profile_enable": (None, [C.c_int]),
     "rnnt_profile_reset": (None, []),
     "rnnt_profile_collect": (None, []),

@@ -10,10 +10,9 @@ transducer, whose joint logits are ``trans_acts[:, :, None] + pred_acts[:, None]
 
 but it binds ``compute_rnnt_loss_add`` of include/rnnt.h: exp(f+g) = exp(f) exp(g), so the partition
 function and d(trans_acts) = sum_u, d(pred_acts) = sum_t (docs/rnnt_notes.tex:147-153) are three
-small GEMMs per sample on the fp32 matrix cores (csrc/rnnt_joint_kernels.h).  GPU.  The kernels are float32;
-bfloat16 / float16 activations are accepted and staged through float32 copies here (the two activations are
-(B,T,V) and (B,U+1,V), not (B,T,U,V): the staging passes are small next to what the fusion saves), their gradients
-come back in the activations' dtype.
+small GEMMs per sample on the fp32 matrix cores (csrc/rnnt_joint_kernels.h).  GPU.  float32, bfloat16 or
+float16 activations (storage type; the kernels compute in fp32 and write the gradients in the activations'
+dtype -- compute_rnnt_loss_add_fwd_dt / _bwd_dt); the loss is float32.
 """
 import torch
 from torch.autograd import Function
@@ -22,6 +21,8 @@ from torch.nn import Module
 from . import _lib, check_contiguous, check_dim, check_type
 
 __all__ = ["rnnt_loss_add", "RNNTLossAdd"]
+
+_DT = {torch.float32: _lib.DT_F32, torch.bfloat16: _lib.DT_BF16, torch.float16: _lib.DT_F16}
 
 
 def _certify(trans_acts, pred_acts, labels, act_lens, label_lens):
@@ -38,8 +39,8 @@ def _certify(trans_acts, pred_acts, labels, act_lens, label_lens):
     check_dim(label_lens, 1, "label_lengths")
     if not (trans_acts.is_cuda and pred_acts.is_cuda):
         raise ValueError("the additive-joint loss runs on the GPU only")
-    if trans_acts.dtype is not torch.float32 or pred_acts.dtype is not torch.float32:
-        raise TypeError("trans_acts and pred_acts must be torch.float32 (rnnt_loss_add stages 16-bit inputs)")
+    if trans_acts.dtype not in _DT or pred_acts.dtype is not trans_acts.dtype:
+        raise TypeError("trans_acts and pred_acts must both be torch.float32, torch.bfloat16 or torch.float16")
     B, T, V = trans_acts.shape
     if pred_acts.shape[0] != B or pred_acts.shape[2] != V:
         raise ValueError("trans_acts (B,T,V) and pred_acts (B,U+1,V) disagree")
@@ -71,10 +72,10 @@ class _RNNTAdd(Function):
                                    stream=torch.cuda.current_stream(dev).cuda_stream, blank_label=int(blank),
                                    maxT=T, maxU=U, batch_first=True)
             lab_ptr = labels.data_ptr() if labels.numel() else costs.data_ptr()   # maxU == 1: never read
-            st = lib.compute_rnnt_loss_add_fwd_fastemit(trans_acts.data_ptr(), pred_acts.data_ptr(), lab_ptr,
-                                                        label_lens.data_ptr(), act_lens.data_ptr(), V, B,
-                                                        costs.data_ptr(), ws.data_ptr(), opt, 1 if need_grad else 0,
-                                                        float(fastemit_lambda))
+            st = lib.compute_rnnt_loss_add_fwd_dt(trans_acts.data_ptr(), pred_acts.data_ptr(), lab_ptr,
+                                                  label_lens.data_ptr(), act_lens.data_ptr(), V, B,
+                                                  costs.data_ptr(), ws.data_ptr(), opt, _DT[trans_acts.dtype],
+                                                  1 if need_grad else 0, float(fastemit_lambda))
             _lib.check(st, "compute_rnnt_loss_add_fwd")
             ws.record_stream(torch.cuda.current_stream(dev))
         ctx.save_for_backward(trans_acts, pred_acts, labels, act_lens, label_lens)
@@ -102,9 +103,10 @@ class _RNNTAdd(Function):
                                    stream=torch.cuda.current_stream(dev).cuda_stream, blank_label=ctx.blank,
                                    maxT=T, maxU=U, batch_first=True)
             lab_ptr = labels.data_ptr() if labels.numel() else scale.data_ptr()
-            st = lib.compute_rnnt_loss_add_bwd(trans_acts.data_ptr(), pred_acts.data_ptr(), df.data_ptr(),
-                                               dg.data_ptr(), scale.data_ptr(), lab_ptr, label_lens.data_ptr(),
-                                               act_lens.data_ptr(), V, B, ctx.workspace.data_ptr(), opt)
+            st = lib.compute_rnnt_loss_add_bwd_dt(trans_acts.data_ptr(), pred_acts.data_ptr(), df.data_ptr(),
+                                                  dg.data_ptr(), scale.data_ptr(), lab_ptr, label_lens.data_ptr(),
+                                                  act_lens.data_ptr(), V, B, ctx.workspace.data_ptr(), opt,
+                                                  _DT[trans_acts.dtype])
             _lib.check(st, "compute_rnnt_loss_add_bwd")
             ctx.workspace.record_stream(torch.cuda.current_stream(dev))
         return df, dg, None, None, None, None, None, None
@@ -113,14 +115,8 @@ class _RNNTAdd(Function):
 def rnnt_loss_add(trans_acts, pred_acts, labels, act_lens, label_lens, blank=0, reduction="mean",
                   fastemit_lambda=0.0):
     """RNN-T loss of the additive joint ``trans_acts[:, :, None] + pred_acts[:, None]`` without
-    forming it.  Arguments as `rnnt_loss`, with the two activations instead of the joint tensor.
-    float32, or bfloat16 / float16 (staged through float32; the loss is float32, the gradients arrive in the
-    activations' dtype through autograd's cast)."""
-    half = (torch.bfloat16, torch.float16)
-    if trans_acts.dtype in half or pred_acts.dtype in half:
-        if trans_acts.dtype != pred_acts.dtype:
-            raise TypeError("trans_acts and pred_acts must have the same dtype")
-        trans_acts, pred_acts = trans_acts.float(), pred_acts.float()      # differentiable: grads are cast back
+    forming it.  Arguments as `rnnt_loss`, with the two activations instead of the joint tensor
+    (float32, bfloat16 or float16; the loss is float32, the gradients have the activations' dtype)."""
     return _RNNTAdd.apply(trans_acts, pred_acts, labels, act_lens, label_lens, blank, reduction, fastemit_lambda)
 
 

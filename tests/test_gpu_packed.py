@@ -181,3 +181,28 @@ def test_packed_two_phase_is_graph_capturable(oracle):
         assert np.abs(costs.cpu().numpy() - ref_c).max() <= 1e-4 * np.abs(ref_c).max()
         assert np.abs(grads.cpu().numpy() - ref_pk).max() < 2e-4
 
+
+
+def test_supplied_maxima_are_checked_on_the_device(oracle):
+    """max_T / max_U supplied by the caller (no host round trip): a row count that disagrees with the lengths, or maxima
+    smaller than the batch's, give NaN losses instead of silent garbage, and nothing is accessed out of bounds (the
+    valid samples of a batch with one too-long sample are still right)."""
+    from warprnnt_pytorch.packed import RNNTLossPacked, pack_joint
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(31)
+    N, T, U, A = 4, 12, 6, 300
+    acts = torch.tensor(rng.standard_normal((N, T, U, A)).astype(np.float32), device=dev)
+    labels = torch.tensor(rng.integers(1, A, size=(N, U - 1)).astype(np.int32), device=dev)
+    tl = torch.tensor([T, 7, 9, T], dtype=torch.int32, device=dev)
+    ll = torch.tensor([U - 1, 2, 4, 3], dtype=torch.int32, device=dev)
+    packed = pack_joint(acts, tl, ll).contiguous()
+    crit = RNNTLossPacked(blank=0, reduction="none")
+    good = crit(packed, labels, tl, ll, max_T=T, max_U=U)
+    ref_c, _ = oracle.rnnt_logits(acts.double().cpu().numpy(), labels.cpu().numpy(), tl.cpu().numpy(), ll.cpu().numpy())
+    assert np.abs(good.cpu().numpy() - ref_c).max() < 1e-4 * np.abs(ref_c).max()
+    short = crit(packed[:-5].contiguous(), labels, tl, ll, max_T=T, max_U=U)       # fewer rows than the lengths describe
+    assert torch.isnan(short).all()
+    small = crit(packed, labels[:, :U - 2].contiguous(), tl, ll, max_T=T - 1, max_U=U - 1)   # maxima below samples 0 and 3
+    sc = small.cpu().numpy()
+    assert np.isnan(sc[0]) and np.isnan(sc[3]) and not np.isnan(sc[1])
+    torch.cuda.synchronize()

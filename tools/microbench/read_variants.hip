@@ -58,12 +58,12 @@ int main(int argc, char** argv) {
     for (int w : {2, 4, 8}) {
         char nm[64]; snprintf(nm, 64, "row_stats_kernel W=%d NT", w);
         dim3 rg((T * Uu + w - 1) / w, N);
-        if (w == 2) timeit(nm, [&] { hipLaunchKernelGGL((row_stats_kernel<F32, 2, true>), rg, dim3(128), 0, 0, acts, labels, xlen, ylen, lp2, logz, T, Uu, Up, A, 0, 1, nullptr); });
-        if (w == 4) timeit(nm, [&] { hipLaunchKernelGGL((row_stats_kernel<F32, 4, true>), rg, dim3(256), 0, 0, acts, labels, xlen, ylen, lp2, logz, T, Uu, Up, A, 0, 1, nullptr); });
-        if (w == 8) timeit(nm, [&] { hipLaunchKernelGGL((row_stats_kernel<F32, 8, true>), rg, dim3(512), 0, 0, acts, labels, xlen, ylen, lp2, logz, T, Uu, Up, A, 0, 1, nullptr); });
+        if (w == 2) timeit(nm, [&] { hipLaunchKernelGGL((row_stats_kernel<F32, 2, true>), rg, dim3(128), 0, 0, acts, labels, xlen, ylen, lp2, logz, T, Uu, Up, A, 0, 1, nullptr, 0ull); });
+        if (w == 4) timeit(nm, [&] { hipLaunchKernelGGL((row_stats_kernel<F32, 4, true>), rg, dim3(256), 0, 0, acts, labels, xlen, ylen, lp2, logz, T, Uu, Up, A, 0, 1, nullptr, 0ull); });
+        if (w == 8) timeit(nm, [&] { hipLaunchKernelGGL((row_stats_kernel<F32, 8, true>), rg, dim3(512), 0, 0, acts, labels, xlen, ylen, lp2, logz, T, Uu, Up, A, 0, 1, nullptr, 0ull); });
     }
     { dim3 rg(T * Uu, N);
-#define RB(KK) timeit("row_stats_block_kernel NT K=" #KK, [&] { hipLaunchKernelGGL((row_stats_block_kernel<F32, true, KK>), rg, dim3(256), 0, 0, acts, labels, xlen, ylen, lp2, logz, T, Uu, Up, A, 0, 1, nullptr); })
+#define RB(KK) timeit("row_stats_block_kernel NT K=" #KK, [&] { hipLaunchKernelGGL((row_stats_block_kernel<F32, true, KK>), rg, dim3(256), 0, 0, acts, labels, xlen, ylen, lp2, logz, T, Uu, Up, A, 0, 1, nullptr, 0ull); })
       RB(2); RB(3); RB(4); RB(5); RB(8); }
     return 0;
 }

@@ -249,11 +249,11 @@ static void launch_row_stats(Plan<typename Tag::comp>& p, const typename Tag::st
         if (tn.nta)
             hipLaunchKernelGGL((row_stats_block_kernel<Tag, true, 4>), bgrid, dim3(256), 0, p.stream, acts, p.labels,
                                p.input_lengths, p.label_lengths, p.lp2, p.logz, p.maxT, p.maxU, p.Up, p.A, p.blank, vec_ok,
-                               p.offsets);
+                               p.offsets, p.packed_rows);
         else
             hipLaunchKernelGGL((row_stats_block_kernel<Tag, false, 4>), bgrid, dim3(256), 0, p.stream, acts, p.labels,
                                p.input_lengths, p.label_lengths, p.lp2, p.logz, p.maxT, p.maxU, p.Up, p.A, p.blank, vec_ok,
-                               p.offsets);
+                               p.offsets, p.packed_rows);
         p.check();
         return;
     }
@@ -261,7 +261,7 @@ static void launch_row_stats(Plan<typename Tag::comp>& p, const typename Tag::st
 #define RNNT_STATS(WV, NT)                                                                                       \
     hipLaunchKernelGGL((row_stats_kernel<Tag, WV, NT>), dim3((p.cells_per_sample + WV - 1) / WV, p.N), dim3(WV * 64), \
                        0, p.stream, acts, p.labels, p.input_lengths, p.label_lengths, p.lp2, p.logz, p.maxT, p.maxU, \
-                       p.Up, p.A, p.blank, vec_ok, p.offsets)
+                       p.Up, p.A, p.blank, vec_ok, p.offsets, p.packed_rows)
     if (tn.nta) { if (tn.sw == 8) RNNT_STATS(8, true); else if (tn.sw == 2) RNNT_STATS(2, true); else RNNT_STATS(4, true); }
     else { if (tn.sw == 8) RNNT_STATS(8, false); else if (tn.sw == 2) RNNT_STATS(2, false); else RNNT_STATS(4, false); }
 #undef RNNT_STATS
@@ -339,7 +339,7 @@ static void launch_grad(Plan<typename Tag::comp>& p, const typename Tag::store* 
         if (packed && grad_scale) {
             rowscale = reinterpret_cast<CC*>(p.alpha);
             hipLaunchKernelGGL((fill_row_scale_kernel<CC>), dim3(p.N, 8), dim3(256), 0, p.stream, p.offsets, grad_scale,
-                               rowscale);
+                               rowscale, static_cast<long long>(p.packed_rows));
         }
 #define RNNT_FLAT(SC, PP, PS)                                                                                       \
     hipLaunchKernelGGL((grad_flat_kernel<Tag, SC, PP, PS>), dim3(grid), dim3(256), 0, p.stream, acts, grads,        \

@@ -118,7 +118,8 @@ __global__ __launch_bounds__(WAVES * 64) void row_stats_kernel(
         const typename Tag::store* __restrict__ acts, const int* __restrict__ labels,
         const int* __restrict__ xlen, const int* __restrict__ ylen,
         LogPair<typename Tag::comp>* __restrict__ lp2, typename Tag::comp* __restrict__ logz,
-        int maxT, int maxU, int Up, int A, int blank, int vec_ok, const long long* __restrict__ offsets) {
+        int maxT, int maxU, int Up, int A, int blank, int vec_ok, const long long* __restrict__ offsets,
+        unsigned long long total_rows) {                     // packed layout: rows of the tensor (offsets are device data: never read past it)
     using S = typename Tag::store;
     using C = typename Tag::comp;
     constexpr int V = Vec<Tag>::N;
@@ -136,6 +137,7 @@ __global__ __launch_bounds__(WAVES * 64) void row_stats_kernel(
 
     const size_t rix = offsets != nullptr ? static_cast<size_t>(offsets[b]) + q
                                           : static_cast<size_t>(b) * maxT * maxU + q;
+    if (offsets != nullptr && rix >= total_rows) return;
     const S* row = acts + rix * A;
     const bool has_lab = u < Ub - 1;
     int lab = blank;
@@ -203,7 +205,8 @@ __global__ __launch_bounds__(256) void row_stats_block_kernel(
         const typename Tag::store* __restrict__ acts, const int* __restrict__ labels,
         const int* __restrict__ xlen, const int* __restrict__ ylen,
         LogPair<typename Tag::comp>* __restrict__ lp2, typename Tag::comp* __restrict__ logz,
-        int maxT, int maxU, int Up, int A, int blank, int vec_ok, const long long* __restrict__ offsets) {
+        int maxT, int maxU, int Up, int A, int blank, int vec_ok, const long long* __restrict__ offsets,
+        unsigned long long total_rows) {                     // packed layout: rows of the tensor (offsets are device data: never read past it)
     using S = typename Tag::store;
     using C = typename Tag::comp;
     constexpr int V = Vec<Tag>::N;
@@ -219,6 +222,7 @@ __global__ __launch_bounds__(256) void row_stats_block_kernel(
 
     const size_t rix = offsets != nullptr ? static_cast<size_t>(offsets[b]) + q
                                           : static_cast<size_t>(b) * maxT * maxU + q;
+    if (offsets != nullptr && rix >= total_rows) return;
     const S* row = acts + rix * A;
     int head, nvec, tail0;
     row_split<S>(reinterpret_cast<uintptr_t>(row), A, vec_ok != 0, head, nvec, tail0);
@@ -1011,7 +1015,8 @@ __global__ __launch_bounds__(256) void coef_cell_kernel(
     const CoefRaw<L> raw = coef_fetch<L>(lp2, logz, alpha_arr, beta, offa, offb, labels, b, n, u, maxT, maxU, Up, lw, lsh, wu);
     const Cell<L> o = coef_eval<L>(raw, ll_fwd[b], t, u, Tb, Ub, fastemit);
     if (offsets != nullptr) {
-        if (t < Tb && u < Ub) rowtab[static_cast<size_t>(offsets[b]) + static_cast<size_t>(t) * Ub + u] = o;
+        const size_t at = static_cast<size_t>(offsets[b]) + static_cast<size_t>(t) * Ub + u;
+        if (t < Tb && u < Ub && at < static_cast<size_t>(gridDim.y) * maxT * maxU) rowtab[at] = o;   // (inside the table whatever the offsets say)
     } else if (planes != 4) {
         rowtab[(static_cast<size_t>(b) * maxT + t) * maxU + u] = o;
     }
@@ -1093,7 +1098,8 @@ __global__ __launch_bounds__(256) void coef_kernel(
         if (u > u0 + 63 || u >= maxU || t + u >= n0 + DN || t + u >= D) continue;
         const Cell<L> o = recs[t + u - n0][u - u0];
         if (offsets != nullptr) {                          // packed row order: the run of a time row stays contiguous
-            if (t < Tb && u < Ub) rowtab[static_cast<size_t>(offsets[b]) + static_cast<size_t>(t) * Ub + u] = o;
+            const size_t at = static_cast<size_t>(offsets[b]) + static_cast<size_t>(t) * Ub + u;
+            if (t < Tb && u < Ub && at < static_cast<size_t>(gridDim.y) * maxT * maxU) rowtab[at] = o;
         } else if (planes != 4) {
             rowtab[(static_cast<size_t>(b) * maxT + t) * maxU + u] = o;
         }
@@ -1118,9 +1124,10 @@ __global__ __launch_bounds__(256) void coef_kernel(
 // grid = (N, 8), block = 256.
 template <typename C>
 __global__ __launch_bounds__(256) void fill_row_scale_kernel(
-        const long long* __restrict__ offsets, const C* __restrict__ grad_scale, C* __restrict__ rowscale) {
+        const long long* __restrict__ offsets, const C* __restrict__ grad_scale, C* __restrict__ rowscale,
+        long long total_rows) {
     const int b = blockIdx.x;
-    const long long lo = offsets[b], hi = offsets[b + 1];
+    const long long lo = offsets[b], hi = offsets[b + 1] < total_rows ? offsets[b + 1] : total_rows;
     const C s = grad_scale[b];
     for (long long r = lo + static_cast<long long>(blockIdx.y) * 256 + threadIdx.x; r < hi;
          r += static_cast<long long>(gridDim.y) * 256)

@@ -69,6 +69,7 @@ class _RNNTPacked(Function):
         if not acts.is_cuda:
             return _RNNTPacked._forward_cpu(ctx, acts, labels, act_lens, label_lens, offs, blank, reduction,
                                             fastemit_lambda, max_T, max_U)
+        lazy_check = not (max_T is None or max_U is None)
         if max_T is None or max_U is None:
             # one host round trip for the lattice dimensions (pass max_T / max_U to avoid it)
             mt, ml, total = torch.stack([act_lens.max().to(torch.int64), label_lens.max().to(torch.int64),
@@ -96,6 +97,11 @@ class _RNNTPacked(Function):
                                                   1 if need_grad else 0, float(fastemit_lambda))
             _lib.check(st, "compute_rnnt_loss_packed_fwd")
             ws.record_stream(torch.cuda.current_stream(dev))
+            if lazy_check:
+                # max_T / max_U were supplied, so nothing was brought to the host: the consistency of the row count is
+                # checked on the device and a mismatch poisons the loss (too-small maxima poison the affected samples
+                # inside the library; nothing is read or written out of bounds either way)
+                costs = torch.where(offs[-1] == R, costs, torch.full_like(costs, float("nan")))
         ctx.save_for_backward(acts, offs)
         ctx.workspace = ws if need_grad else None
         ctx.opt_dims = (int(blank), int(max_T), int(max_U), N)

@@ -1,4 +1,4 @@
 set -x
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-( timeout 900 python -m pytest tests/test_gpu_packed.py tests/test_gpu_parity.py -m gpu -x -q 2>&1 | tail -25 ) > gpurun_out/pytest_gpu.log
+( python tools/stage_times.py c4; python tools/stage_times.py c4 ) > gpurun_out/r02p_coef_occ.log 2>&1

@@ -1044,6 +1044,12 @@ __global__ __launch_bounds__(256) void coef_cell_kernel(
 //            cell, which cost 0.225 of this kernel's 0.42 ms on c4 even with the partial lines meeting in
 //            one L2.  The dense weight matrix of the additive-joint path leaves the same way.
 // grid = (ceil(D/DN) * ceil(maxU/64), N), block = 256.
+// Cells of a wavefront whose operands are requested together in the tiled kernel.  All eight: 155 VGPRs, three
+// wavefronts per SIMD, c4 0.30 ms; FOUR (two round trips): 126 VGPRs, four wavefronts per SIMD, 0.27 ms; two: the
+// same; one: 0.39 ms.
+#ifndef COEF_KB
+#define COEF_KB 4
+#endif
 template <typename L>
 __global__ __launch_bounds__(256) void coef_kernel(
         const LogPair<L>* __restrict__ lp2, const L* __restrict__ logz, const L* __restrict__ alpha_arr,
@@ -1061,27 +1067,31 @@ __global__ __launch_bounds__(256) void coef_kernel(
     const int D = maxT + maxU - 1;
     const int Tb = clamp_len(xlen[b], maxT), Ub = clamp_len(ylen[b] + 1, maxU);
 
-    // ---- compute, skewed order: all operands of the wavefront's DN/4 cells are requested first (one round trip)
+    // ---- compute, skewed order: the operands of COEF_KB of the wavefront's DN/4 cells are requested together
     {
         constexpr int K = DN / 4;                          // diagonals per wavefront
+        constexpr int KB = COEF_KB;                        // ... requested together
         const int u = u0 + lane;
         const int uc = u < maxU ? u : maxU - 1;            // columns past the lattice fetch a valid one, their record is padding
         const double ll2 = ll_fwd[b];
-        CoefRaw<L> raw[K];
+#pragma unroll 1
+        for (int i0 = 0; i0 < K; i0 += KB) {
+            CoefRaw<L> raw[KB];
 #pragma unroll
-        for (int i = 0; i < K; ++i) {
-            const int n = n0 + wave + 4 * i;
-            raw[i] = coef_fetch<L>(lp2, logz, alpha_arr, beta, offa, offb, labels, b, n < D ? n : D - 1, uc, maxT, maxU, Up, lw, lsh,
-                                   u0 >> lsh);
-        }
+            for (int i = 0; i < KB; ++i) {
+                const int n = n0 + wave + 4 * (i0 + i);
+                raw[i] = coef_fetch<L>(lp2, logz, alpha_arr, beta, offa, offb, labels, b, n < D ? n : D - 1, uc, maxT, maxU, Up, lw, lsh,
+                                       u0 >> lsh);
+            }
 #pragma unroll
-        for (int i = 0; i < K; ++i) {
-            const int dn = wave + 4 * i;
-            const int n = n0 + dn, t = n - u;
-            Cell<L> o;
-            o.x = log_zero<L>(); o.y = 0; o.z = 0; o.w = static_cast<L>(kPadded);
-            if (n < D && u < maxU && t >= 0 && t < maxT) o = coef_eval<L>(raw[i], ll2, t, u, Tb, Ub, fastemit);
-            recs[dn][lane] = o;
+            for (int i = 0; i < KB; ++i) {
+                const int dn = wave + 4 * (i0 + i);
+                const int n = n0 + dn, t = n - u;
+                Cell<L> o;
+                o.x = log_zero<L>(); o.y = 0; o.z = 0; o.w = static_cast<L>(kPadded);
+                if (n < D && u < maxU && t >= 0 && t < maxT) o = coef_eval<L>(raw[i], ll2, t, u, Tb, Ub, fastemit);
+                recs[dn][lane] = o;
+            }
         }
     }
     __syncthreads();

@@ -216,3 +216,37 @@ def test_device_side_lengths_are_validated(oracle):
     assert lib.compute_rnnt_loss(x.data_ptr(), grads.data_ptr(), lab.data_ptr(), tll.data_ptr(), ttl.data_ptr(), A, N,
                                  costs.data_ptr(), ws.data_ptr(), opt) == 0
     assert np.abs(costs.numpy() - ref_c).max() < 1e-4
+
+
+def test_wide_lattice_sweep(oracle):
+    """The multi-wavefront lattice forms with ragged batches: 48 seeded problems with maxU between 65 and 1024 (one and two
+    columns per lane, every instantiation), T_b and U_b anywhere in range -- U_b on, just before and just after wavefront and
+    lane-pair boundaries --, fp32 and fp64, against the oracle."""
+    rng = np.random.default_rng(20260926)
+    edges = [1, 2, 63, 64, 65, 66, 127, 128, 129, 130, 191, 192, 193, 255, 256, 257, 258, 319, 320, 383, 384, 385, 511, 512, 513,
+             514, 639, 640, 641, 767, 768, 769, 1023, 1024]
+    for it in range(48):
+        U = int(rng.choice([65, 66, 100, 128, 129, 192, 200, 256, 257, 258, 300, 320, 321, 384, 400, 512, 513, 514, 600, 640, 700, 768, 1000, 1024]))
+        N = int(rng.integers(2, 5))
+        T = int(rng.integers(1, 40))
+        A = int(rng.choice([2, 3, 5, 9]))
+        acts = rng.standard_normal((N, T, U, A)) * float(rng.choice([0.5, 2.0, 5.0]))
+        blank = int(rng.integers(0, A))
+        labels = rng.integers(0, A, size=(N, U - 1))
+        labels[labels == blank] = (blank + 1) % A
+        tl = rng.integers(1, T + 1, size=N); tl[int(rng.integers(0, N))] = T
+        cand = [e for e in edges if e <= U]
+        ul = np.array([int(rng.choice(cand)) if rng.random() < 0.7 else int(rng.integers(1, U + 1)) for _ in range(N)])
+        ul[int(rng.integers(0, N))] = U
+        ll = ul - 1
+        dtype = torch.float64 if it % 3 == 0 else torch.float32
+        x = acts if dtype == torch.float64 else acts.astype(np.float32).astype(np.float64)
+        ref_c, ref_g = oracle.rnnt_logits(x, labels, tl, ll, blank)
+        costs, grads = run_gpu(x, labels, tl, ll, blank, dtype=dtype)
+        # fp32: north_star's 1e-3 -- a thousand lattice steps on logits of magnitude 25 sit right at it (the log-probs
+        # themselves are fp32: 2e-6 each); the shorter lattices stay under 5e-4
+        tol_c, tol_g = (1e-10, 1e-9) if dtype == torch.float64 else (1e-4, 1e-3 if U >= 512 else 5e-4)
+        assert np.abs(costs - ref_c).max() <= tol_c * max(1.0, np.abs(ref_c).max()), (it, N, T, U, A, ul.tolist(), str(dtype))
+        assert np.abs(grads - ref_g).max() < tol_g, (it, N, T, U, A, ul.tolist(), str(dtype))
+        for b in range(N):
+            assert not grads[b, tl[b]:].any() and not grads[b, :, ll[b] + 1:].any()

@@ -167,6 +167,8 @@ def main():
     ap.add_argument("--pinned-costs", action="store_true",
                     help="host costs in pinned memory: the lattice kernel writes them directly, no staged D2H copy "
                          "(the default, pageable costs, is what the reference's callers pass)")
+    ap.add_argument("--overlap-collective", action="store_true",
+                    help="sharded step through the two-phase entry with the all-reduce BESIDE the gradient pass (A/B runs)")
     ap.add_argument("--force-sharded", action="store_true",
                     help="dev: run the multi-GPU step (async entry + RCCL all-reduce) even with one rank")
     args = ap.parse_args()
@@ -271,17 +273,39 @@ def main():
             code = {"fp32": _lib.DT_F32, "bf16": _lib.DT_BF16}[w["dtype"]]
             argv = (acts.data_ptr(), grads.data_ptr(), labels.data_ptr(), label_lens.data_ptr(),
                     act_lens.data_ptr(), A, N, costs.data_ptr(), None, ws.data_ptr(), opt, code)
+            fwd_argv = (acts.data_ptr(), labels.data_ptr(), label_lens.data_ptr(), act_lens.data_ptr(), A, N,
+                        costs.data_ptr(), ws.data_ptr(), opt, code, 1)
+            bwd_argv = (acts.data_ptr(), grads.data_ptr(), None, A, N, ws.data_ptr(), opt, code)
             packed = torch.zeros(2, dtype=torch.float64, device=dev)     # [summed loss, sample count]
 
-            def step():
-                st = lib.compute_rnnt_loss_async(*argv)
-                assert st == 0, _lib.status_string(st)
-                torch.sum(costs, dtype=torch.float64, out=packed[0])
+            def reduce_loss(async_op):
+                torch.sum(costs, dim=0, keepdim=True, dtype=torch.float64, out=packed[0:1])   # (no per-step allocation)
                 packed[1] = float(N)
-                dist.all_reduce(packed)          # the one collective of the data path (RCCL over xGMI)
-                torch.cuda.synchronize(dev)
-                lib.rnnt_profile_collect()
-                return packed
+                return dist.all_reduce(packed, async_op=async_op)   # the one collective of the data path (RCCL over xGMI)
+
+            if args.overlap_collective:
+                def step():
+                    # two-phase entry: the costs exist after the forward phase, so the collective (16 bytes, RCCL's own
+                    # stream) can run BESIDE the gradient pass.  Measured on one rank (`profiles/r02x_*`): the two
+                    # cross-stream event waits cost more (+30 us) than a one-rank collective takes, so this is an option
+                    # for multi-GPU A/B runs, not the default.
+                    st = lib.compute_rnnt_loss_fwd(*fwd_argv)
+                    assert st == 0, _lib.status_string(st)
+                    work = reduce_loss(True)
+                    st = lib.compute_rnnt_loss_bwd(*bwd_argv)
+                    assert st == 0, _lib.status_string(st)
+                    work.wait()                                  # the compute stream waits for the reduced loss
+                    torch.cuda.synchronize(dev)
+                    lib.rnnt_profile_collect()
+                    return packed
+            else:
+                def step():
+                    st = lib.compute_rnnt_loss_async(*argv)
+                    assert st == 0, _lib.status_string(st)
+                    reduce_loss(False)
+                    torch.cuda.synchronize(dev)
+                    lib.rnnt_profile_collect()
+                    return packed
 
         for _ in range(warmup):
             step()
@@ -357,7 +381,8 @@ def main():
                                   + (", host costs in pinned memory" if args.pinned_costs else "")),
                    "global_batch": w["N"] * world, "per_gpu_batch": w["N"],
                    "parallelism": "batch-sharded x%d, one RCCL all-reduce of the summed loss" % world
-                   if world > 1 else "single GPU"},
+                   if sharded else "single GPU"},
+        "check": {"loss_sum": r["loss_sum"], "note": "summed loss of the last step (all ranks when sharded)"},
         "samples_per_s": round(w["N"] * world / (ms * 1e-3), 1),
         "step_ms": r["step_ms"],
         "plain_step_ms": r["plain_step_ms"],
@@ -404,10 +429,16 @@ def main():
                            "stage_ms": [round(x, 4) for x in e["stage_ms"]],
                            "path_frac": round(eb["path"] / (e["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
         out["other_workloads"] = extra
-    if rank == 0:
-        print(json.dumps(out))
     if sharded:
         dist.destroy_process_group()
+    # RCCL prints its version banner through C stdio, which would otherwise be flushed at exit, BEHIND the JSON line:
+    # flush it first so that the JSON line is the last line of stdout
+    try:
+        C.CDLL(None).fflush(None)
+    except OSError:
+        pass
+    if rank == 0:
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

@@ -411,7 +411,10 @@ rnntStatus_t compute_rnnt_loss_add_bwd_dt(const void* trans_acts,
  *   ms[3] gradient kernel  (dense gradient write-back)
  *   ms[4] whole enqueue, first kernel start -> last kernel end
  * compute_rnnt_loss_async does not synchronise, so its events are read by an explicit
- * rnnt_profile_collect() once the caller has synchronised the stream.
+ * rnnt_profile_collect() once the caller has synchronised the stream.  A two-phase step
+ * (compute_rnnt_loss_fwd ... compute_rnnt_loss_bwd, one collect after both) counts as ONE call:
+ * ms[0..2] come from the forward call, ms[3] from the backward call, and what the caller
+ * enqueued between the two is inside ms[4] only.
  * Process-global, not thread-safe; meant for bench.py only. */
 void rnnt_profile_enable(int on);
 void rnnt_profile_collect(void);   /* after synchronising a compute_rnnt_loss_async call: add its times */

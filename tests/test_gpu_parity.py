@@ -240,6 +240,48 @@ def test_pinned_host_costs_are_written_directly():
         warp_rnnt.gpu_rnnt(x, lab, bad, llen, torch.zeros(x.shape[0], pin_memory=True), torch.zeros_like(x), blank, 0)
 
 
+def test_pageable_host_costs_through_the_staging_buffer():
+    """Pageable host costs (the reference's callers) come back through the calling thread's pinned staging buffer:
+    a small batch first, then one that makes the buffer grow (fp64: 8 bytes per sample), then the same call from a
+    second thread (its own buffer) -- always the values of the device-cost entry, and untouched memory around them."""
+    import threading
+    from warprnnt_pytorch import warp_rnnt
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(3)
+
+    def one(n, dtype):
+        x = torch.randn((n, 6, 4, 9), generator=g, device=dev, dtype=dtype)
+        lab = torch.randint(1, 9, (n, 3), generator=g, device=dev, dtype=torch.int32)
+        tl = torch.full((n,), 6, dtype=torch.int32, device=dev)
+        ll = torch.full((n,), 3, dtype=torch.int32, device=dev)
+        host = torch.full((n + 2,), -7.0, dtype=dtype)                 # guard words on both sides
+        grads = torch.zeros_like(x)
+        assert warp_rnnt.gpu_rnnt(x, lab, tl, ll, host[1:n + 1], grads, 0, 0) == 0
+        ref = torch.empty(n, dtype=dtype, device=dev)
+        ws = warp_rnnt.gpu_rnnt_fwd(x, lab, tl, ll, ref, 0, False)
+        torch.cuda.synchronize()
+        del ws
+        assert host[0].item() == -7.0 and host[n + 1].item() == -7.0
+        assert torch.equal(host[1:n + 1], ref.cpu())
+        assert bool(torch.isfinite(host).all()) and bool((host[1:n + 1] > 0).all())
+
+    one(3, torch.float32)
+    one(2000, torch.float64)                                           # 16 000 bytes: past the first 4 KB buffer
+    one(5, torch.float32)
+    errs = []
+
+    def worker():
+        try:
+            torch.cuda.set_device(0)
+            one(1500, torch.float32)
+            one(7, torch.float64)
+        except Exception as e:                                         # noqa: BLE001 -- reported to the main thread
+            errs.append(e)
+    th = threading.Thread(target=worker)
+    th.start(); th.join()
+    assert not errs, errs
+
+
 def test_determinism():
     acts, labels, tl, ll, blank = case_inputs("wide_u70")
     a = run_gpu(acts, labels, tl, ll, blank)

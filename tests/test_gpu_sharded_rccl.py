@@ -131,6 +131,27 @@ def test_bench_self_launches_two_ranks():
     assert line["n_gpus"] == 2 and line["config"]["global_batch"] == 256 and line["dtype"] == "bf16"
 
 
+def test_bench_sharded_step_on_one_rank():
+    """The step `bench.py --gpus N` times for N > 1 (loss + gradients -> RCCL all-reduce of [loss sum, count]; and its
+    two-phase variant with the collective beside the gradient pass), on a one-rank RCCL group so that it runs on a one-GPU
+    box too: same loss sum as the plain one-GPU step on the same inputs, a complete JSON line as the LAST line of stdout."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29547")
+    base = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--workload", "c5", "--steps", "4", "--warmup", "1",
+            "--no-cpu-baseline"]
+    lines = []
+    for extra in (["--force-sharded"], ["--force-sharded", "--overlap-collective"], []):
+        out = subprocess.run(base + extra, capture_output=True, text=True, timeout=900, env=env)
+        assert out.returncode == 0, out.stderr[-2000:]
+        lines.append(json.loads(out.stdout.strip().splitlines()[-1]))
+    sh, ov, plain = lines
+    assert abs(ov["check"]["loss_sum"] - plain["check"]["loss_sum"]) <= 1e-6 * abs(plain["check"]["loss_sum"])
+    assert ov["stage_ms"]["grad"] > 0 and ov["stage_ms"]["row_stats"] > 0      # two calls, one profiled step
+    assert sh["n_gpus"] == 1 and sh["scaling"] == "weak" and sh["dtype"] == "bf16" and sh["value"] > 0
+    assert "all-reduce" in sh["config"]["parallelism"]
+    assert abs(sh["check"]["loss_sum"] - plain["check"]["loss_sum"]) <= 1e-6 * abs(plain["check"]["loss_sum"])
+    assert sh["stage_ms"]["grad"] > 0 and sh["stage_ms"]["row_stats"] > 0
+
+
 def test_bench_refuses_more_gpus_than_visible():
     """`bench.py --gpus N` with fewer than N devices must fail loudly, never fall back to fewer GPUs."""
     n = torch.cuda.device_count() + 1

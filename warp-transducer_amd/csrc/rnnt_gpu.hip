@@ -64,13 +64,19 @@ static Layout make_layout(int maxT, int maxU, int N, size_t lat, bool joint) {
 }
 
 // ----------------------------------------------------------------------------- profiling
+// Stage boundaries as HIP events on the caller's stream: 0 start, 1 after the statistics, 2 after the lattice, 3 after
+// the coefficients (end of a forward phase), 4 start and 5 end of the gradient stage.  A one-call entry records all six;
+// the two-phase entries record 0-3 (compute_rnnt_loss_fwd) and 4-5 (compute_rnnt_loss_bwd), and whatever the caller
+// enqueues between the two calls is in neither stage.  One rnnt_profile_collect() reads what has been recorded since
+// the last one as ONE step.
 struct Profile {
     bool on = false;
     bool ready = false;
-    hipEvent_t ev[5];
-    double ms[5] = {0, 0, 0, 0, 0};
+    hipEvent_t ev[6];
+    double ms[5] = {0, 0, 0, 0, 0};   // statistics, lattice, coefficients, gradient, first event to last
     int calls = 0;
     bool pending = false;   // events of an asynchronous call recorded, not yet read
+    bool has_fwd = false, has_bwd = false;
 };
 static Profile g_prof;
 
@@ -84,15 +90,28 @@ static bool prof_prepare() {
     return true;
 }
 
-static void prof_accumulate() {
-    for (int i = 0; i < 4; ++i) {
-        float ms = 0.f;
-        if (hipEventElapsedTime(&ms, g_prof.ev[i], g_prof.ev[i + 1]) == hipSuccess) g_prof.ms[i] += ms;
+// mark(i) of the run_* functions: i = 0..4 are the boundaries of the four stages of one call
+static void prof_mark(int i, bool do_fwd, bool do_bwd, hipStream_t stream) {
+    if (i < 3) { if (do_fwd) (void)hipEventRecord(g_prof.ev[i], stream); return; }
+    if (i == 3) {
+        if (do_fwd) { (void)hipEventRecord(g_prof.ev[3], stream); g_prof.has_fwd = true; }
+        if (do_bwd) (void)hipEventRecord(g_prof.ev[4], stream);
+        return;
     }
+    if (do_bwd) { (void)hipEventRecord(g_prof.ev[5], stream); g_prof.has_bwd = true; }
+}
+
+static void prof_accumulate() {
     float ms = 0.f;
-    if (hipEventElapsedTime(&ms, g_prof.ev[0], g_prof.ev[4]) == hipSuccess) g_prof.ms[4] += ms;
+    if (g_prof.has_fwd)
+        for (int i = 0; i < 3; ++i)
+            if (hipEventElapsedTime(&ms, g_prof.ev[i], g_prof.ev[i + 1]) == hipSuccess) g_prof.ms[i] += ms;
+    if (g_prof.has_bwd && hipEventElapsedTime(&ms, g_prof.ev[4], g_prof.ev[5]) == hipSuccess) g_prof.ms[3] += ms;
+    if ((g_prof.has_fwd || g_prof.has_bwd) &&
+        hipEventElapsedTime(&ms, g_prof.ev[g_prof.has_fwd ? 0 : 4], g_prof.ev[g_prof.has_bwd ? 5 : 3]) == hipSuccess)
+        g_prof.ms[4] += ms;
     g_prof.calls++;
-    g_prof.pending = false;
+    g_prof.pending = g_prof.has_fwd = g_prof.has_bwd = false;
 }
 
 // ----------------------------------------------------------------------------- tuning knobs
@@ -365,6 +384,34 @@ static void launch_grad(Plan<typename Tag::comp>& p, const typename Tag::store* 
 
 // The materialised path.  phases: bit 0 = forward part (row statistics, lattice and -- when gradients
 // are wanted -- the coefficient table), bit 1 = gradient kernel; the two-call form
+// Pageable host costs (what the reference's callers pass): the lattice kernel writes them into a small PINNED staging
+// buffer of the calling thread -- N values, allocated on the thread's first such call, grown when a larger batch comes
+// along, host memory only -- and the call copies them out after its stream synchronisation.  The alternative, a
+// hipMemcpyAsync into pageable memory behind the last kernel, stages through the runtime's own pinned buffers and
+// costs ~10 us of a 50 us call.  (Never freed: a thread_local destructor would call into the HIP runtime while the
+// process tears it down.)
+struct HostStage { void* host = nullptr; void* dev = nullptr; size_t cap = 0; };
+static void* host_stage(size_t bytes, void** host_out) {
+    static thread_local HostStage st;
+    if (st.cap < bytes) {
+        if (st.host != nullptr) (void)hipHostFree(st.host);
+        st = HostStage{};
+        size_t cap = 4096;
+        while (cap < bytes) cap <<= 1;
+        void* h = nullptr;
+        void* d = nullptr;
+        if (hipHostMalloc(&h, cap, hipHostMallocPortable | hipHostMallocMapped) != hipSuccess ||
+            hipHostGetDevicePointer(&d, h, 0) != hipSuccess) {
+            if (h != nullptr) (void)hipHostFree(h);
+            (void)hipGetLastError();
+            return nullptr;                            // the caller falls back to the asynchronous copy
+        }
+        st.host = h; st.dev = d; st.cap = cap;
+    }
+    *host_out = st.host;
+    return st.dev;
+}
+
 // (compute_rnnt_loss_fwd / _bwd) keeps only the workspace alive in between.  want_grad < 0: decided by
 // `grads != nullptr` (the reference's "gradients == NULL means score only").
 template <typename Tag>
@@ -378,16 +425,22 @@ static rnntStatus_t run_gpu(const typename Tag::store* acts, typename Tag::store
     using C = typename Tag::comp;
     Plan<C> p;
     // Host costs in PINNED memory (hipHostMalloc / hipHostRegister, e.g. a torch tensor with pin_memory=True) are
-    // written by the lattice kernel directly: no staged pageable copy behind the last kernel, only the stream
-    // synchronisation the contract asks for (a 0.08 ms call spends ~10 us in that copy).  Pageable memory, which
-    // the reference's callers pass, takes the hipMemcpyAsync below.
+    // written by the lattice kernel directly: no copy behind the last kernel, only the stream synchronisation the
+    // contract asks for.  Pageable memory, which the reference's callers pass, goes through the thread's pinned staging
+    // buffer (host_stage above); the hipMemcpyAsync below is the fallback when that cannot be allocated.
     C* costs_direct = nullptr;
+    C* costs_staged = nullptr;                         // host view of the staging buffer, when it is in use
     if (costs_host != nullptr && costs_device_out == nullptr) {
         hipPointerAttribute_t attr;
         if (hipPointerGetAttributes(&attr, costs_host) == hipSuccess && attr.type == hipMemoryTypeHost &&
             attr.devicePointer != nullptr)
             costs_direct = static_cast<C*>(attr.devicePointer);
         (void)hipGetLastError();                       // (the query of a pageable pointer reports an error: not ours)
+        if (costs_direct == nullptr && N > 0) {
+            void* h = nullptr;
+            costs_direct = static_cast<C*>(host_stage(sizeof(C) * static_cast<size_t>(N), &h));
+            if (costs_direct != nullptr) costs_staged = static_cast<C*>(h);
+        }
     }
     if (!make_plan(p, A, N, opt, workspace, labels, label_lengths, input_lengths,
                    costs_direct != nullptr ? costs_direct : costs_device_out))
@@ -415,7 +468,7 @@ static rnntStatus_t run_gpu(const typename Tag::store* acts, typename Tag::store
         return RNNT_STATUS_INVALID_VALUE;
 
     const bool prof = prof_prepare();
-    auto mark = [&](int i) { if (prof) (void)hipEventRecord(g_prof.ev[i], p.stream); };
+    auto mark = [&](int i) { if (prof) prof_mark(i, do_fwd, do_bwd, p.stream); };
 
     mark(0);
     if (do_fwd) launch_row_stats<Tag>(p, acts, vec_ok);
@@ -434,6 +487,7 @@ static rnntStatus_t run_gpu(const typename Tag::store* acts, typename Tag::store
             hipMemcpyAsync(costs_host, p.costs_dev, sizeof(C) * N, hipMemcpyDeviceToHost, p.stream) != hipSuccess)
             return RNNT_STATUS_MEMOPS_FAILED;
         if (hipStreamSynchronize(p.stream) != hipSuccess) return RNNT_STATUS_EXECUTION_FAILED;
+        if (costs_staged != nullptr) std::memcpy(costs_host, costs_staged, sizeof(C) * static_cast<size_t>(N));
         if (prof) prof_accumulate();
         // device-side lengths that do not fit the tensor (lattice_kernel marks the sample's cost): the same
         // status the CPU location returns for them (rnnt_cpu.cpp)
@@ -472,7 +526,7 @@ static rnntStatus_t run_gpu_joint(const typename Tag::store* f, const typename T
         return RNNT_STATUS_INVALID_VALUE;
     const bool training = want_grad;
     const bool prof = prof_prepare();
-    auto mark = [&](int i) { if (prof) (void)hipEventRecord(g_prof.ev[i], p.stream); };
+    auto mark = [&](int i) { if (prof) prof_mark(i, do_fwd, do_bwd, p.stream); };
 
     const int maxT = p.maxT, maxU = p.maxU;
     // rows made of whole 16-byte packets (row-maximum kernel) and 4-element loads aligned (Z kernel)

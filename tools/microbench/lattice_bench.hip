@@ -6,6 +6,12 @@
 #include "../../warp-transducer_amd/csrc/rnnt_kernels.h"
 using namespace rnnt;
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1);} } while (0)
+// argv[5] = 1: the same measurement while a second stream keeps the memory system saturated with a streaming copy
+// (what the lattice kernel would see beside the statistics / gradient kernel of another half of the batch)
+__global__ __launch_bounds__(256) void hog_copy(const u32x4* __restrict__ in, u32x4* __restrict__ out, size_t n) {
+    for (size_t i = blockIdx.x * 256ull + threadIdx.x; i < n; i += static_cast<size_t>(gridDim.x) * 256)
+        __builtin_nontemporal_store(__builtin_nontemporal_load(in + i), out + i);
+}
 int main(int argc, char** argv) {
     const int N = argc > 1 ? atoi(argv[1]) : 16, T = argc > 2 ? atoi(argv[2]) : 1500, U = argc > 3 ? atoi(argv[3]) : 41;
     const int Up = (U + 63) / 64 * 64, W = Up / 64;
@@ -21,20 +27,34 @@ int main(int argc, char** argv) {
     std::vector<int> hx(N, T), hy(N, U - 1);
     CK(hipMemcpy(xlen, hx.data(), N * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(ylen, hy.data(), N * 4, hipMemcpyHostToDevice));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    hipStream_t ls; CK(hipStreamCreateWithFlags(&ls, hipStreamNonBlocking));
     auto launch = [&] {
         const int cols = argc > 4 ? atoi(argv[4]) : 2;          // columns per lane for U > 64
-        if (W == 1) hipLaunchKernelGGL((lattice_kernel<float, 1, 1>), dim3(N * 2), dim3(64), 0, 0, cells, alpha, beta, offa, offb, llf, llb, costs, xlen, ylen, T, U, Up, 2);
-        else if (cols == 1) hipLaunchKernelGGL((lattice_kernel<float, 8, 1>), dim3(N * 2), dim3(Up), 0, 0, cells, alpha, beta, offa, offb, llf, llb, costs, xlen, ylen, T, U, Up, 2);
-        else if (lat_waves(Up, 2) <= 4) hipLaunchKernelGGL((lattice_kernel<float, 4, 2>), dim3(N * 2), dim3(lat_waves(Up, 2) * 64), 0, 0, cells, alpha, beta, offa, offb, llf, llb, costs, xlen, ylen, T, U, Up, 2);
-        else hipLaunchKernelGGL((lattice_kernel<float, 8, 2>), dim3(N * 2), dim3(lat_waves(Up, 2) * 64), 0, 0, cells, alpha, beta, offa, offb, llf, llb, costs, xlen, ylen, T, U, Up, 2);
+        if (W == 1) hipLaunchKernelGGL((lattice_kernel<float, 1, 1>), dim3(N * 2), dim3(64), 0, ls, cells, alpha, beta, offa, offb, llf, llb, costs, xlen, ylen, T, U, Up, 2);
+        else if (cols == 1) hipLaunchKernelGGL((lattice_kernel<float, 8, 1>), dim3(N * 2), dim3(Up), 0, ls, cells, alpha, beta, offa, offb, llf, llb, costs, xlen, ylen, T, U, Up, 2);
+        else if (lat_waves(Up, 2) <= 4) hipLaunchKernelGGL((lattice_kernel<float, 4, 2>), dim3(N * 2), dim3(lat_waves(Up, 2) * 64), 0, ls, cells, alpha, beta, offa, offb, llf, llb, costs, xlen, ylen, T, U, Up, 2);
+        else hipLaunchKernelGGL((lattice_kernel<float, 8, 2>), dim3(N * 2), dim3(lat_waves(Up, 2) * 64), 0, ls, cells, alpha, beta, offa, offb, llf, llb, costs, xlen, ylen, T, U, Up, 2);
     };
     for (int i = 0; i < 3; ++i) launch();
     CK(hipDeviceSynchronize());
-    CK(hipEventRecord(e0));
+    const bool contend = argc > 5 && atoi(argv[5]) != 0;
+    hipStream_t hog; CK(hipStreamCreateWithFlags(&hog, hipStreamNonBlocking));
+    u32x4 *hin = nullptr, *hout = nullptr;
+    const size_t hn = (1ull << 30) / 16;                         // 1 GiB read + 1 GiB written per launch (~0.33 ms)
     const int reps = 10;
+    if (contend) {
+        CK(hipMalloc(&hin, hn * 16)); CK(hipMalloc(&hout, hn * 16));
+        CK(hipMemset(hin, 1, hn * 16));
+        CK(hipDeviceSynchronize());
+        for (int i = 0; i < 40 * reps; ++i) hipLaunchKernelGGL(hog_copy, dim3(16384), dim3(256), 0, hog, hin, hout, hn);
+    }
+    CK(hipEventRecord(e0, ls));
     for (int i = 0; i < reps; ++i) launch();
-    CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+    CK(hipEventRecord(e1, ls)); CK(hipEventSynchronize(e1));
     float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= reps;
+    const bool still = contend && hipStreamQuery(hog) == hipErrorNotReady;   // the copy outlasted the measurement
+    CK(hipDeviceSynchronize());
+    if (contend) printf("[beside a streaming copy%s] ", still ? "" : " -- WARNING: the copy ended first");
     float c0; CK(hipMemcpy(&c0, costs, 4, hipMemcpyDeviceToHost));
     printf("cols=%d N=%d T=%d U=%d: %.1f us, %.1f ns/diagonal (cost[0]=%.3f)\n", (U > 64 ? (argc > 4 ? atoi(argv[4]) : 2) : 1), N, T, U, ms * 1e3, ms * 1e6 / (T + U - 2), c0);
     return 0;

@@ -641,6 +641,14 @@ __device__ __forceinline__ void lat_store1(__amdgpu_buffer_rsrc_t r, int voff, i
 __host__ __device__ inline int lat_waves(int Up, int cols) { return (Up + 64 * cols - 1) / (64 * cols); }
 __host__ __device__ inline int lat_col_shift(int cols) { return cols == 2 ? 7 : 6; }
 
+// Block barrier that orders LDS traffic only.  __syncthreads() also waits for every outstanding GLOBAL access of the
+// wavefront (s_waitcnt vmcnt(0)): here that would be the next chunk's prefetch and the acknowledgement of the last
+// chunk's stores, neither of which the other wavefronts of the block ever look at (they meet in the LDS ring only).
+__device__ __forceinline__ void lds_barrier() {
+    __builtin_amdgcn_s_waitcnt(0xc07f);                    // lgkmcnt(0); vmcnt and expcnt left alone
+    __builtin_amdgcn_s_barrier();
+}
+
 template <typename L, int MAXW, int COLS>
 __global__ __launch_bounds__(MAXW * 64) void lattice_kernel(
         const LogPair<L>* __restrict__ lp2, L* __restrict__ alpha, L* __restrict__ beta,
@@ -772,14 +780,14 @@ __global__ __launch_bounds__(MAXW * 64) void lattice_kernel(
                 if (j >= 0 && j < nchunks) {
                     if (j & 1) chunk(s, j, bufB_b, bufB_l, bufA_b, bufA_l); else chunk(s, j, bufA_b, bufA_l, bufB_b, bufB_l);
                 }
-                if constexpr (MULTI) __syncthreads();
+                if constexpr (MULTI) lds_barrier();
             }
             if (s + 1 < nslots) {
                 const int j = MULTI ? s + 1 - wave : s + 1;
                 if (j >= 0 && j < nchunks) {
                     if (j & 1) chunk(s + 1, j, bufB_b, bufB_l, bufA_b, bufA_l); else chunk(s + 1, j, bufA_b, bufA_l, bufB_b, bufB_l);
                 }
-                if constexpr (MULTI) __syncthreads();
+                if constexpr (MULTI) lds_barrier();
             }
         }
         if (jprev >= 0) flush();
@@ -874,14 +882,14 @@ __global__ __launch_bounds__(MAXW * 64) void lattice_kernel(
                 if (j >= 0 && j < nchunks) {
                     if (j & 1) chunk(s, j, bufB_b, bufB_l, bufA_b, bufA_l); else chunk(s, j, bufA_b, bufA_l, bufB_b, bufB_l);
                 }
-                if constexpr (MULTI) __syncthreads();
+                if constexpr (MULTI) lds_barrier();
             }
             if (s + 1 < nslots) {
                 const int j = MULTI ? s + 1 - (W - 1 - wave) : s + 1;
                 if (j >= 0 && j < nchunks) {
                     if (j & 1) chunk(s + 1, j, bufB_b, bufB_l, bufA_b, bufA_l); else chunk(s + 1, j, bufA_b, bufA_l, bufB_b, bufB_l);
                 }
-                if constexpr (MULTI) __syncthreads();
+                if constexpr (MULTI) lds_barrier();
             }
         }
         if (jprev >= 0) flush();

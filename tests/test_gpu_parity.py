@@ -282,6 +282,48 @@ def test_pageable_host_costs_through_the_staging_buffer():
     assert not errs, errs
 
 
+def test_concurrent_threads_on_their_own_streams():
+    """Four host threads call the synchronous entry at the same time, each on its own stream and its own shape: every
+    call returns exactly what the same call returns alone (no shared mutable state in the library besides the per-thread
+    staging buffer)."""
+    import threading
+    from warprnnt_pytorch import warp_rnnt
+    dev = torch.device("cuda:0")
+    shapes = [(5, 40, 9, 33), (3, 70, 70, 12), (8, 25, 5, 300), (2, 130, 20, 64)]
+    g = torch.Generator(device=dev).manual_seed(11)
+    cases = []
+    for n, t, u, a in shapes:
+        x = torch.randn((n, t, u, a), generator=g, device=dev)
+        lab = torch.randint(1, a, (n, u - 1), generator=g, device=dev, dtype=torch.int32)
+        tl = torch.randint(t // 2, t + 1, (n,), generator=g, device=dev, dtype=torch.int32)
+        ll = torch.randint((u - 1) // 2, u, (n,), generator=g, device=dev, dtype=torch.int32)
+        costs, grads = torch.zeros(n), torch.zeros_like(x)
+        assert warp_rnnt.gpu_rnnt(x, lab, tl, ll, costs, grads, 0, 0) == 0
+        cases.append((x, lab, tl, ll, costs.clone(), grads.clone()))
+    torch.cuda.synchronize()
+    errs = []
+    start = threading.Barrier(len(cases))
+
+    def worker(case):
+        try:
+            x, lab, tl, ll, want_c, want_g = case
+            torch.cuda.set_device(0)
+            with torch.cuda.stream(torch.cuda.Stream(dev)):
+                start.wait()
+                for _ in range(25):
+                    costs, grads = torch.zeros(x.shape[0]), torch.empty_like(x)
+                    assert warp_rnnt.gpu_rnnt(x, lab, tl, ll, costs, grads, 0, 0) == 0
+                    assert torch.equal(costs, want_c) and torch.equal(grads, want_g)
+        except Exception as e:                                         # noqa: BLE001 -- reported to the main thread
+            errs.append(repr(e))
+    threads = [threading.Thread(target=worker, args=(c,)) for c in cases]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errs, errs
+
+
 def test_determinism():
     acts, labels, tl, ll, blank = case_inputs("wide_u70")
     a = run_gpu(acts, labels, tl, ll, blank)

@@ -1,0 +1,29 @@
+import sys, time, os
+sys.path.insert(0, os.path.join(os.getcwd(), "warp-transducer_amd"))
+import torch
+from warprnnt_pytorch import _lib
+lib = _lib.lib()
+dev = torch.device("cuda:0")
+N, T, U, A = 16, 150, 41, 28
+x = torch.rand((N, T, U, A), device=dev)
+lab = torch.randint(1, A, (N, U - 1), device=dev, dtype=torch.int32)
+tl = torch.full((N,), T, dtype=torch.int32, device=dev); ll = torch.full((N,), U - 1, dtype=torch.int32, device=dev)
+g = torch.empty_like(x); costs = torch.zeros(N)
+ws = torch.empty(_lib.workspace_bytes(T, U, N, True, 4), dtype=torch.uint8, device=dev)
+opt = _lib.rnntOptions(loc=_lib.RNNT_GPU, num_threads=0, stream=torch.cuda.current_stream().cuda_stream, blank_label=0, maxT=T, maxU=U, batch_first=True)
+torch.cuda.synchronize()
+if len(sys.argv) > 1:      # a 1x1x1 problem first: what it costs is the code-object load (+ the staging buffer), not the problem
+    x1 = torch.rand((1, 1, 1, A), device=dev); g1 = torch.empty_like(x1); c1 = torch.zeros(1)
+    one = torch.ones(1, dtype=torch.int32, device=dev); zero = torch.zeros(1, dtype=torch.int32, device=dev)
+    o1 = _lib.rnntOptions(loc=_lib.RNNT_GPU, num_threads=0, stream=torch.cuda.current_stream().cuda_stream, blank_label=0, maxT=1, maxU=1, batch_first=True)
+    w1 = torch.empty(_lib.workspace_bytes(1, 1, 1, True, 4), dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    st = lib.compute_rnnt_loss(x1.data_ptr(), g1.data_ptr(), zero.data_ptr(), zero.data_ptr(), one.data_ptr(), A, 1, c1.data_ptr(), w1.data_ptr(), o1)
+    print("call on a 1x1x1 problem: %.3f ms (status %d)" % ((time.perf_counter() - t0) * 1e3, st))
+    t0 = time.perf_counter(); p = torch.empty(1024, pin_memory=True); print("call torch pinned alloc: %.3f ms" % ((time.perf_counter() - t0) * 1e3))
+for i in range(4):
+    t0 = time.perf_counter()
+    st = lib.compute_rnnt_loss(x.data_ptr(), g.data_ptr(), lab.data_ptr(), ll.data_ptr(), tl.data_ptr(), A, N, costs.data_ptr(), ws.data_ptr(), opt)
+    t1 = time.perf_counter()
+    print("call %d: %.3f ms (status %d)" % (i, (t1 - t0) * 1e3, st))

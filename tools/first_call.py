@@ -1,5 +1,7 @@
+"""Cold start: what the first GPU call of a process costs (python tools/first_call.py [x]; with an argument a 1x1x1
+problem goes first, so the code-object load is separated from the c2-sized call behind it)."""
 import sys, time, os
-sys.path.insert(0, os.path.join(os.getcwd(), "warp-transducer_amd"))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "warp-transducer_amd"))
 import torch
 from warprnnt_pytorch import _lib
 lib = _lib.lib()

@@ -1,0 +1,272 @@
+// rnnt_host.h -- what the two host translation units of the library share: workspace layout, stage timers, tuning
+// constants, the launch plan, and the launchers of the two stages both paths run (lattice, coefficients).
+//   rnnt_gpu.hip    the materialised path (row statistics ... gradient stream) and the C entry points of rnnt.h
+//   rnnt_joint.hip  the additive-joint path and its entry points (compute_rnnt_loss_add*)
+// Two translation units = two code objects: HIP loads a code object on the first launch of one of its kernels, and the
+// additive-joint kernels are 45 % of the library's device code -- a caller of compute_rnnt_loss does not pay for loading
+// them (first call of a process: tools/first_call.py).  Everything here is static / template code, compiled into both.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+#include "../../include/rnnt.h"
+#include "rnnt_kernels.h"
+
+namespace rnnt {
+
+// ----------------------------------------------------------------------------- workspace
+constexpr size_t kAlign = 256;
+static inline size_t align_up(size_t x) { return (x + kAlign - 1) / kAlign * kAlign; }
+
+struct Layout {
+    size_t lp2, logz, alpha, rowtab, beta, offa, offb, llf, llb, costs, rowmax, side, side_bytes, wmat, total;
+};
+
+// lat = bytes of one lattice value (4: fp32 lattice for 16/32-bit activations, 8: fp64).
+// joint: also the additive-joint planes (get_workspace_size_add); they sit BEHIND everything the
+// materialised path uses, so a plan carved with joint = true is valid for both.
+static Layout make_layout(int maxT, int maxU, int N, size_t lat, bool joint) {
+    const size_t D = lat_rows(maxT, maxU);      // diagonals + padding rows
+    const size_t Up = (static_cast<size_t>(maxU) + 63) / 64 * 64;   // one 64-lane row per wavefront
+    const size_t W = Up / 64;
+    const size_t sk = D * Up * N;               // skewed lattice cells
+    Layout l{};
+    size_t o = 0;
+    l.lp2 = o;   o = align_up(o + sk * 2 * lat);
+    l.logz = o;  o = align_up(o + sk * lat);
+    l.alpha = o; o = align_up(o + sk * lat);
+    l.rowtab = o; o = align_up(o + static_cast<size_t>(maxT) * maxU * N * 4 * lat);
+    l.beta = o;  o = align_up(o + (sk + Up + 64) * lat);
+    l.offa = o;  o = align_up(o + D * W * N * sizeof(double));
+    l.offb = o;  o = align_up(o + (D * W * N + D) * sizeof(double));
+    l.llf = o;   o = align_up(o + N * sizeof(double));
+    l.llb = o;   o = align_up(o + N * sizeof(double));
+    l.costs = o; o = align_up(o + N * sizeof(double));
+    // additive joint only: row maxima of f and g, dense matrices W, CB, CL (row stride = maxU rounded up to 8)
+    l.rowmax = o; l.wmat = o; l.side = o; l.side_bytes = 0;
+    if (joint) {
+        o = align_up(o + ((static_cast<size_t>(maxT) + maxU) * N + 1) * sizeof(float));   // + the +inf sentinel
+        // correction sums for the GEMM epilogues: sfb[N*maxT] | sgb[N*maxU] | sgl[N*maxU] floats | far flags[N] ints
+        l.side = o;
+        l.side_bytes = ((static_cast<size_t>(maxT) + 2 * static_cast<size_t>(maxU)) * N + N) * sizeof(float);
+        o = align_up(o + l.side_bytes);
+        l.wmat = o;   o = align_up(o + 3 * static_cast<size_t>(maxT) * joint_upad(maxU) * N * sizeof(float));   // W | CB | CL
+    }
+    l.total = o + kAlign;                       // slack to align the caller's base pointer
+    return l;
+}
+
+// ----------------------------------------------------------------------------- profiling
+// Stage boundaries as HIP events on the caller's stream: 0 start, 1 after the statistics, 2 after the lattice, 3 after
+// the coefficients (end of a forward phase), 4 start and 5 end of the gradient stage.  A one-call entry records all six;
+// the two-phase entries record 0-3 (compute_rnnt_loss_fwd) and 4-5 (compute_rnnt_loss_bwd), and whatever the caller
+// enqueues between the two calls is in neither stage.  One rnnt_profile_collect() reads what has been recorded since
+// the last one as ONE step.
+struct Profile {
+    bool on = false;
+    bool ready = false;
+    hipEvent_t ev[6];
+    double ms[5] = {0, 0, 0, 0, 0};   // statistics, lattice, coefficients, gradient, first event to last
+    int calls = 0;
+    bool pending = false;   // events of an asynchronous call recorded, not yet read
+    bool has_fwd = false, has_bwd = false;
+};
+extern Profile g_prof;     // one instance for the library (defined in rnnt_gpu.hip)
+
+static bool prof_prepare() {
+    if (!g_prof.on) return false;
+    if (!g_prof.ready) {
+        for (auto& e : g_prof.ev)
+            if (hipEventCreate(&e) != hipSuccess) return false;
+        g_prof.ready = true;
+    }
+    return true;
+}
+
+// mark(i) of the run_* functions: i = 0..4 are the boundaries of the four stages of one call
+static void prof_mark(int i, bool do_fwd, bool do_bwd, hipStream_t stream) {
+    if (i < 3) { if (do_fwd) (void)hipEventRecord(g_prof.ev[i], stream); return; }
+    if (i == 3) {
+        if (do_fwd) { (void)hipEventRecord(g_prof.ev[3], stream); g_prof.has_fwd = true; }
+        if (do_bwd) (void)hipEventRecord(g_prof.ev[4], stream);
+        return;
+    }
+    if (do_bwd) { (void)hipEventRecord(g_prof.ev[5], stream); g_prof.has_bwd = true; }
+}
+
+static inline void prof_accumulate() {
+    float ms = 0.f;
+    if (g_prof.has_fwd)
+        for (int i = 0; i < 3; ++i)
+            if (hipEventElapsedTime(&ms, g_prof.ev[i], g_prof.ev[i + 1]) == hipSuccess) g_prof.ms[i] += ms;
+    if (g_prof.has_bwd && hipEventElapsedTime(&ms, g_prof.ev[4], g_prof.ev[5]) == hipSuccess) g_prof.ms[3] += ms;
+    if ((g_prof.has_fwd || g_prof.has_bwd) &&
+        hipEventElapsedTime(&ms, g_prof.ev[g_prof.has_fwd ? 0 : 4], g_prof.ev[g_prof.has_bwd ? 5 : 3]) == hipSuccess)
+        g_prof.ms[4] += ms;
+    g_prof.calls++;
+    g_prof.pending = g_prof.has_fwd = g_prof.has_bwd = false;
+}
+
+// ----------------------------------------------------------------------------- tuning knobs
+// The measured-best launch parameters.  A release build has exactly these constants; a development
+// build (make dev: -DRNNT_DEV, lib/dev/libwarprnnt.so) can override them for A/B runs with
+// RNNT_TUNE="key=value,key=value".  sw = waves per block of the row-stats kernel (2|4|8),
+// nta = non-temporal stats loads, gmax = grid cap of the flat gradient kernel, rows = 1 forces
+// the row-form gradient kernel, tile / tilekb = LDS-tile stats kernel on/off and its LDS budget,
+// ppt = packets per thread of the flat gradient kernel.  Additive joint: jfnk / jgnk = columns
+// per lane of the DF / DG kernels (0: widest the alignment allows), jfpf / jgpf = operand ping-pong;
+// blk = block-per-row statistics kernel for rows >= 12 KB on/off, jzs = vocabulary split of the Z kernel (1|4|8),
+// xcd = XCD-aware tile order of the short-row statistics kernel on/off, ctile = tiled coefficient kernel on/off,
+// pskip = the gradient kernel's skip-padded-rows form for rows >= 8 KB on/off, joh = one-hot df corrections in the
+// additive-joint DF kernel (-1: vocabularies <= 256), lat2 = two lattice columns per lane (-1: maxU > 256).
+struct Tune { int sw = 4, nta = 1, gmax = 4194304, rows = 0, tile = 1, tilekb = 52, ppt = 2;
+              int jfnk = 0, jfpf = 1, jgnk = 0, jgpf = 1, blk = 1, jzs = 0, xcd = 1, ctile = 1, pskip = 1, joh = -1;
+              int lat2 = -1, xst = 0; };
+#ifdef RNNT_DEV
+static Tune read_tune() {
+    Tune t;
+    const char* e = getenv("RNNT_TUNE");
+    if (e == nullptr) return t;
+    const struct { const char* key; int* dst; } keys[] = {
+        {"sw", &t.sw}, {"nta", &t.nta}, {"gmax", &t.gmax}, {"rows", &t.rows}, {"tile", &t.tile},
+        {"tilekb", &t.tilekb}, {"ppt", &t.ppt}, {"jfnk", &t.jfnk}, {"jfpf", &t.jfpf}, {"jgnk", &t.jgnk},
+        {"jgpf", &t.jgpf}, {"blk", &t.blk}, {"jzs", &t.jzs}, {"xcd", &t.xcd}, {"ctile", &t.ctile},
+        {"pskip", &t.pskip}, {"joh", &t.joh}, {"lat2", &t.lat2}, {"xst", &t.xst}};
+    // tokens are separated by ',', a token is key=value with the WHOLE key compared
+    for (const char* p = e; *p;) {
+        const char* end = strchr(p, ',');
+        const size_t len = end ? static_cast<size_t>(end - p) : strlen(p);
+        const char* eq = static_cast<const char*>(memchr(p, '=', len));
+        if (eq != nullptr)
+            for (const auto& k : keys)
+                if (strlen(k.key) == static_cast<size_t>(eq - p) && strncmp(k.key, p, eq - p) == 0) *k.dst = atoi(eq + 1);
+        p += len + (end ? 1 : 0);
+    }
+    return t;
+}
+static const Tune& tune() {
+    static const Tune t = read_tune();     // function-local static: initialised once, thread-safe
+    return t;
+}
+#else
+static const Tune& tune() {
+    static const Tune t;
+    return t;
+}
+#endif
+
+// ----------------------------------------------------------------------------- launch
+// Everything one call needs: problem dimensions, the carved workspace, the stream.
+template <typename C> struct Plan {
+    int N, maxT, maxU, Up, A, blank;
+    int cells_per_sample;          // maxT * maxU
+    hipStream_t stream;
+    const int *labels, *input_lengths, *label_lengths;
+    LogPair<C>* lp2; C *logz, *alpha, *beta; Cell<C>* rowtab;
+    double *offa, *offb, *llf, *llb;
+    float *rowmax, *wmat, *side;
+    size_t side_bytes = 0;
+    int lat_cols = 1;              // lattice columns per lane (1 | 2), its wavefronts per block ...
+    int lat_w = 1, lat_sh = 6;     // ... and the column -> wavefront shift (coefficient kernels)
+    float fastemit = 0.0f;         // FastEmit lambda (extension entries only)
+    const long long* offsets = nullptr;        // packed layout: cumulative row offsets (device, N+1 entries) ...
+    unsigned long long packed_rows = 0;        // ... and the total number of rows (host)
+    C* costs_dev;
+    bool failed = false;
+    void check() { if (hipGetLastError() != hipSuccess) failed = true; }
+};
+
+template <typename C>
+static bool make_plan(Plan<C>& p, int A, int N, const rnntOptions& opt, void* workspace, const int* labels,
+                      const int* label_lengths, const int* input_lengths, C* costs_device_out, bool joint = false) {
+    (void)hipGetLastError();                       // a stale error of an unrelated earlier HIP call is not ours
+    p.N = N; p.maxT = opt.maxT; p.maxU = opt.maxU; p.A = A; p.blank = opt.blank_label;
+    if (p.blank < 0 || p.blank >= A) return false;
+    if (p.maxU > 1024) return false;               // one lane per label position (as the reference)
+    if (static_cast<long long>(p.maxT) * p.maxU > 0x7fffffffLL / 4) return false;
+    if (N > 65535) return false;
+    p.Up = ((p.maxU + 63) / 64) * 64;
+    // one sample's skewed lp2 array is addressed through a buffer descriptor with a 32-bit size
+    if (lat_rows(p.maxT, p.maxU) * p.Up * sizeof(LogPair<C>) >= (1ull << 31)) return false;
+    // lattice kernel form: one wavefront for maxU <= 64; one column per lane while every wavefront of the block
+    // has a SIMD to itself (maxU <= 256), two columns per lane beyond (measured, ns per diagonal at T = 1500,
+    // one / two columns: U=128 79 / 97, U=192 93 / 111, U=256 120 / 117, U=301 148 / 139, U=512 205 / 188)
+    const int lat2 = tune().lat2 >= 0 ? tune().lat2 : (p.Up > 256 ? 1 : 0);
+    p.lat_cols = p.Up == 64 ? 1 : ((p.Up > 512 || lat2) ? 2 : 1);
+    p.lat_w = lat_waves(p.Up, p.lat_cols);
+    p.lat_sh = lat_col_shift(p.lat_cols);
+    p.cells_per_sample = p.maxT * p.maxU;
+    p.stream = reinterpret_cast<hipStream_t>(opt.stream);
+    p.labels = labels; p.input_lengths = input_lengths; p.label_lengths = label_lengths;
+    const Layout lay = make_layout(p.maxT, p.maxU, N, sizeof(C), joint);
+    char* ws = reinterpret_cast<char*>(align_up(reinterpret_cast<size_t>(workspace)));
+    p.lp2 = reinterpret_cast<LogPair<C>*>(ws + lay.lp2);
+    p.logz = reinterpret_cast<C*>(ws + lay.logz);
+    p.alpha = reinterpret_cast<C*>(ws + lay.alpha);
+    p.rowtab = reinterpret_cast<Cell<C>*>(ws + lay.rowtab);
+    p.beta = reinterpret_cast<C*>(ws + lay.beta);
+    p.offa = reinterpret_cast<double*>(ws + lay.offa);
+    p.offb = reinterpret_cast<double*>(ws + lay.offb);
+    p.llf = reinterpret_cast<double*>(ws + lay.llf);
+    p.llb = reinterpret_cast<double*>(ws + lay.llb);
+    p.rowmax = reinterpret_cast<float*>(ws + lay.rowmax);
+    p.wmat = reinterpret_cast<float*>(ws + lay.wmat);
+    p.side = reinterpret_cast<float*>(ws + lay.side);
+    p.side_bytes = lay.side_bytes;
+    p.costs_dev = costs_device_out ? costs_device_out : reinterpret_cast<C*>(ws + lay.costs);
+    return true;
+}
+
+// Stage 2: alpha (and, for gradients, beta) recursion; writes the costs.
+template <typename C> static void launch_lattice(Plan<C>& p, bool with_beta) {
+    const int dirs = with_beta ? 2 : 1;
+#define RNNT_LATTICE(MW, CC)                                                                                     \
+    hipLaunchKernelGGL((lattice_kernel<C, MW, CC>), dim3(p.N * dirs), dim3(p.lat_w * 64), 0, p.stream, p.lp2,          \
+                       p.alpha, p.beta, p.offa, p.offb, p.llf, p.llb, p.costs_dev, p.input_lengths, p.label_lengths,  \
+                       p.maxT, p.maxU, p.Up, dirs)
+    if (p.Up == 64) RNNT_LATTICE(1, 1);                            // one wavefront, no synchronisation
+    else if (p.lat_cols == 1) RNNT_LATTICE(8, 1);                  // maxU <= 512, one column per lane
+    else if (p.lat_w <= 4) RNNT_LATTICE(4, 2);                     // two columns per lane, one wavefront per SIMD
+    else RNNT_LATTICE(8, 2);                                       // maxU <= 1024 in at most 8 wavefronts
+#undef RNNT_LATTICE
+    p.check();
+}
+
+// Stage 3: gradient coefficients per row into the natural-order row table.
+template <typename C> static void launch_coef(Plan<C>& p, bool joint = false, bool onehot = false) {
+    float* wmat = joint ? p.wmat : nullptr;
+    const int Upad = joint_upad(p.maxU);
+    // additive joint: W and CL planes always (the DF kernel takes its label corrections from CL); small
+    // vocabularies add CB and replace the records by a plane of c
+    const int planes = onehot ? joint_planes_onehot(p.maxU) : (joint ? 2 : 1);
+    if (p.maxU <= 48 || !tune().ctile) {
+        // small lattices: one thread per skewed cell, scattered record store
+        const long long skew_cells = static_cast<long long>(p.maxT + p.maxU - 1) * p.Up;
+        const dim3 cgrid(static_cast<unsigned>(((skew_cells + 255) / 256 + 7) / 8 * 8), p.N);   // multiple of 8: XCD-aware remap
+        hipLaunchKernelGGL((coef_cell_kernel<C>), cgrid, dim3(256), 0, p.stream, p.lp2, p.logz, p.alpha, p.beta, p.offa,
+                           p.offb, p.llf, p.labels, p.input_lengths, p.label_lengths, p.rowtab, p.maxT, p.maxU, p.Up,
+                           wmat, Upad, p.fastemit, planes, p.offsets, p.lat_w, p.lat_sh);
+    } else {
+        const int DN = sizeof(C) == 4 ? 32 : 16;           // diagonals per tile (coef_kernel)
+        const int tilesU = (p.maxU + 63) / 64, tilesN = (p.maxT + p.maxU - 1 + DN - 1) / DN;
+        const dim3 cgrid(static_cast<unsigned>(tilesU * tilesN), p.N);
+        hipLaunchKernelGGL((coef_kernel<C>), cgrid, dim3(256), 0, p.stream, p.lp2, p.logz, p.alpha, p.beta, p.offa,
+                           p.offb, p.llf, p.labels, p.input_lengths, p.label_lengths, p.rowtab, p.maxT, p.maxU, p.Up,
+                           wmat, Upad, tilesU, p.fastemit, planes, p.offsets, p.lat_w, p.lat_sh);
+    }
+    p.check();
+}
+
+static bool bad_args(const void* acts, const int* labels, const int* label_lengths,
+                     const int* input_lengths, const void* costs, const void* workspace, int A, int N,
+                     const rnntOptions& o) {
+    // reference src/rnnt_entrypoint.cpp:49-59
+    return acts == nullptr || labels == nullptr || label_lengths == nullptr || input_lengths == nullptr ||
+           costs == nullptr || workspace == nullptr || A <= 0 || N <= 0 || o.maxT <= 0 || o.maxU <= 0;
+}
+
+}  // namespace rnnt

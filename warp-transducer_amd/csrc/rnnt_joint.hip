@@ -1,0 +1,251 @@
+// rnnt_joint.hip -- host driver and C entry points of the additive-joint ("add network") path, SURVEY.md 8f rank 1
+// (kernels: rnnt_joint_kernels.h; lattice and coefficient stages: the launchers of rnnt_host.h).  Its own translation
+// unit, hence its own code object: see rnnt_host.h.
+#include "rnnt_host.h"
+#include "rnnt_joint_kernels.h"
+
+namespace rnnt {
+
+// ----------------------------------------------------------------------------- additive joint
+// f (N,maxT,A) + g (N,maxU,A) -> costs, df, dg without the (N,T,U,A) tensor (rnnt_joint_kernels.h):
+// the two streaming stages are replaced, lattice and coefficients are the same launches as above.
+// Enqueue only: device costs, no host copy, no synchronisation.  Storage of f, g, df, dg by tag (fp32 / bf16 / fp16),
+// arithmetic fp32.
+// phases: 1 = forward (row maxima, Z, lattice, and with want_grad the coefficient table + W),
+// 2 = backward (DF, DG, corrections from the workspace a forward call left), 3 = both.
+template <typename Tag>
+static rnntStatus_t run_gpu_joint(const typename Tag::store* f, const typename Tag::store* g, typename Tag::store* df,
+                                  typename Tag::store* dg, const int* labels,
+                                  const int* label_lengths, const int* input_lengths, int A, int N,
+                                  float* costs_device, const float* grad_scale, void* workspace,
+                                  const rnntOptions& opt, int phases, bool want_grad, float fastemit = 0.0f) {
+    using S = typename Tag::store;
+    Plan<float> p;
+    if (!make_plan(p, A, N, opt, workspace, labels, label_lengths, input_lengths, costs_device, /*joint=*/true))
+        return RNNT_STATUS_INVALID_VALUE;
+    if (!(fastemit >= 0.0f)) return RNNT_STATUS_INVALID_VALUE;
+    p.fastemit = fastemit;
+    const bool do_fwd = (phases & 1) != 0, do_bwd = (phases & 2) != 0;
+    if (do_bwd && (df == nullptr || dg == nullptr)) return RNNT_STATUS_INVALID_VALUE;
+    // the gradient GEMMs address one sample's rows with 32-bit element offsets
+    if (static_cast<long long>(p.maxT > p.maxU ? p.maxT : p.maxU) * A >= (1LL << 31) ||
+        static_cast<long long>(N) * (p.maxT + p.maxU) >= (1LL << 31))
+        return RNNT_STATUS_INVALID_VALUE;
+    const bool training = want_grad;
+    const bool prof = prof_prepare();
+    auto mark = [&](int i) { if (prof) prof_mark(i, do_fwd, do_bwd, p.stream); };
+
+    const int maxT = p.maxT, maxU = p.maxU;
+    // rows made of whole 16-byte packets (row-maximum kernel) and 4-element loads aligned (Z kernel)
+    const bool vec = (A % static_cast<int>(16 / sizeof(S)) == 0) &&
+                     ((reinterpret_cast<uintptr_t>(f) | reinterpret_cast<uintptr_t>(g)) & 15u) == 0;
+    const int tilesT = (maxT + 31) / 32, tilesU = (maxU + 31) / 32, tiles = tilesT * tilesU;
+    mark(0);
+    if (do_fwd) {   // row maxima, then the partition-function GEMM with the log-prob epilogue
+        const long long rows = static_cast<long long>(N) * (maxT + maxU);
+        const bool per_block = static_cast<size_t>(A) * sizeof(S) >= 12288;       // long rows: a block per row
+        const dim3 rgrid(static_cast<unsigned>(per_block ? rows : (rows + 3) / 4));
+#define RNNT_JMAX(VV, WW)                                                                                      \
+    hipLaunchKernelGGL((joint_rowmax_kernel<Tag, VV, WW>), rgrid, dim3(256), 0, p.stream, f, g, input_lengths,       \
+                       label_lengths, p.rowmax, maxT, maxU, A, N, training ? p.side : nullptr,                  \
+                       static_cast<unsigned>(p.side_bytes / sizeof(float)))
+        if (per_block) { if (vec) RNNT_JMAX(true, 4); else RNNT_JMAX(false, 4); }
+        else { if (vec) RNNT_JMAX(true, 1); else RNNT_JMAX(false, 1); }
+#undef RNNT_JMAX
+        p.check();
+        // vocabulary slices per tile: few tiles and a long contraction -> split it over 4 or 8 wavefronts
+        const long long all_tiles = static_cast<long long>(N) * tiles;
+        const int nchunk = (A + 31) / 32;
+        int S = (all_tiles >= 4096 || nchunk < 16) ? 1 : ((all_tiles < 1024 && nchunk >= 32) ? 8 : 4);
+        if (tune().jzs == 1 || tune().jzs == 4 || tune().jzs == 8) S = tune().jzs;
+#define RNNT_JZ(SS, VV)                                                                                          \
+    hipLaunchKernelGGL((joint_z_kernel<Tag, SS, VV>), dim3(SS == 1 ? ((tiles + 3) / 4 + 7) / 8 * 8 : tiles, N),                      \
+                       dim3(SS == 1 ? 256 : SS * 64), 0, p.stream, f, g, p.rowmax, labels, input_lengths,        \
+                       label_lengths, p.lp2, p.logz, maxT, maxU, p.Up, A, p.blank, tilesU, tiles, N)
+        if (S == 1 && A <= kJointZSmallA && tune().jzs != 1)
+            hipLaunchKernelGGL((joint_z_small_kernel<Tag>), dim3(((tiles + 3) / 4 + 7) / 8 * 8, N), dim3(256),
+                               4 * kJointZSmallSlice * sizeof(float), p.stream, f, g, p.rowmax, labels,
+                               input_lengths, label_lengths, p.lp2, p.logz, maxT, maxU, p.Up, A, p.blank, tilesU,
+                               tiles, N);
+        else if (S == 8) { if (vec) RNNT_JZ(8, true); else RNNT_JZ(8, false); }
+        else if (S == 4) { if (vec) RNNT_JZ(4, true); else RNNT_JZ(4, false); }
+        else { if (vec) RNNT_JZ(1, true); else RNNT_JZ(1, false); }
+#undef RNNT_JZ
+        p.check();
+    }
+    mark(1);
+    if (do_fwd) launch_lattice(p, training);
+    mark(2);
+    // small vocabularies: the df corrections ride along in the DF GEMM as one-hot operands (3x its
+    // contraction) instead of one global atomic per lattice cell in the fix-up kernel
+    // (fp32 storage only: with 16-bit storage the one-hot DF kernel needs 228 + 128 registers and runs at a third of
+    // the speed -- c4 shape 0.81 vs 0.51 ms for the backward phase -- so 16-bit keeps the epilogue corrections)
+    const bool onehot = tune().joh >= 0 ? tune().joh != 0 : (A <= 256 && sizeof(S) == 4);
+    // correction sums (fp32 side vectors in the workspace) for the epilogues of the gradient GEMMs
+    float* sfb = p.side;
+    float* sgb = sfb + static_cast<size_t>(N) * maxT;
+    float* sgl = sgb + static_cast<size_t>(N) * maxU;
+    int* farflag = reinterpret_cast<int*>(sgl + static_cast<size_t>(N) * maxU);
+    const float* cplanes = onehot && joint_planes_onehot(maxU) == 4 ? p.wmat : nullptr;   // c / cb / cl as dense planes
+    const dim3 fixgrid((maxU + 63) / 64, (maxT + kJointFixT - 1) / kJointFixT, N);
+    if (do_fwd && training) {
+        launch_coef(p, /*joint=*/true, onehot);
+        hipLaunchKernelGGL(joint_sums_kernel, fixgrid, dim3(256), 0, p.stream, p.rowtab, input_lengths, label_lengths, sfb,
+                           sgb, sgl, farflag, maxT, maxU, N, cplanes, joint_upad(maxU));
+        p.check();
+    }
+    mark(3);
+    if (do_bwd) {
+        // gradient GEMMs with the corrections in their epilogues (plain stores of every element, padding
+        // included), then the far cells (rare).
+        // NK adjacent columns per lane = the widest vector the vocabulary size and alignment allow.
+        const int Upad = joint_upad(maxU);
+        const uintptr_t all4 = reinterpret_cast<uintptr_t>(f) | reinterpret_cast<uintptr_t>(g) |
+                               reinterpret_cast<uintptr_t>(df) | reinterpret_cast<uintptr_t>(dg);
+        const int NKmax = (A % 4 == 0 && (all4 & (4 * sizeof(S) - 1)) == 0 && A >= 96) ? 4
+                        : (A % 2 == 0 && (all4 & (2 * sizeof(S) - 1)) == 0 && A >= 48) ? 2 : 1;
+        const Tune& tn = tune();
+        auto pick = [&](int want) { int nk = want > 0 ? want : NKmax; while (nk > NKmax) nk >>= 1; return nk; };
+        const int NKf = pick(tn.jfnk), NKg = pick(tn.jgnk);
+#define RNNT_JDF(NN, PP, OO)                                                                                     \
+    hipLaunchKernelGGL((joint_df_kernel<Tag, NN, PP, OO>), dim3((A + 128 * NN - 1) / (128 * NN), tilesT, N), dim3(256), 0, \
+                       p.stream, f, g, p.rowmax, p.wmat, grad_scale, labels, input_lengths, label_lengths, df, maxT,  \
+                       maxU, Upad, A, N, p.blank, sfb)
+#define RNNT_JDG(NN, PP)                                                                                         \
+    hipLaunchKernelGGL((joint_dg_kernel<Tag, NN, PP>), dim3((A + 128 * NN - 1) / (128 * NN), tilesU, N), dim3(256), 0, \
+                       p.stream, f, g, p.rowmax, p.wmat, grad_scale, input_lengths, label_lengths, dg, maxT,     \
+                       maxU, Upad, A, N, labels, p.blank, sgb, sgl)
+        // 16-bit storage: the operand ping-pong doubles the AGPR count of these kernels (172 + 128 registers: one wavefront
+        // per SIMD at four columns per lane); without it they keep two (DF) / three (DG) wavefronts per SIMD
+        const bool pf_f = tn.jfpf != 0 && (sizeof(S) == 4 || NKf < 4), pf_g = tn.jgpf != 0 && (sizeof(S) == 4 || NKg < 4);
+        if (onehot)       { if (NKf == 4) RNNT_JDF(4, true, true); else if (NKf == 2) RNNT_JDF(2, true, true); else RNNT_JDF(1, true, true); }
+        else if (pf_f) { if (NKf == 4) RNNT_JDF(4, true, false); else if (NKf == 2) RNNT_JDF(2, true, false); else RNNT_JDF(1, true, false); }
+        else              { if (NKf == 4) RNNT_JDF(4, false, false); else if (NKf == 2) RNNT_JDF(2, false, false); else RNNT_JDF(1, false, false); }
+        if (pf_g) { if (NKg == 4) RNNT_JDG(4, true); else if (NKg == 2) RNNT_JDG(2, true); else RNNT_JDG(1, true); }
+        else         { if (NKg == 4) RNNT_JDG(4, false); else if (NKg == 2) RNNT_JDG(2, false); else RNNT_JDG(1, false); }
+#undef RNNT_JDF
+#undef RNNT_JDG
+        p.check();
+        hipLaunchKernelGGL((joint_far_kernel<Tag>), fixgrid, dim3(256), 0, p.stream, f, g, p.rowmax, p.rowtab, grad_scale,
+                           input_lengths, label_lengths, farflag, df, dg, maxT, maxU, A, N, cplanes, Upad);
+        p.check();
+    }
+    mark(4);
+    if (prof) g_prof.pending = true;
+    return p.failed ? RNNT_STATUS_EXECUTION_FAILED : RNNT_STATUS_SUCCESS;
+}
+
+}  // namespace rnnt
+
+using namespace rnnt;
+
+#pragma GCC visibility push(default)
+extern "C" {
+
+rnntStatus_t compute_rnnt_loss_add(const float* const trans_acts, const float* const pred_acts,
+                                   float* trans_grads, float* pred_grads, const int* const flat_labels,
+                                   const int* const label_lengths, const int* const input_lengths,
+                                   int alphabet_size, int minibatch, float* costs_device, void* workspace,
+                                   rnntOptions options) {
+    if (bad_args(trans_acts, flat_labels, label_lengths, input_lengths, costs_device, workspace, alphabet_size,
+                 minibatch, options) || pred_acts == nullptr || options.loc != RNNT_GPU)
+        return RNNT_STATUS_INVALID_VALUE;
+    if ((trans_grads == nullptr) != (pred_grads == nullptr)) return RNNT_STATUS_INVALID_VALUE;
+    const bool training = trans_grads != nullptr;
+    return run_gpu_joint<F32>(trans_acts, pred_acts, trans_grads, pred_grads, flat_labels, label_lengths,
+                         input_lengths, alphabet_size, minibatch, costs_device, nullptr, workspace, options,
+                         training ? 3 : 1, training);
+}
+
+rnntStatus_t compute_rnnt_loss_add_fwd(const float* const trans_acts, const float* const pred_acts,
+                                       const int* const flat_labels, const int* const label_lengths,
+                                       const int* const input_lengths, int alphabet_size, int minibatch,
+                                       float* costs_device, void* workspace, rnntOptions options,
+                                       int prepare_backward) {
+    if (bad_args(trans_acts, flat_labels, label_lengths, input_lengths, costs_device, workspace, alphabet_size,
+                 minibatch, options) || pred_acts == nullptr || options.loc != RNNT_GPU)
+        return RNNT_STATUS_INVALID_VALUE;
+    return run_gpu_joint<F32>(trans_acts, pred_acts, nullptr, nullptr, flat_labels, label_lengths, input_lengths,
+                         alphabet_size, minibatch, costs_device, nullptr, workspace, options, 1,
+                         prepare_backward != 0);
+}
+
+rnntStatus_t compute_rnnt_loss_add_fwd_fastemit(const float* const trans_acts, const float* const pred_acts,
+                                                const int* const flat_labels, const int* const label_lengths,
+                                                const int* const input_lengths, int alphabet_size, int minibatch,
+                                                float* costs_device, void* workspace, rnntOptions options,
+                                                int prepare_backward, float fastemit_lambda) {
+    if (bad_args(trans_acts, flat_labels, label_lengths, input_lengths, costs_device, workspace, alphabet_size,
+                 minibatch, options) || pred_acts == nullptr || options.loc != RNNT_GPU)
+        return RNNT_STATUS_INVALID_VALUE;
+    return run_gpu_joint<F32>(trans_acts, pred_acts, nullptr, nullptr, flat_labels, label_lengths, input_lengths,
+                         alphabet_size, minibatch, costs_device, nullptr, workspace, options, 1,
+                         prepare_backward != 0, fastemit_lambda);
+}
+
+rnntStatus_t compute_rnnt_loss_add_bwd(const float* const trans_acts, const float* const pred_acts,
+                                       float* trans_grads, float* pred_grads, const float* grad_scale_device,
+                                       const int* const flat_labels, const int* const label_lengths,
+                                       const int* const input_lengths, int alphabet_size, int minibatch,
+                                       void* workspace, rnntOptions options) {
+    if (trans_acts == nullptr || pred_acts == nullptr || trans_grads == nullptr || pred_grads == nullptr ||
+        flat_labels == nullptr || label_lengths == nullptr || input_lengths == nullptr || workspace == nullptr ||
+        alphabet_size <= 0 || minibatch <= 0 || options.maxT <= 0 || options.maxU <= 0 || options.loc != RNNT_GPU)
+        return RNNT_STATUS_INVALID_VALUE;
+    return run_gpu_joint<F32>(trans_acts, pred_acts, trans_grads, pred_grads, flat_labels, label_lengths,
+                         input_lengths, alphabet_size, minibatch, nullptr, grad_scale_device, workspace, options, 2,
+                         true);
+}
+
+// Additive joint with the activations' storage type as an argument (0 fp32, 2 bf16, 3 fp16; fp64 is not offered).
+rnntStatus_t compute_rnnt_loss_add_fwd_dt(const void* trans_acts, const void* pred_acts, const int* const flat_labels,
+                                          const int* const label_lengths, const int* const input_lengths,
+                                          int alphabet_size, int minibatch, float* costs_device, void* workspace,
+                                          rnntOptions options, int dtype_code, int prepare_backward,
+                                          float fastemit_lambda) {
+    if (bad_args(trans_acts, flat_labels, label_lengths, input_lengths, costs_device, workspace, alphabet_size,
+                 minibatch, options) || pred_acts == nullptr || options.loc != RNNT_GPU)
+        return RNNT_STATUS_INVALID_VALUE;
+    const bool pb = prepare_backward != 0;
+    switch (dtype_code) {
+        case 0: return run_gpu_joint<F32>(static_cast<const float*>(trans_acts), static_cast<const float*>(pred_acts), nullptr,
+                                          nullptr, flat_labels, label_lengths, input_lengths, alphabet_size, minibatch,
+                                          costs_device, nullptr, workspace, options, 1, pb, fastemit_lambda);
+        case 2: return run_gpu_joint<BF16>(static_cast<const uint16_t*>(trans_acts), static_cast<const uint16_t*>(pred_acts),
+                                           nullptr, nullptr, flat_labels, label_lengths, input_lengths, alphabet_size, minibatch,
+                                           costs_device, nullptr, workspace, options, 1, pb, fastemit_lambda);
+        case 3: return run_gpu_joint<F16>(static_cast<const uint16_t*>(trans_acts), static_cast<const uint16_t*>(pred_acts),
+                                          nullptr, nullptr, flat_labels, label_lengths, input_lengths, alphabet_size, minibatch,
+                                          costs_device, nullptr, workspace, options, 1, pb, fastemit_lambda);
+        default: return RNNT_STATUS_INVALID_VALUE;
+    }
+}
+
+rnntStatus_t compute_rnnt_loss_add_bwd_dt(const void* trans_acts, const void* pred_acts, void* trans_grads,
+                                          void* pred_grads, const float* grad_scale_device,
+                                          const int* const flat_labels, const int* const label_lengths,
+                                          const int* const input_lengths, int alphabet_size, int minibatch,
+                                          void* workspace, rnntOptions options, int dtype_code) {
+    if (trans_acts == nullptr || pred_acts == nullptr || trans_grads == nullptr || pred_grads == nullptr ||
+        flat_labels == nullptr || label_lengths == nullptr || input_lengths == nullptr || workspace == nullptr ||
+        alphabet_size <= 0 || minibatch <= 0 || options.maxT <= 0 || options.maxU <= 0 || options.loc != RNNT_GPU)
+        return RNNT_STATUS_INVALID_VALUE;
+    switch (dtype_code) {
+        case 0: return run_gpu_joint<F32>(static_cast<const float*>(trans_acts), static_cast<const float*>(pred_acts),
+                                          static_cast<float*>(trans_grads), static_cast<float*>(pred_grads), flat_labels,
+                                          label_lengths, input_lengths, alphabet_size, minibatch, nullptr, grad_scale_device,
+                                          workspace, options, 2, true);
+        case 2: return run_gpu_joint<BF16>(static_cast<const uint16_t*>(trans_acts), static_cast<const uint16_t*>(pred_acts),
+                                           static_cast<uint16_t*>(trans_grads), static_cast<uint16_t*>(pred_grads), flat_labels,
+                                           label_lengths, input_lengths, alphabet_size, minibatch, nullptr, grad_scale_device,
+                                           workspace, options, 2, true);
+        case 3: return run_gpu_joint<F16>(static_cast<const uint16_t*>(trans_acts), static_cast<const uint16_t*>(pred_acts),
+                                          static_cast<uint16_t*>(trans_grads), static_cast<uint16_t*>(pred_grads), flat_labels,
+                                          label_lengths, input_lengths, alphabet_size, minibatch, nullptr, grad_scale_device,
+                                          workspace, options, 2, true);
+        default: return RNNT_STATUS_INVALID_VALUE;
+    }
+}
+
+}  // extern "C"
+#pragma GCC visibility pop

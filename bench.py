@@ -167,6 +167,8 @@ def main():
     ap.add_argument("--pinned-costs", action="store_true",
                     help="host costs in pinned memory: the lattice kernel writes them directly, no staged D2H copy "
                          "(the default, pageable costs, is what the reference's callers pass)")
+    ap.add_argument("--graph", action="store_true",
+                    help="one GPU: compute_rnnt_loss_async captured into a HIP graph once, step = replay + device sync")
     ap.add_argument("--overlap-collective", action="store_true",
                     help="sharded step through the two-phase entry with the all-reduce BESIDE the gradient pass (A/B runs)")
     ap.add_argument("--force-sharded", action="store_true",
@@ -255,6 +257,30 @@ def main():
                 assert st == 0, _lib.status_string(st)
                 torch.cuda.synchronize(dev)
                 lib.rnnt_profile_collect()
+                return costs
+        elif args.graph and not sharded:
+            # the asynchronous entry (device costs) captured ONCE into a HIP graph; a step = one replay + one device sync.
+            # For launch-bound problems (c2: four kernels of a few microseconds) the replay replaces four host launches.
+            costs = torch.zeros(N, dtype=torch.float32, device=dev)
+            code = {"fp32": _lib.DT_F32, "bf16": _lib.DT_BF16}[w["dtype"]]
+            cap = torch.cuda.Stream(dev)
+            cap.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(cap):
+                gopt = _lib.rnntOptions(loc=_lib.RNNT_GPU, num_threads=0, stream=cap.cuda_stream, blank_label=0, maxT=T,
+                                        maxU=U, batch_first=True)
+                gargv = (acts.data_ptr(), grads.data_ptr(), labels.data_ptr(), label_lens.data_ptr(), act_lens.data_ptr(),
+                         A, N, costs.data_ptr(), None, ws.data_ptr(), gopt, code)
+                assert lib.compute_rnnt_loss_async(*gargv) == 0            # warm-up outside the capture
+                cap.synchronize()
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph, stream=cap):
+                    st = lib.compute_rnnt_loss_async(*gargv)
+                assert st == 0, _lib.status_string(st)
+            torch.cuda.current_stream(dev).wait_stream(cap)
+
+            def step():
+                graph.replay()
+                torch.cuda.synchronize(dev)
                 return costs
         elif not sharded:
             # the drop-in C-ABI call: host costs, one stream sync per call
@@ -378,7 +404,8 @@ def main():
                                % (args.workload, w["N"], w["T"], U, w["L"], w["A"], w["dtype"],
                                   (", VARIABLE lengths T_b~U[T/2,T] L_b~U[L/2,L]" if args.varlen else "")
                                   + (", PACKED layout (compute_rnnt_loss_packed)" if args.packed else "")
-                                  + (", host costs in pinned memory" if args.pinned_costs else "")),
+                                  + (", host costs in pinned memory" if args.pinned_costs else "")
+                                  + (", compute_rnnt_loss_async replayed from a HIP graph" if args.graph else "")),
                    "global_batch": w["N"] * world, "per_gpu_batch": w["N"],
                    "parallelism": "batch-sharded x%d, one RCCL all-reduce of the summed loss" % world
                    if sharded else "single GPU"},

@@ -116,6 +116,36 @@ def test_large_logit_range_is_safe(oracle, shape):
     assert np.allclose(dg, ref_gz.sum(axis=1), rtol=1e-3, atol=5e-4)
 
 
+@pytest.mark.parametrize("A", [200, 600, 1200])            # vocabulary handled by 1 / 4 / 8 wavefronts per tile
+@pytest.mark.parametrize("bump", [20.0, 70.0, "masked"])
+def test_sampled_row_references_and_their_guard(oracle, A, bump):
+    """Vocabularies of 64 symbols and more: the Z kernel takes the maximum of a row's FIRST 32 columns as the exponent
+    reference instead of a row-maximum pass (rnnt_joint_kernels.h, SAMPLED).  bump = 20: some rows peak 20 nats above
+    that sample, inside the guard (40 in base 2 = 27.7 nats) -- the sampled reference is used as it is; 70: beyond the
+    guard -- the exact pass behind it takes over; "masked": the first 32 columns are -inf, so there is no finite
+    sample at all.  Every case against the fp64 oracle on the materialised joint."""
+    N, T, U = 3, 37, 9
+    f, g, labels, tl, ll, blank = problem((N, T, U, A), 5 + A)
+    blank = 40 + blank % (A - 40)                          # keep blank and labels out of the masked columns
+    labels = (40 + labels % (A - 40)).astype(np.int32)
+    labels[labels == blank] = 40 + (blank - 39) % (A - 40)
+    if bump == "masked":
+        f[..., :32] = -np.inf
+        g[..., :32] = -np.inf
+    else:
+        f[0, ::3, 32 + (A // 3)] += bump                   # some rows of some samples, far from the sampled columns
+        f[2, 5, A - 1] += bump
+        g[1, 2::2, 32 + (A // 2)] += 1.5 * bump
+    z = f[:, :, None, :].astype(np.float64) + g[:, None, :, :].astype(np.float64)
+    ref_c, ref_gz = oracle.rnnt_logits(z, labels, tl, ll, blank)
+    costs, df, dg = run_add(f, g, labels, tl, ll, blank)
+    assert np.isfinite(costs).all() and np.abs(costs - ref_c).max() <= 2e-4 * max(1.0, np.abs(ref_c).max())
+    rdf, rdg = ref_gz.sum(axis=2), ref_gz.sum(axis=1)
+    assert np.isfinite(df).all() and np.isfinite(dg).all()
+    assert np.allclose(df, rdf, rtol=1e-3, atol=5e-4)
+    assert np.allclose(dg, rdg, rtol=1e-3, atol=5e-4 * max(1.0, T / 32))
+
+
 def test_per_sample_grad_output_is_folded_in(oracle):
     """reduction='none' with a non-uniform grad_output: the two-phase backward multiplies sample b's
     gradients by grad_output[b] inside the gradient kernels."""

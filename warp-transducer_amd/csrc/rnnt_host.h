@@ -49,7 +49,7 @@ static Layout make_layout(int maxT, int maxU, int N, size_t lat, bool joint) {
     // additive joint only: row maxima of f and g, dense matrices W, CB, CL (row stride = maxU rounded up to 8)
     l.rowmax = o; l.wmat = o; l.side = o; l.side_bytes = 0;
     if (joint) {
-        o = align_up(o + ((static_cast<size_t>(maxT) + maxU) * N + 1) * sizeof(float));   // + the +inf sentinel
+        o = align_up(o + ((static_cast<size_t>(maxT) + maxU) * N + 2) * sizeof(float));   // + the +inf sentinel + the gate word
         // correction sums for the GEMM epilogues: sfb[N*maxT] | sgb[N*maxU] | sgl[N*maxU] floats | far flags[N] ints
         l.side = o;
         l.side_bytes = ((static_cast<size_t>(maxT) + 2 * static_cast<size_t>(maxU)) * N + N) * sizeof(float);
@@ -122,10 +122,11 @@ static inline void prof_accumulate() {
 // blk = block-per-row statistics kernel for rows >= 12 KB on/off, jzs = vocabulary split of the Z kernel (1|4|8),
 // xcd = XCD-aware tile order of the short-row statistics kernel on/off, ctile = tiled coefficient kernel on/off,
 // pskip = the gradient kernel's skip-padded-rows form for rows >= 8 KB on/off, joh = one-hot df corrections in the
-// additive-joint DF kernel (-1: vocabularies <= 256), lat2 = two lattice columns per lane (-1: maxU > 256).
+// additive-joint DF kernel (-1: vocabularies <= 256), lat2 = two lattice columns per lane (-1: maxU > 256),
+// jsamp = additive joint: sampled row references + guard instead of the row-maximum pass (rnnt_joint_kernels.h) on/off.
 struct Tune { int sw = 4, nta = 1, gmax = 4194304, rows = 0, tile = 1, tilekb = 52, ppt = 2;
               int jfnk = 0, jfpf = 1, jgnk = 0, jgpf = 1, blk = 1, jzs = 0, xcd = 1, ctile = 1, pskip = 1, joh = -1;
-              int lat2 = -1, xst = 0; };
+              int lat2 = -1, xst = 0, jsamp = 1; };
 #ifdef RNNT_DEV
 static Tune read_tune() {
     Tune t;
@@ -135,7 +136,7 @@ static Tune read_tune() {
         {"sw", &t.sw}, {"nta", &t.nta}, {"gmax", &t.gmax}, {"rows", &t.rows}, {"tile", &t.tile},
         {"tilekb", &t.tilekb}, {"ppt", &t.ppt}, {"jfnk", &t.jfnk}, {"jfpf", &t.jfpf}, {"jgnk", &t.jgnk},
         {"jgpf", &t.jgpf}, {"blk", &t.blk}, {"jzs", &t.jzs}, {"xcd", &t.xcd}, {"ctile", &t.ctile},
-        {"pskip", &t.pskip}, {"joh", &t.joh}, {"lat2", &t.lat2}, {"xst", &t.xst}};
+        {"pskip", &t.pskip}, {"joh", &t.joh}, {"lat2", &t.lat2}, {"xst", &t.xst}, {"jsamp", &t.jsamp}};
     // tokens are separated by ',', a token is key=value with the WHOLE key compared
     for (const char* p = e; *p;) {
         const char* end = strchr(p, ',');

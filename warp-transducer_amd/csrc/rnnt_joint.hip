@@ -1,6 +1,8 @@
 // rnnt_joint.hip -- host driver and C entry points of the additive-joint ("add network") path, SURVEY.md 8f rank 1
 // (kernels: rnnt_joint_kernels.h; lattice and coefficient stages: the launchers of rnnt_host.h).  Its own translation
 // unit, hence its own code object: see rnnt_host.h.
+#include <atomic>
+
 #include "rnnt_host.h"
 #include "rnnt_joint_kernels.h"
 
@@ -45,32 +47,61 @@ static rnntStatus_t run_gpu_joint(const typename Tag::store* f, const typename T
         const long long rows = static_cast<long long>(N) * (maxT + maxU);
         const bool per_block = static_cast<size_t>(A) * sizeof(S) >= 12288;       // long rows: a block per row
         const dim3 rgrid(static_cast<unsigned>(per_block ? rows : (rows + 3) / 4));
-#define RNNT_JMAX(VV, WW)                                                                                      \
-    hipLaunchKernelGGL((joint_rowmax_kernel<Tag, VV, WW>), rgrid, dim3(256), 0, p.stream, f, g, input_lengths,       \
-                       label_lengths, p.rowmax, maxT, maxU, A, N, training ? p.side : nullptr,                  \
-                       static_cast<unsigned>(p.side_bytes / sizeof(float)))
-        if (per_block) { if (vec) RNNT_JMAX(true, 4); else RNNT_JMAX(false, 4); }
-        else { if (vec) RNNT_JMAX(true, 1); else RNNT_JMAX(false, 1); }
-#undef RNNT_JMAX
-        p.check();
         // vocabulary slices per tile: few tiles and a long contraction -> split it over 4 or 8 wavefronts
         const long long all_tiles = static_cast<long long>(N) * tiles;
         const int nchunk = (A + 31) / 32;
         int S = (all_tiles >= 4096 || nchunk < 16) ? 1 : ((all_tiles < 1024 && nchunk >= 32) ? 8 : 4);
         if (tune().jzs == 1 || tune().jzs == 4 || tune().jzs == 8) S = tune().jzs;
-#define RNNT_JZ(SS, VV)                                                                                          \
-    hipLaunchKernelGGL((joint_z_kernel<Tag, SS, VV>), dim3(SS == 1 ? ((tiles + 3) / 4 + 7) / 8 * 8 : tiles, N),                      \
+        const bool small = S == 1 && A <= kJointZSmallA && tune().jzs != 1;
+        // sampled row references + guard (rnnt_joint_kernels.h): no row-maximum pass in front of the Z kernel; the exact
+        // pair runs behind it only when a row tripped the guard
+        const bool sampled = !small && A >= 64 && tune().jsamp != 0;
+        int* const gate = reinterpret_cast<int*>(p.rowmax + rows + 1);
+        static std::atomic<int> call_counter{1};
+        const int seq = call_counter.fetch_add(1, std::memory_order_relaxed);
+        float* side0 = training ? p.side : nullptr;
+        const unsigned nside = static_cast<unsigned>(p.side_bytes / sizeof(float));
+#define RNNT_JMAX(VV, WW, SIDE, GATE)                                                                           \
+    hipLaunchKernelGGL((joint_rowmax_kernel<Tag, VV, WW>), rgrid, dim3(256), 0, p.stream, f, g, input_lengths,       \
+                       label_lengths, p.rowmax, maxT, maxU, A, N, SIDE, nside, GATE, seq)
+#define RNNT_JMAX_ALL(SIDE, GATE)                                                                               \
+        do {                                                                                                    \
+            if (per_block) { if (vec) RNNT_JMAX(true, 4, SIDE, GATE); else RNNT_JMAX(false, 4, SIDE, GATE); }   \
+            else { if (vec) RNNT_JMAX(true, 1, SIDE, GATE); else RNNT_JMAX(false, 1, SIDE, GATE); }             \
+        } while (0)
+#define RNNT_JZ(SS, VV, SAMP, GATE)                                                                              \
+    hipLaunchKernelGGL((joint_z_kernel<Tag, SS, VV, SAMP>), dim3(SS == 1 ? ((tiles + 3) / 4 + 7) / 8 * 8 : tiles, N),               \
                        dim3(SS == 1 ? 256 : SS * 64), 0, p.stream, f, g, p.rowmax, labels, input_lengths,        \
-                       label_lengths, p.lp2, p.logz, maxT, maxU, p.Up, A, p.blank, tilesU, tiles, N)
-        if (S == 1 && A <= kJointZSmallA && tune().jzs != 1)
-            hipLaunchKernelGGL((joint_z_small_kernel<Tag>), dim3(((tiles + 3) / 4 + 7) / 8 * 8, N), dim3(256),
-                               4 * kJointZSmallSlice * sizeof(float), p.stream, f, g, p.rowmax, labels,
-                               input_lengths, label_lengths, p.lp2, p.logz, maxT, maxU, p.Up, A, p.blank, tilesU,
-                               tiles, N);
-        else if (S == 8) { if (vec) RNNT_JZ(8, true); else RNNT_JZ(8, false); }
-        else if (S == 4) { if (vec) RNNT_JZ(4, true); else RNNT_JZ(4, false); }
-        else { if (vec) RNNT_JZ(1, true); else RNNT_JZ(1, false); }
+                       label_lengths, p.lp2, p.logz, maxT, maxU, p.Up, A, p.blank, tilesU, tiles, N, GATE, seq)
+#define RNNT_JZ_ALL(SAMP, GATE)                                                                                  \
+        do {                                                                                                    \
+            if (S == 8) { if (vec) RNNT_JZ(8, true, SAMP, GATE); else RNNT_JZ(8, false, SAMP, GATE); }          \
+            else if (S == 4) { if (vec) RNNT_JZ(4, true, SAMP, GATE); else RNNT_JZ(4, false, SAMP, GATE); }     \
+            else { if (vec) RNNT_JZ(1, true, SAMP, GATE); else RNNT_JZ(1, false, SAMP, GATE); }                 \
+        } while (0)
+        if (sampled) {
+            const unsigned pgrid = (nside + 255) / 256 > 0 ? (nside + 255) / 256 : 1;
+            hipLaunchKernelGGL(joint_prep_kernel, dim3(pgrid), dim3(256), 0, p.stream, p.rowmax, side0, nside, gate, seq,
+                               static_cast<unsigned>(rows));
+            RNNT_JZ_ALL(true, gate);
+            RNNT_JMAX_ALL(static_cast<float*>(nullptr), gate);           // the exact pair: returns at once unless the gate is raised
+            RNNT_JZ_ALL(false, gate);
+        } else {
+            int* const no_gate = nullptr;                                // the row-maximum pass always runs
+            RNNT_JMAX_ALL(side0, no_gate);
+            p.check();
+            if (small)
+                hipLaunchKernelGGL((joint_z_small_kernel<Tag>), dim3(((tiles + 3) / 4 + 7) / 8 * 8, N), dim3(256),
+                                   4 * kJointZSmallSlice * sizeof(float), p.stream, f, g, p.rowmax, labels,
+                                   input_lengths, label_lengths, p.lp2, p.logz, maxT, maxU, p.Up, A, p.blank, tilesU,
+                                   tiles, N);
+            else
+                RNNT_JZ_ALL(false, no_gate);
+        }
+#undef RNNT_JMAX
+#undef RNNT_JMAX_ALL
 #undef RNNT_JZ
+#undef RNNT_JZ_ALL
         p.check();
     }
     mark(1);

@@ -64,8 +64,10 @@ template <typename Tag, bool VEC, int WPR>
 __global__ __launch_bounds__(256) void joint_rowmax_kernel(
         const typename Tag::store* __restrict__ f, const typename Tag::store* __restrict__ g, const int* __restrict__ xlen,
         const int* __restrict__ ylen, float* __restrict__ rowmax, int maxT, int maxU, int A, int N,
-        float* __restrict__ side, unsigned nside) {
+        float* __restrict__ side, unsigned nside, const int* __restrict__ gate, int seq) {
     __shared__ float red[4];
+    // second, exact pass of the sampled-reference forward (joint_z_kernel, SAMPLED): only if a row tripped the guard
+    if (gate != nullptr && *gate != seq) return;
     // the correction sums of joint_sums_kernel (N*(maxT + 2 maxU) floats + N flags) start at zero: the grid has at
     // least 64 threads per row of f and g, more than that many words
     {
@@ -194,18 +196,44 @@ __device__ __forceinline__ float4 joint_load4(const typename Tag::store* __restr
 // fragments through LDS at the end; with S = 1 the four wavefronts of a block own four tiles.
 // Epilogue per cell: log Z -> logz (relative), blank / label log2-probs -> lp2, both in the skewed
 // lattice layout.  grid = (tiles or ceil(tiles/4), N), block = 64 * max(S, 4).
+// Sampled reference values (SAMPLED): the row-maximum pass is a full read of f and g (c3 shape: 438 MB, 66 us of a 0.6 ms
+// step) whose only purpose is a safe exponent reference per row.  Any reference R with max - R <= kJointGuard (base 2)
+// is as good: exp2((x - R) log2 e) <= 2^40, products of two <= 2^80, a sum over <= 2^23 symbols < 2^127; smaller elements
+// underflow no earlier than with the exact maximum.  So the Z kernel takes R = the maximum of the row's FIRST 32 columns
+// (every tile and every wavefront that needs row t derives the same value from the same 128 bytes), tracks the true
+// maximum of what it streams anyway, and raises a gate word when some row exceeds its reference by more than the guard
+// (or has no finite reference at all).  The exact pair -- joint_rowmax_kernel, then joint_z_kernel without SAMPLED -- is
+// enqueued behind it in every call and returns at once unless the gate is raised: ordinary logits never raise it,
+// arbitrary finite (and -inf-masked) logits are still handled exactly.  The gate holds the call's sequence number
+// when raised and is reset by joint_prep_kernel, which also takes over the row-maximum kernel's housekeeping (zeroed
+// correction sums, the +inf sentinel).
+constexpr float kJointGuard = 40.0f;
+__global__ __launch_bounds__(256) void joint_prep_kernel(float* __restrict__ rowmax, float* __restrict__ side, unsigned nside,
+                                                         int* __restrict__ gate, int seq, unsigned sentinel) {
+    const unsigned gid = blockIdx.x * 256u + threadIdx.x;
+    if (side != nullptr && gid < nside) side[gid] = 0.0f;
+    if (gid == 0) {
+        rowmax[sentinel] = -neg_inf<float>();
+        *gate = ~seq;
+    }
+}
+
 constexpr int kJointZPad = 36;                              // LDS row stride in floats (conflict-free b128)
 constexpr int kJointZSlice = 2 * 32 * kJointZPad;           // floats per wavefront: ef piece + eg piece
 
-template <typename Tag, int S, bool VEC>
+template <typename Tag, int S, bool VEC, bool SAMPLED = false>
 __global__ __launch_bounds__(S == 1 ? 256 : S * 64) void joint_z_kernel(
-        const typename Tag::store* __restrict__ f, const typename Tag::store* __restrict__ g, const float* __restrict__ rowmax,
+        const typename Tag::store* __restrict__ f, const typename Tag::store* __restrict__ g, float* rowmax,
         const int* __restrict__ labels, const int* __restrict__ xlen, const int* __restrict__ ylen,
         LogPair<float>* __restrict__ lp2, float* __restrict__ logz, int maxT, int maxU, int Up, int A,
-        int blank, int tilesU, int tiles, int N) {
+        int blank, int tilesU, int tiles, int N, int* gate, int seq) {
     constexpr int WAVES = S == 1 ? 4 : S;
     __shared__ float4 stage4[WAVES * kJointZSlice / 4];
+    __shared__ float refs[SAMPLED ? (S == 1 ? WAVES : 1) : 1][64];   // SAMPLED: the tile's 32 + 32 reference values (x log2 e)
+    (void)refs;
     float* stage = reinterpret_cast<float*>(stage4);
+    if constexpr (!SAMPLED)                                // the exact pass behind a sampled one: only when the gate is raised
+        if (gate != nullptr && *gate != seq) return;
     const int b = blockIdx.y;
     const int lane = threadIdx.x & 63, wave = uniform(threadIdx.x >> 6), half = lane >> 5, col = lane & 31;
     // S == 1 (many tiles): XCD-aware order -- workgroup i runs on XCD i % 8, so every XCD is given one
@@ -234,9 +262,55 @@ __global__ __launch_bounds__(S == 1 ? 256 : S * 64) void joint_z_kernel(
         const int u = u0 + r < Ub ? u0 + r : Ub - 1;
         frow[i] = f + (static_cast<size_t>(b) * maxT + t) * A;
         grow4[i] = g + (static_cast<size_t>(b) * maxU + u) * A;
-        mfr[i] = mf[t];
-        mgr[i] = mg[u];
+        if constexpr (!SAMPLED) {
+            mfr[i] = mf[t];
+            mgr[i] = mg[u];
+        }
     }
+    float tf[4], tg[4];                                    // SAMPLED: the true maxima of what this lane streams
+    if constexpr (SAMPLED) {
+        // reference of a row = maximum of its first 32 columns (eight lanes hold four each), clamped to a finite value;
+        // S > 1: the wavefronts of the block share one tile -- the first one reads the 32 columns, the others take the
+        // values from LDS (one block barrier)
+        constexpr int RW = S == 1 ? WAVES : 1;             // copies of the reference table
+        const int rw = S == 1 ? wave : 0;
+        if (S == 1 || wave == 0) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float4 a = joint_load4<Tag, VEC>(frow[i], lcol, A), c = joint_load4<Tag, VEC>(grow4[i], lcol, A);
+                float ma = fmaxf(fmaxf(a.x, a.y), fmaxf(a.z, a.w)), mc = fmaxf(fmaxf(c.x, c.y), fmaxf(c.z, c.w));
+#pragma unroll
+                for (int d = 1; d < 8; d <<= 1) {
+                    ma = fmaxf(ma, __shfl_xor(ma, d));
+                    mc = fmaxf(mc, __shfl_xor(mc, d));
+                }
+                ma = fmaxf(ma, kJointMinMax) * static_cast<float>(kLog2e);
+                mc = fmaxf(mc, kJointMinMax) * static_cast<float>(kLog2e);
+                if ((lane & 7) == 0) {                     // one copy per row: for the block, and the arrays for the later kernels
+                    refs[rw % RW][lrow + 8 * i] = ma;
+                    refs[rw % RW][32 + lrow + 8 * i] = mc;
+                    const int t = t0 + lrow + 8 * i, u = u0 + lrow + 8 * i;
+                    if (u0 == 0 && t < Tb) rowmax[static_cast<size_t>(b) * maxT + t] = ma;
+                    if (t0 == 0 && u < Ub) rowmax[static_cast<size_t>(N) * maxT + static_cast<size_t>(b) * maxU + u] = mc;
+                }
+            }
+        }
+        if constexpr (S == 1) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        } else {
+            __syncthreads();
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            mfr[i] = refs[rw % RW][lrow + 8 * i];
+            mgr[i] = refs[rw % RW][32 + lrow + 8 * i];
+            tf[i] = neg_inf<float>();
+            tg[i] = neg_inf<float>();
+        }
+    }
+    (void)tf; (void)tg;
     float* fs = stage + wave * kJointZSlice;               // [32][kJointZPad]
     float* gs = fs + 32 * kJointZPad;
 
@@ -251,7 +325,17 @@ __global__ __launch_bounds__(S == 1 ? 256 : S * 64) void joint_z_kernel(
             gv[i] = joint_load4<Tag, VEC>(grow4[i], cc * 32 + lcol, A);
         }
     };
+    auto track = [&](const float4 (&fv)[4], const float4 (&gv)[4]) {     // (columns past the end repeat valid ones)
+        if constexpr (SAMPLED) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                tf[i] = fmaxf(fmaxf(tf[i], fmaxf(fv[i].x, fv[i].y)), fmaxf(fv[i].z, fv[i].w));
+                tg[i] = fmaxf(fmaxf(tg[i], fmaxf(gv[i].x, gv[i].y)), fmaxf(gv[i].z, gv[i].w));
+            }
+        }
+    };
     auto compute = [&](const float4 (&fv)[4], const float4 (&gv)[4], int cc) {
+        track(fv, gv);
         // columns past the end were read elsewhere: cancel them through the maximum (VEC: the whole packet)
         const int k = cc * 32 + lcol;
         const float pinf = -neg_inf<float>();
@@ -303,6 +387,26 @@ __global__ __launch_bounds__(S == 1 ? 256 : S * 64) void joint_z_kernel(
         if (c < nchunk) compute(f0, g0, c);
     }
 
+    if constexpr (SAMPLED) {
+        // the guard: true maximum of every row this wavefront streamed against its reference
+        bool trip = false;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float a = tf[i], c = tg[i];
+#pragma unroll
+            for (int d = 1; d < 8; d <<= 1) {
+                a = fmaxf(a, __shfl_xor(a, d));
+                c = fmaxf(c, __shfl_xor(c, d));
+            }
+            trip |= !(a * static_cast<float>(kLog2e) - mfr[i] <= kJointGuard) || !(c * static_cast<float>(kLog2e) - mgr[i] <= kJointGuard);
+        }
+        if (__ballot(trip) != 0 && lane == 0) *gate = seq;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");     // refs[wave][..] written above, read below
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    auto ref_f = [&](int row, int t) -> float { if constexpr (SAMPLED) { (void)t; return refs[S == 1 ? wave : 0][row]; } else { (void)row; return mf[t]; } };
+    auto ref_g = [&](int colx, int uu) -> float { if constexpr (SAMPLED) { (void)uu; return refs[S == 1 ? wave : 0][32 + colx]; } else { (void)colx; return mg[uu]; } };
     // per-lane constants of the epilogue: this lane's label row u = u0 + col
     const int u = u0 + col;
     const int ui = u < Ub ? u : Ub - 1;
@@ -313,7 +417,7 @@ __global__ __launch_bounds__(S == 1 ? 256 : S * 64) void joint_z_kernel(
         lab = lab < 0 ? 0 : (lab >= A ? A - 1 : lab);
     }
     const ST* gu = g + (static_cast<size_t>(b) * maxU + ui) * A;
-    const float mgu = mg[ui];
+    const float mgu = ref_g(col, ui);
     const float l2e = static_cast<float>(kLog2e), ln2 = static_cast<float>(kLn2);
     const float gbl = __builtin_fmaf(load1<Tag>(gu + blank), l2e, -mgu), glab = __builtin_fmaf(load1<Tag>(gu + lab), l2e, -mgu);   // base 2
 
@@ -331,7 +435,7 @@ __global__ __launch_bounds__(S == 1 ? 256 : S * 64) void joint_z_kernel(
         const ST* ft = f + (static_cast<size_t>(b) * maxT + tc) * A;
         fbl[i] = load1<Tag>(ft + blank);
         flb[i] = load1<Tag>(ft + lab);
-        mtv[i] = mf[tc];
+        mtv[i] = ref_f(mfma_row(rbase + i, lane), tc);
     }
 
     auto finish = [&](int i, float z) {                    // i-th register of this wavefront's share
@@ -354,7 +458,7 @@ __global__ __launch_bounds__(S == 1 ? 256 : S * 64) void joint_z_kernel(
             float s = 0.0f;
             for (int k = lane; k < A; k += 64) s += fast_exp(load1<Tag>(fr + k) + load1<Tag>(gr + k) - m);
             s = wave_sum(s);
-            const float v = (m - (mf[tt] + mg[uu]) * ln2) + acc_log(s);
+            const float v = (m - (ref_f(mfma_row(r, src), tt) + ref_g(src & 31, uu)) * ln2) + acc_log(s);
             if (lane == src) lz = v;
         }
         if (!valid) return;

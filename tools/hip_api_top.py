@@ -1,3 +1,6 @@
+"""Longest HIP API calls of a rocprofv3 --hip-trace run (rocpd database): python tools/hip_api_top.py <file.db>.
+Used with tools/first_call.py to see what the first GPU call of a process spends its milliseconds on (the lazy
+code-object load inside the first hipLaunchKernel)."""
 import sqlite3,sys
 c=sqlite3.connect(sys.argv[1])
 cols=[r[1] for r in c.execute("pragma table_info(regions)")]

@@ -116,7 +116,7 @@ def test_large_logit_range_is_safe(oracle, shape):
     assert np.allclose(dg, ref_gz.sum(axis=1), rtol=1e-3, atol=5e-4)
 
 
-@pytest.mark.parametrize("A", [200, 600, 1200])            # vocabulary handled by 1 / 4 / 8 wavefronts per tile
+@pytest.mark.parametrize("A", [200, 203, 600, 1200])       # 1 / 1 (unaligned rows: scalar loads) / 4 / 8 wavefronts per tile
 @pytest.mark.parametrize("bump", [20.0, 70.0, "masked"])
 def test_sampled_row_references_and_their_guard(oracle, A, bump):
     """Vocabularies of 64 symbols and more: the Z kernel takes the maximum of a row's FIRST 32 columns as the exponent

@@ -1,0 +1,36 @@
+#!/usr/bin/env python
+"""RNNTLoss through autograd (the reference's pytorch_binding/test/test_time.py role): forward + backward of the module on the
+BASELINE shapes, wall clock per step with one device sync per step, beside the C-ABI call of bench.py.
+Usage: python tools/autograd_bench.py [c2 c3 c5]"""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "warp-transducer_amd"))
+import numpy as np
+import torch
+from warprnnt_pytorch import RNNTLoss
+
+SHAPES = {"c2": (16, 150, 41, 28, torch.float32), "c3": (128, 150, 21, 5000, torch.float32),
+          "c5": (128, 200, 41, 1024, torch.bfloat16)}
+dev = torch.device("cuda:0")
+for name in sys.argv[1:] or ["c2", "c3", "c5"]:
+    N, T, U, A, dt = SHAPES[name]
+    x = torch.rand((N, T, U, A), device=dev).to(dt).requires_grad_(True)
+    lab = torch.randint(1, A, (N, U - 1), device=dev, dtype=torch.int32)
+    tl = torch.full((N,), T, dtype=torch.int32, device=dev)
+    ll = torch.full((N,), U - 1, dtype=torch.int32, device=dev)
+    crit = RNNTLoss(reduction="mean")
+    def step():
+        x.grad = None
+        loss = crit(x, lab, tl, ll)
+        loss.backward()
+        torch.cuda.synchronize()
+    for _ in range(10):
+        step()
+    ts = []
+    for _ in range(100 if name == "c2" else 30):
+        t0 = time.perf_counter(); step(); ts.append((time.perf_counter() - t0) * 1e3)
+    print("%s N=%d T=%d U=%d A=%d %s: RNNTLoss forward + backward median %.4f ms (p10 %.4f, p90 %.4f)"
+          % (name, N, T, U, A, str(dt).replace("torch.", ""), np.median(ts), np.percentile(ts, 10), np.percentile(ts, 90)))

@@ -24,7 +24,7 @@ def check_dim(var, dim, name):
 
 def certify_inputs(log_probs, labels, lengths, label_lengths):
     """(N,T,U,V) activations, (N,U-1) int32 labels, (N,) int32 lengths: dtype, contiguity, one length per sample,
-    ranks, and T == max(lengths), U == max(label_lengths) + 1 (one device-to-host read each)."""
+    ranks, and T == max(lengths), U == max(label_lengths) + 1 (one device-to-host read for both)."""
     arg = {"log_probs": log_probs, "labels": labels, "lengths": lengths, "label_lengths": label_lengths}
     for name in ("labels", "label_lengths", "lengths"):
         check_type(arg[name], torch.int32, name)
@@ -38,7 +38,13 @@ def certify_inputs(log_probs, labels, lengths, label_lengths):
     for name, rank, shown in (("log_probs", 4, "log_probs"), ("labels", 2, "labels"),
                               ("lengths", 1, "lenghts"), ("label_lengths", 1, "label_lenghts")):
         check_dim(arg[name], rank, shown)
-    if log_probs.shape[1] != int(lengths.max()):
+    # the reference reads the two maxima back one after the other (two device synchronisations per forward when
+    # the lengths live on the GPU); one read of both keeps its checks and their order at half the stalls
+    if lengths.device == label_lengths.device:
+        max_t, max_l = torch.stack((lengths.max(), label_lengths.max())).tolist()
+    else:
+        max_t, max_l = int(lengths.max()), int(label_lengths.max())
+    if log_probs.shape[1] != max_t:
         raise ValueError("Input length mismatch")
-    if log_probs.shape[2] != int(label_lengths.max()) + 1:
+    if log_probs.shape[2] != max_l + 1:
         raise ValueError("Output length mismatch")

@@ -127,13 +127,14 @@ static void launch_grad(Plan<typename Tag::comp>& p, const typename Tag::store* 
     hipLaunchKernelGGL((grad_flat_kernel<Tag, SC, PP, PS>), dim3(grid), dim3(256), 0, p.stream, acts, grads,        \
                        p.rowtab, grad_scale, E, R, p.A, p.blank, p.cells_per_sample, invA, dq, drem, rowscale)
         const bool padskip = tn.pskip && row_bytes >= 8192;     // skip reading padded rows only where rows are long
-        if (grad_scale) { if (padskip) RNNT_FLAT(true, 2, true); else RNNT_FLAT(true, 2, false); }
+        if (grad_scale && rowscale) { if (padskip) RNNT_FLAT(2, 2, true); else RNNT_FLAT(2, 2, false); }
+        else if (grad_scale) { if (padskip) RNNT_FLAT(1, 2, true); else RNNT_FLAT(1, 2, false); }
 #ifdef RNNT_DEV
-        else if (ppt == 1) RNNT_FLAT(false, 1, false);
-        else if (ppt == 4) RNNT_FLAT(false, 4, false);
+        else if (ppt == 1) RNNT_FLAT(0, 1, false);
+        else if (ppt == 4) RNNT_FLAT(0, 4, false);
 #endif
-        else if (padskip) RNNT_FLAT(false, 2, true);
-        else RNNT_FLAT(false, 2, false);
+        else if (padskip) RNNT_FLAT(0, 2, true);
+        else RNNT_FLAT(0, 2, false);
 #undef RNNT_FLAT
     } else {
         const dim3 rg((p.cells_per_sample + 3) / 4, p.N);

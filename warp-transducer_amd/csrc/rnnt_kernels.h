@@ -1163,13 +1163,14 @@ __global__ __launch_bounds__(256) void fill_row_scale_kernel(
 // here, so no memset of the gradient tensor exists (the reference does one: gpu_rnnt.h:107-110).
 // Measured on MI355X (tools/microbench/stream_variants.hip): this structure sustains
 // 6.4-6.5 TB/s read+write with the exp included, the wavefront-per-row form 5.1 TB/s.
-template <typename Tag, bool SCALED, int PPT, bool PADSKIP>   // PPT = packets per thread and iteration
-__global__ __launch_bounds__(256) void grad_flat_kernel(
+template <typename Tag, int SCALE, int PPT, bool PADSKIP>   // SCALE: 0 none, 1 per sample (padded layout), 2 per row (packed); PPT = packets per thread and iteration
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(typename Tag::comp) == 8 ? 1 : 8))) void grad_flat_kernel(
         const typename Tag::store* __restrict__ acts, typename Tag::store* __restrict__ grads,
         const Cell<typename Tag::comp>* __restrict__ rowtab, const typename Tag::comp* __restrict__ grad_scale,
         unsigned long long E, unsigned long long R, int A, int blank, int TU, float invA,
         unsigned long long dq, int drem, const typename Tag::comp* __restrict__ rowscale) {
     using C = typename Tag::comp;
+    constexpr bool SCALED = SCALE != 0;
     constexpr int V = Vec<Tag>::N;
     constexpr int kChunkPackets = PPT * 256;
     constexpr int CH = kChunkPackets * V;                 // elements per chunk
@@ -1192,18 +1193,18 @@ __global__ __launch_bounds__(256) void grad_flat_kernel(
     // grad_output / N folded in -- 10 % slower than the plain one on c3 (2.82 vs 2.55 ms; now 2.69) and the c5 step
     // through RNNTLoss 1.33 instead of 1.19 ms.  (Also measured: the scale folded into the exponent as exp(x + c + log s)
     // and a division-free sample index -- both no better, the former 7 % worse with 8-element bf16 packets.)
-    bool chunk_uniform = false;
+    // A chunk that does span two samples (or more: tiny lattices) goes through the plain per-element loop below, so the
+    // packet code never divides: 68 -> 5x registers for the scaled form, i.e. the occupancy of the plain one.
     C chunk_scale = C(1);
+    auto sample_scale = [&](unsigned long long row) -> C {      // (slow path and the tail elements only)
+        // (a 64-bit division is ~5x the instructions of a 32-bit one; tensors below 2^32 rows take the latter)
+        if (R <= 0xffffffffull) return grad_scale[static_cast<unsigned>(row) / static_cast<unsigned>(TU)];
+        return grad_scale[row / static_cast<unsigned>(TU)];
+    };
     auto scale_of = [&](unsigned long long row) -> C {
-        if constexpr (SCALED) {
-            if (chunk_uniform) return chunk_scale;
-            if (rowscale != nullptr) return rowscale[row];
-            // (a 64-bit division is ~5x the instructions of a 32-bit one; tensors below 2^32 rows take the latter)
-            if (R <= 0xffffffffull) return grad_scale[static_cast<unsigned>(row) / static_cast<unsigned>(TU)];
-            return grad_scale[row / static_cast<unsigned>(TU)];
-        } else {
-            return C(1);
-        }
+        if constexpr (SCALE == 2) return rowscale[row];
+        else if constexpr (SCALE == 1) return chunk_scale;
+        else return C(1);
     };
     // One element at position `pos` of a row with record `rec`.
     auto elem = [&](const Cell<C>& rec, int pos, C x, C gs) -> C {
@@ -1218,9 +1219,8 @@ __global__ __launch_bounds__(256) void grad_flat_kernel(
 
     for (; c < nchunks; c += gridDim.x) {
         const unsigned long long pk0 = c * kChunkPackets;
-        if constexpr (SCALED) {
-            chunk_uniform = false;
-            if (rowscale == nullptr) {                      // padded layout: sample = row / (maxT*maxU)
+        if constexpr (SCALE == 1) {
+            {                                               // padded layout: sample = row / (maxT*maxU)
                 const unsigned long long rl0 = r + static_cast<unsigned>(CH / A + 1);
                 const unsigned long long rl = rl0 < R ? rl0 : R - 1;          // last row the chunk can touch
                 unsigned long long b0, b1;
@@ -1232,7 +1232,26 @@ __global__ __launch_bounds__(256) void grad_flat_kernel(
                     b1 = rl / static_cast<unsigned>(TU);
                 }
                 chunk_scale = grad_scale[b0];
-                chunk_uniform = b0 == b1;
+                if (b0 != b1) {                             // block-uniform: the chunk crosses into another sample
+                    // element by element, in 32-bit arithmetic relative to the chunk (no wide divisions: this rare path
+                    // must not cost the packet code registers)
+                    const unsigned long long e0 = c * static_cast<unsigned long long>(CH);
+                    const unsigned len = static_cast<unsigned>(e0 + CH < npk * V ? CH : npk * V - e0);
+                    for (unsigned i = threadIdx.x; i < len; i += 256) {
+                        const unsigned idx = static_cast<unsigned>(rem) + i;      // offset from the start of row r (< 2^24)
+                        unsigned q = static_cast<unsigned>(static_cast<float>(idx) * invA);
+                        int pos = static_cast<int>(idx - q * static_cast<unsigned>(A));
+                        if (pos < 0) { pos += A; --q; } else if (pos >= A) { pos -= A; ++q; }
+                        const unsigned long long rw = r + q;
+                        unsigned long long sb = b0, next = (b0 + 1) * static_cast<unsigned>(TU);
+                        while (rw >= next) { ++sb; next += static_cast<unsigned>(TU); }
+                        store1<Tag>(grads + e0 + i, elem(rowtab[rw], pos, load1<Tag>(acts + e0 + i), grad_scale[sb]));
+                    }
+                    r += dq;
+                    rem += drem;
+                    if (rem >= A) { rem -= A; ++r; }
+                    continue;
+                }
             }
         }
         uint4 raw[PPT];
@@ -1341,12 +1360,14 @@ __global__ __launch_bounds__(256) void grad_flat_kernel(
     }
 
     // the E % V elements after the last whole packet
-    chunk_uniform = false;
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         for (unsigned long long e = npk * V; e < E; ++e) {
             const unsigned long long rw = e / static_cast<unsigned>(A);
             const int pos = static_cast<int>(e - rw * static_cast<unsigned>(A));
-            store1<Tag>(grads + e, elem(rowtab[rw], pos, load1<Tag>(acts + e), scale_of(rw)));
+            C gs = C(1);
+            if constexpr (SCALE == 2) gs = rowscale[rw];
+            else if constexpr (SCALE == 1) gs = sample_scale(rw);
+            store1<Tag>(grads + e, elem(rowtab[rw], pos, load1<Tag>(acts + e), gs));
         }
     }
 }

@@ -22,7 +22,7 @@ static void launch_row_stats(Plan<typename Tag::comp>& p, const typename Tag::st
     using S = typename Tag::store;
     const Tune& tn = tune();
     const size_t row_bytes = static_cast<size_t>(p.A) * sizeof(S);
-    if (tn.tile && vec_ok && row_bytes <= static_cast<size_t>(kTileMaxRowBytes)) {
+    if (tn.tile && vec_ok && row_bytes <= static_cast<size_t>(tn.tilemax)) {
         // short rows: LDS-tile kernel; smallest lane group G whose tile of 256/G rows fits the budget
         const size_t budget = static_cast<size_t>(tn.tilekb) * 1024;
         int G = 1;

@@ -156,6 +156,29 @@ def test_unaligned_rows_and_odd_vocab(oracle):
     assert np.abs(costs.numpy() - ref_c).max() < 1e-4 and np.abs(g.cpu().numpy() - ref_g).max() < 1e-5
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("A", [29, 511, 1023, 1025, 1279, 2047, 2049, 4097])
+def test_vocabularies_next_to_powers_of_two(oracle, A, dtype):
+    """V + blank and V - 1 symbols: rows that start at every 2- / 4-byte phase.  Covers the statistics kernels' forms for
+    such rows -- aligned 8-byte LDS words with masked edges (rows up to 4 KB), covering 16-byte packets with masked edges
+    and the fifth packet of a 2^k + 1 row (longer rows) -- and the straddling packets of the gradient stream."""
+    from warprnnt_pytorch import warp_rnnt
+    rng = np.random.default_rng(A)
+    N, T, U = 3, 6, 4
+    dev = torch.device("cuda:0")
+    x = torch.tensor(rng.standard_normal((N, T, U, A)) * 2.0, dtype=dtype, device=dev)
+    labels = rng.integers(1, A, size=(N, U - 1)).astype(np.int32)
+    tl, ll = np.array([T, T - 2, 3], dtype=np.int32), np.array([U - 1, 1, 0], dtype=np.int32)
+    ref_c, ref_g = oracle.rnnt_logits(x.double().cpu().numpy(), labels, tl, ll)
+    costs, grads = torch.zeros(N), torch.empty_like(x)
+    assert warp_rnnt.gpu_rnnt(x, torch.tensor(labels, device=dev), torch.tensor(tl, device=dev), torch.tensor(ll, device=dev),
+                              costs, grads, 0, 0) == 0
+    assert np.abs(costs.numpy() - ref_c).max() <= 1e-4 * max(1.0, np.abs(ref_c).max())
+    tol = 1e-5 if dtype == torch.float32 else (4e-3 if dtype == torch.bfloat16 else 5e-4)      # storage quantum of the gradients
+    assert np.abs(grads.double().cpu().numpy() - ref_g).max() <= tol
+    assert not grads[1, T - 2:].any() and not grads[2, :, 1:].any()                             # padding: exact zeros
+
+
 def test_gpu_status_codes():
     from warprnnt_pytorch import _lib
     lib = _lib.lib()

@@ -148,35 +148,78 @@ __global__ __launch_bounds__(WAVES * 64) void row_stats_kernel(
     const C xb = load1<Tag>(row + blank);
     const C xl = load1<Tag>(row + lab);
 
-    int head, nvec, tail0;
-    row_split<S>(reinterpret_cast<uintptr_t>(row), A, vec_ok != 0, head, nvec, tail0);
-
     C m = neg_inf<C>(), s = 0;
-    for (int e = lane; e < head; e += 64) {
-        C v[1] = {load1<Tag>(row + e)};
-        absorb<C, 1>(v, m, s);
-    }
-    const u32x4* vp = reinterpret_cast<const u32x4*>(row + head);
-    int i = lane;
-    for (; i + 192 < nvec; i += 256) {
-        const uint4 r0 = load_packet<NT>(vp + i), r1 = load_packet<NT>(vp + i + 64),
-                    r2 = load_packet<NT>(vp + i + 128), r3 = load_packet<NT>(vp + i + 192);
-        C v[4 * V];
-        unpack<Tag>(r0, v);
-        unpack<Tag>(r1, v + V);
-        unpack<Tag>(r2, v + 2 * V);
-        unpack<Tag>(r3, v + 3 * V);
-        absorb<C, 4 * V>(v, m, s);
-    }
-    for (; i < nvec; i += 64) {
-        const uint4 r = load_packet<NT>(vp + i);
-        C v[V];
-        unpack<Tag>(r, v);
-        absorb<C, V>(v, m, s);
-    }
-    for (int e = tail0 + lane; e < A; e += 64) {
-        C v[1] = {load1<Tag>(row + e)};
-        absorb<C, 1>(v, m, s);
+    if (vec_ok) {
+        // The aligned 16-byte packets that COVER the row (its first and last packet may reach into the neighbouring rows:
+        // those elements are masked to -inf, which drops them from the maximum and from the sum; a packet never
+        // leaves the 16-byte granule that holds an element of this row, so it stays inside mapped memory even at the
+        // ends of the tensor).  Up to four packets per lane in flight.  A scalar head / tail per row, which this
+        // replaces, made a 1025-symbol bf16 vocabulary 1.7x slower than a 1024-symbol one.
+        const uintptr_t addr = reinterpret_cast<uintptr_t>(row);
+        const int skip = static_cast<int>((addr & 15u) / sizeof(S));      // elements of the first packet before the row
+        const u32x4* vp = reinterpret_cast<const u32x4*>(addr & ~static_cast<uintptr_t>(15));
+        const int npk = (skip + A + V - 1) / V;
+        auto finish = [&](const uint4& raw, int pidx, C* v) {            // unpack one packet, edges masked
+            unpack<Tag>(raw, v);
+            if (pidx == 0 || pidx == npk - 1) {
+#pragma unroll
+                for (int e = 0; e < V; ++e)
+                    if (static_cast<unsigned>(pidx * V + e - skip) >= static_cast<unsigned>(A)) v[e] = neg_inf<C>();
+            }
+        };
+        for (int base = 0; base < npk;) {                                  // rounds of (up to) four packets per lane
+            const int remaining = npk - base;                              // wave-uniform
+            const int i = base + lane;
+            const int left = npk - i;                                      // this lane has packets i, i+64, ... below npk
+            if (remaining > 256 && remaining <= 320) {
+                // a row of 2^k + 1 symbols: the few packets past a full round ride along as a fifth load instead of taking
+                // a round (= a memory round trip) of their own
+                const bool has5 = i + 256 < npk;
+                const uint4 r0 = load_packet<NT>(vp + i), r1 = load_packet<NT>(vp + i + 64),
+                            r2 = load_packet<NT>(vp + i + 128), r3 = load_packet<NT>(vp + i + 192);
+                uint4 r4 = make_uint4(0, 0, 0, 0);
+                if (has5) r4 = load_packet<NT>(vp + i + 256);
+                C v[4 * V];
+                finish(r0, i, v); finish(r1, i + 64, v + V); finish(r2, i + 128, v + 2 * V); finish(r3, i + 192, v + 3 * V);
+                absorb<C, 4 * V>(v, m, s);
+                if (has5) {
+                    C w[V];
+                    finish(r4, i + 256, w);
+                    absorb<C, V>(w, m, s);
+                }
+                base += 320;
+                continue;
+            }
+            base += 256;
+            // all loads of the round first (a load behind the masking branch of the previous packet is a round trip of its own)
+            if (left > 192) {
+                const uint4 r0 = load_packet<NT>(vp + i), r1 = load_packet<NT>(vp + i + 64),
+                            r2 = load_packet<NT>(vp + i + 128), r3 = load_packet<NT>(vp + i + 192);
+                C v[4 * V];
+                finish(r0, i, v); finish(r1, i + 64, v + V); finish(r2, i + 128, v + 2 * V); finish(r3, i + 192, v + 3 * V);
+                absorb<C, 4 * V>(v, m, s);
+            } else if (left > 128) {
+                const uint4 r0 = load_packet<NT>(vp + i), r1 = load_packet<NT>(vp + i + 64), r2 = load_packet<NT>(vp + i + 128);
+                C v[3 * V];
+                finish(r0, i, v); finish(r1, i + 64, v + V); finish(r2, i + 128, v + 2 * V);
+                absorb<C, 3 * V>(v, m, s);
+            } else if (left > 64) {
+                const uint4 r0 = load_packet<NT>(vp + i), r1 = load_packet<NT>(vp + i + 64);
+                C v[2 * V];
+                finish(r0, i, v); finish(r1, i + 64, v + V);
+                absorb<C, 2 * V>(v, m, s);
+            } else if (left > 0) {
+                const uint4 r0 = load_packet<NT>(vp + i);
+                C v[V];
+                finish(r0, i, v);
+                absorb<C, V>(v, m, s);
+            }
+        }
+    } else {
+        for (int e = lane; e < A; e += 64) {                               // elements not even element-aligned packets: scalar
+            C v[1] = {load1<Tag>(row + e)};
+            absorb<C, 1>(v, m, s);
+        }
     }
 
     const C M = wave_max(m);
@@ -352,7 +395,7 @@ __device__ __forceinline__ void tile_reduce_words(const W* __restrict__ words, i
     m_out = m; shift_out = shift; sum_out = sum;
 }
 
-constexpr int kTileMaxRowBytes = 2048;
+constexpr int kTileMaxRowBytes = 4096;   // (2048 until the reduce phase learned rows at any byte phase: A/B on 2-4 KB rows in DESIGN.md 3)
 
 template <typename Tag, int G>
 __global__ __launch_bounds__(256) void row_stats_tile_kernel(

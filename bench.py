@@ -13,7 +13,9 @@ A "step" = one pass of the hot path over one synthetic batch already resident in
 -> gradient write-back), i.e. exactly what the reference's tests/test_time.cu times
 (compute_rnnt_loss incl. the costs D2H copy and stream sync).  With N>1 the batch is sharded
 (weak scaling: every rank gets the full per-GPU batch) and each step adds the single RCCL
-all-reduce of the summed loss.
+all-reduce of the summed loss; the line then carries `multi_gpu` (ranks RCCL saw, per-rank ms, the same
+per-GPU workload timed without the collective, scaling efficiency).  Every line carries `check`: two
+samples of the timed batch against the fp64 oracle (outside the timed region; --no-verify skips it).
 
 Workloads (BASELINE.json configs; lattice U = L+1 as tests/test_time.cu:56):
   c2: N=16  T=150  L=40  A=28   fp32      c3: N=128 T=150 L=20 A=5000 fp32  (default, headline)
@@ -148,6 +150,26 @@ def cpu_baseline(w, acts, labels, act_lens, label_lens, budget_samples):
                                              % (n2, N, N / n2)))
 
 
+def verify_batch(w, acts, labels, act_lens, label_lens, grads, costs):
+    """Parity evidence for THIS run, outside the timed region: the first and the last sample of the timed batch (the
+    gradients and costs the last timed step left behind) against the fp64 oracle on the same -- storage-rounded --
+    inputs.  Tolerances are north_star's: loss 1e-4 relative, gradients 1e-3 absolute (bf16 storage: 4e-3, its quantum)."""
+    from oracle import oracle as O
+    N = acts.shape[0]
+    pick = sorted({0, N - 1})
+    xs = acts[pick].double().cpu().numpy()
+    O.lib().oracle_set_num_threads(min(len(pick), os.cpu_count() or 1))
+    ref_c, ref_g = O.rnnt_logits(xs, labels[pick].cpu().numpy(), act_lens[pick].cpu().numpy(), label_lens[pick].cpu().numpy())
+    got_c = costs[pick].double().cpu().numpy()
+    got_g = grads[pick].double().cpu().numpy()
+    rel = float((np.abs(got_c - ref_c) / np.maximum(1.0, np.abs(ref_c))).max())
+    gerr = float(np.abs(got_g - ref_g).max())
+    tol_g = 1e-3 if w["dtype"] == "fp32" else 4e-3
+    return {"samples_checked": pick, "max_rel_loss_err": rel, "max_abs_grad_err": gerr,
+            "tolerance": {"loss_rel": 1e-4, "grad_abs": tol_g}, "passed": bool(rel <= 1e-4 and gerr <= tol_g),
+            "against": "oracle/ (fp64 restatement of the reference CPU path) on the same inputs, outside the timed region"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -173,6 +195,9 @@ def main():
                     help="sharded step through the two-phase entry with the all-reduce BESIDE the gradient pass (A/B runs)")
     ap.add_argument("--force-sharded", action="store_true",
                     help="dev: run the multi-GPU step (async entry + RCCL all-reduce) even with one rank")
+    ap.add_argument("--no-verify", action="store_true",
+                    help="skip the parity check of the timed batch (two samples against the fp64 oracle, outside the "
+                         "timed region; its result is the JSON line's `check` object)")
     args = ap.parse_args()
     if args.gpus < 1:
         ap.error("--gpus must be >= 1")
@@ -197,7 +222,9 @@ def main():
             port = sk.getsockname()[1]
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
                "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-        raise SystemExit(subprocess.call(cmd))
+        # the host driver only supports dmabuf IPC: without this RCCL's peer setup fails (hipIpcGetMemHandle)
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        raise SystemExit(subprocess.call(cmd, env=env))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -302,12 +329,14 @@ def main():
             fwd_argv = (acts.data_ptr(), labels.data_ptr(), label_lens.data_ptr(), act_lens.data_ptr(), A, N,
                         costs.data_ptr(), ws.data_ptr(), opt, code, 1)
             bwd_argv = (acts.data_ptr(), grads.data_ptr(), None, A, N, ws.data_ptr(), opt, code)
-            packed = torch.zeros(2, dtype=torch.float64, device=dev)     # [summed loss, sample count]
+            # the one collective of the data path: an 8-byte all-reduce of the summed loss (RCCL over xGMI).  Every rank
+            # holds N samples here, so the sample count of the mean is N * world on the host -- nothing else is
+            # written, copied or allocated per step (ShardedRNNTLoss, for ragged shards, reduces [sum, count]).
+            packed = torch.zeros(1, dtype=torch.float64, device=dev)
 
             def reduce_loss(async_op):
-                torch.sum(costs, dim=0, keepdim=True, dtype=torch.float64, out=packed[0:1])   # (no per-step allocation)
-                packed[1] = float(N)
-                return dist.all_reduce(packed, async_op=async_op)   # the one collective of the data path (RCCL over xGMI)
+                torch.sum(costs, dim=0, keepdim=True, dtype=torch.float64, out=packed)
+                return dist.all_reduce(packed, async_op=async_op)
 
             if args.overlap_collective:
                 def step():
@@ -333,6 +362,21 @@ def main():
                     lib.rnnt_profile_collect()
                     return packed
 
+        # Sharded runs: the SAME per-GPU workload first WITHOUT the collective (compute_rnnt_loss_async + device sync),
+        # on every rank at once -- the single-GPU reference the scaling efficiency of this line is read against
+        # (bench.py --gpus 1 times c3, the headline workload, so the driver's 1 -> N curve alone compares two workloads).
+        local_ms = None
+        if sharded:
+            for _ in range(max(warmup, 2)):
+                assert lib.compute_rnnt_loss_async(*argv) == 0
+                torch.cuda.synchronize(dev)
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+            l0 = time.perf_counter()
+            for _ in range(steps):
+                assert lib.compute_rnnt_loss_async(*argv) == 0
+                torch.cuda.synchronize(dev)
+            local_ms = (time.perf_counter() - l0) * 1e3 / steps
         for _ in range(warmup):
             step()
         lib.rnnt_profile_reset()
@@ -368,10 +412,26 @@ def main():
             plain = dict(mean=round(float(pp.mean()), 4), median=round(float(np.median(pp)), 4),
                          p10=round(float(np.percentile(pp, 10)), 4), p90=round(float(np.percentile(pp, 90)), 4),
                          note="the same steps with the per-stage HIP events switched off")
+        multi = None
         if sharded:
-            tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-            elapsed = float(tmax.item())
+            mine = torch.tensor([elapsed * 1e3 / steps, local_ms], dtype=torch.float64, device=dev)
+            every = [torch.zeros_like(mine) for _ in range(world)]
+            dist.all_gather(every, mine)
+            per_rank = [float(t[0]) for t in every]
+            per_rank_local = [float(t[1]) for t in every]
+            elapsed = max(per_rank) * steps / 1e3                      # MAX over ranks, as the contract asks
+            try:
+                rccl = ".".join(str(v) for v in torch.cuda.nccl.version())
+            except Exception:                                          # noqa: BLE001 -- version query only
+                rccl = None
+            multi = dict(ranks_seen=dist.get_world_size(), backend=dist.get_backend(), rccl_version=rccl,
+                         per_rank_ms=[round(v, 4) for v in per_rank],
+                         single_gpu_same_workload_ms=round(max(per_rank_local), 4),
+                         per_rank_single_gpu_ms=[round(v, 4) for v in per_rank_local],
+                         scaling_efficiency=round(max(per_rank_local) / max(per_rank), 4),
+                         note="single_gpu_same_workload_ms = the same per-GPU batch through compute_rnnt_loss_async + "
+                              "device sync with NO collective, all ranks at once (max over ranks); scaling_efficiency = "
+                              "that / value (weak scaling: 1.0 = the all-reduce and the barrier are free)")
         ms_step = elapsed * 1e3 / steps
         stage = (C.c_double * 5)()
         calls = lib.rnnt_profile_read(stage, 5)
@@ -382,8 +442,10 @@ def main():
                    step_ms=dict(median=round(float(np.median(per_step)), 4), p10=round(float(np.percentile(per_step, 10)), 4),
                                 p90=round(float(np.percentile(per_step, 90)), 4), n=int(per_step.size),
                                 note="per-step wall clock on rank 0 (each step ends in a device sync)"),
-                   plain_step_ms=plain,
+                   plain_step_ms=plain, multi=multi,
                    loss_sum=float(out.sum()) if not sharded else float(out[0]))
+        if rank == 0 and not args.no_verify and not args.packed:
+            res["verify"] = verify_batch(w, acts, labels, act_lens, label_lens, grads, costs)
         if with_cpu and rank == 0 and not args.packed:
             res["cpu"] = cpu_baseline(w, acts, labels, act_lens, label_lens, args.cpu_samples)
         del acts, grads, ws
@@ -409,7 +471,8 @@ def main():
                    "global_batch": w["N"] * world, "per_gpu_batch": w["N"],
                    "parallelism": "batch-sharded x%d, one RCCL all-reduce of the summed loss" % world
                    if sharded else "single GPU"},
-        "check": {"loss_sum": r["loss_sum"], "note": "summed loss of the last step (all ranks when sharded)"},
+        "check": dict({"loss_sum": r["loss_sum"], "note": "summed loss of the last step (all ranks when sharded)"},
+                      **(r.get("verify") or {})),
         "samples_per_s": round(w["N"] * world / (ms * 1e-3), 1),
         "step_ms": r["step_ms"],
         "plain_step_ms": r["plain_step_ms"],
@@ -443,6 +506,8 @@ def main():
         out["stats_roofline"] = {"achieved": round(ab["stats_kernel"] / (sm[0] * 1e-3) / 1e9, 1),
                                  "frac": round(ab["stats_kernel"] / (sm[0] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                                  "unit": "GB/s"}
+    if r.get("multi"):
+        out["multi_gpu"] = r["multi"]
     if "cpu" in r:
         out["cpu_baseline"] = r["cpu"]
     if args.extra and not sharded:

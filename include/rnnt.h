@@ -11,6 +11,7 @@
  *   - the library never allocates device or host memory: the caller asks
  *     get_workspace_size() and passes a workspace in the same memory space as
  *     the activations (reference src/rnnt_entrypoint.cpp:96-128, README.md:36-37);
+ *     the one opt-in exception (host memory, off by default) is rnnt_host_staging() below;
  *   - tensors are dense row-major (B, T, U, V), U = max_label_len + 1, labels
  *     are a padded (B, U-1) int32 array (reference include/rnnt.h:69-80,
  *     include/detail/gpu_rnnt_kernel.h:19);
@@ -206,6 +207,20 @@ rnntStatus_t compute_rnnt_loss_bwd(const void* activations,
                                    rnntOptions options,
                                    int dtype_code);
 
+/* The forward and the backward log-likelihood of every sample, log P(y|x) read off the end of the alpha recursion and
+ * off the start of the beta recursion (the reference's llForward / llBackward, include/detail/gpu_rnnt.h:92-105,
+ * whose CPU path compares them as a sanity check: include/detail/cpu_rnnt.h:167-170).  Reads them out of a workspace
+ * that a gradient-computing call (any materialised-path entry above, same maxT / maxU / minibatch / dtype_code) has
+ * filled: two HOST arrays of `minibatch` doubles, natural logs; synchronises options.stream.  A score-only call runs
+ * no beta recursion and leaves ll_backward undefined.  Their difference is the cheapest whole-lattice numerical guard
+ * there is; tests/ bound it. */
+rnntStatus_t compute_rnnt_loss_likelihoods(const void* workspace,
+                                           int minibatch,
+                                           rnntOptions options,
+                                           int dtype_code,
+                                           double* ll_forward_host,
+                                           double* ll_backward_host);
+
 /* FastEmit regularisation (Yu et al., "FastEmit", ICASSP 2021, in the form NVIDIA
  * NeMo's RNN-T loss uses): the gradient of every LABEL transition's log-probability is scaled by
  * (1 + fastemit_lambda), which pushes the model to emit earlier; the returned costs are the plain
@@ -399,6 +414,26 @@ rnntStatus_t compute_rnnt_loss_add_bwd_dt(const void* trans_acts,
                                           void* workspace,
                                           rnntOptions options,
                                           int dtype_code);
+
+/* Revision of the extension entry points below (the reference's get_warprnnt_version() stays 1).
+ *   3: the additive-joint entries (compute_rnnt_loss_add*) must be given a workspace sized by
+ *      get_workspace_size_add(); get_workspace_size() covers the materialised entries only.
+ *      Host staging of pageable costs became opt-in (rnnt_host_staging). */
+int get_warprnnt_extension_version(void);
+
+/* Memory the library itself allocates.  By DEFAULT: none, on the host or on the device, in any entry point -- as the
+ * reference (README.md:36-37); everything lives in the caller's workspace, and pageable host `costs` are copied behind
+ * the last kernel exactly as the reference does (include/detail/gpu_rnnt.h:208-213).  `costs` in PINNED host memory are
+ * written by the kernel directly (no copy, no allocation).
+ * OPT-IN: rnnt_host_staging(1) (or the environment variable WARPRNNT_HOST_STAGING=1 read at the first GPU call) lets
+ * compute_rnnt_loss / _fp64 / _bf16 / _fp16 route PAGEABLE costs through a pinned staging buffer of the calling thread
+ * (about 9 us of a 50 us call): host memory only, 4 KB grown by doubling to at most 1 MB per calling thread; larger
+ * batches use the copy.  rnnt_host_staging(0) turns it off again, any other value only queries; all return the
+ * previous setting (0 | 1).  rnnt_host_staging_bytes() = pinned bytes currently held;
+ * rnnt_host_staging_release() frees every buffer that is not inside a call at that moment and returns the bytes freed. */
+int rnnt_host_staging(int mode);
+long long rnnt_host_staging_bytes(void);
+long long rnnt_host_staging_release(void);
 
 /* Stage timing for benchmarks.  rnnt_profile_enable(1) makes every following
  * GPU call record HIP events around its kernels on options.stream (no extra

@@ -263,46 +263,109 @@ def test_pinned_host_costs_are_written_directly():
         warp_rnnt.gpu_rnnt(x, lab, bad, llen, torch.zeros(x.shape[0], pin_memory=True), torch.zeros_like(x), blank, 0)
 
 
-def test_pageable_host_costs_through_the_staging_buffer():
-    """Pageable host costs (the reference's callers) come back through the calling thread's pinned staging buffer:
-    a small batch first, then one that makes the buffer grow (fp64: 8 bytes per sample), then the same call from a
-    second thread (its own buffer) -- always the values of the device-cost entry, and untouched memory around them."""
-    import threading
+def _pageable_call(n, dtype, g):
+    """One synchronous C-ABI call with PAGEABLE host costs (guard words around them) against the device-cost entry."""
     from warprnnt_pytorch import warp_rnnt
     dev = torch.device("cuda:0")
+    x = torch.randn((n, 6, 4, 9), generator=g, device=dev, dtype=dtype)
+    lab = torch.randint(1, 9, (n, 3), generator=g, device=dev, dtype=torch.int32)
+    tl = torch.full((n,), 6, dtype=torch.int32, device=dev)
+    ll = torch.full((n,), 3, dtype=torch.int32, device=dev)
+    host = torch.full((n + 2,), -7.0, dtype=dtype)                 # guard words on both sides
+    grads = torch.zeros_like(x)
+    assert warp_rnnt.gpu_rnnt(x, lab, tl, ll, host[1:n + 1], grads, 0, 0) == 0
+    ref = torch.empty(n, dtype=dtype, device=dev)
+    ws = warp_rnnt.gpu_rnnt_fwd(x, lab, tl, ll, ref, 0, False)
+    torch.cuda.synchronize()
+    del ws
+    assert host[0].item() == -7.0 and host[n + 1].item() == -7.0
+    assert torch.equal(host[1:n + 1], ref.cpu())
+    assert bool(torch.isfinite(host).all()) and bool((host[1:n + 1] > 0).all())
+
+
+def test_library_makes_no_allocations():
+    """north_star: "the workspace sizing / no-internal-malloc contract is preserved" (reference README.md:36-37).
+    With the default settings the drop-in call allocates NOTHING: the library's own pinned-byte counter stays 0 and the
+    device's free memory (hipMemGetInfo through torch) is the same before and after calls of several shapes, dtypes and
+    entry points -- pageable costs take the copy the reference takes (include/detail/gpu_rnnt.h:208-213), pinned costs are
+    written directly."""
+    from warprnnt_pytorch import _lib, warp_rnnt
+    lib = _lib.lib()
+    assert lib.get_warprnnt_extension_version() >= 3
+    assert lib.rnnt_host_staging(-1) == 0 and lib.rnnt_host_staging_bytes() == 0          # off unless asked for
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(11)
+    cases = []
+    for n, T, U, A, dtype in ((3, 6, 4, 9, torch.float32), (700, 5, 3, 40, torch.float64), (5, 30, 70, 12, torch.float32),
+                              (2, 9, 5, 3000, torch.bfloat16)):
+        x = torch.randn((n, T, U, A), generator=g, device=dev, dtype=torch.float32).to(dtype)
+        lab = torch.randint(1, A, (n, U - 1), generator=g, device=dev, dtype=torch.int32)
+        tl = torch.full((n,), T, dtype=torch.int32, device=dev)
+        ll = torch.full((n,), U - 1, dtype=torch.int32, device=dev)
+        cdt = dtype if dtype == torch.float64 else torch.float32
+        ws = torch.empty(_lib.workspace_bytes(T, U, n, True, x.element_size()), dtype=torch.uint8, device=dev)
+        cases.append((x, lab, tl, ll, torch.zeros(n, dtype=cdt), torch.zeros(n, dtype=cdt, pin_memory=True),
+                      torch.zeros(n, dtype=cdt, device=dev), torch.zeros_like(x), ws))
+    torch.cuda.synchronize()
+
+    def sweep():
+        for x, lab, tl, ll, pageable, pinned, dcosts, grads, ws in cases:
+            assert warp_rnnt.gpu_rnnt(x, lab, tl, ll, pageable, grads, 0, 0, workspace=ws) == 0
+            assert warp_rnnt.gpu_rnnt(x, lab, tl, ll, pinned, grads, 0, 0, workspace=ws) == 0
+            warp_rnnt.gpu_rnnt_async(x, lab, tl, ll, dcosts, grads, 0, workspace=ws)
+            torch.cuda.synchronize()
+            assert torch.equal(pageable, pinned) and torch.equal(pinned, dcosts.cpu())
+    sweep()                                                # first calls: code objects load (the runtime's, not ours)
+    free0 = torch.cuda.mem_get_info(dev)[0]
+    for _ in range(3):
+        sweep()
+    assert torch.cuda.mem_get_info(dev)[0] == free0
+    assert lib.rnnt_host_staging_bytes() == 0
+
+
+def test_opt_in_host_staging():
+    """rnnt_host_staging(1): pageable host costs come back through the calling thread's pinned staging buffer -- a small
+    batch first, then one that makes the buffer grow (fp64: 8 bytes per sample), the same from a second thread (its
+    own buffer), a batch past the 1 MB cap (the copy route), always the values of the device-cost entry and untouched
+    memory around them; the bytes are counted and rnnt_host_staging_release() returns them."""
+    import threading
+    from warprnnt_pytorch import _lib
+    lib = _lib.lib()
+    dev = torch.device("cuda:0")
     g = torch.Generator(device=dev).manual_seed(3)
+    assert lib.rnnt_host_staging(1) == 0
+    try:
+        assert lib.rnnt_host_staging(-1) == 1
+        _pageable_call(3, torch.float32, g)
+        assert lib.rnnt_host_staging_bytes() == 4096
+        _pageable_call(2000, torch.float64, g)                         # 16 000 bytes: past the first 4 KB buffer
+        assert lib.rnnt_host_staging_bytes() == 16384
+        _pageable_call(5, torch.float32, g)
+        assert lib.rnnt_host_staging_bytes() == 16384
+        errs = []
 
-    def one(n, dtype):
-        x = torch.randn((n, 6, 4, 9), generator=g, device=dev, dtype=dtype)
-        lab = torch.randint(1, 9, (n, 3), generator=g, device=dev, dtype=torch.int32)
-        tl = torch.full((n,), 6, dtype=torch.int32, device=dev)
-        ll = torch.full((n,), 3, dtype=torch.int32, device=dev)
-        host = torch.full((n + 2,), -7.0, dtype=dtype)                 # guard words on both sides
-        grads = torch.zeros_like(x)
-        assert warp_rnnt.gpu_rnnt(x, lab, tl, ll, host[1:n + 1], grads, 0, 0) == 0
-        ref = torch.empty(n, dtype=dtype, device=dev)
-        ws = warp_rnnt.gpu_rnnt_fwd(x, lab, tl, ll, ref, 0, False)
-        torch.cuda.synchronize()
-        del ws
-        assert host[0].item() == -7.0 and host[n + 1].item() == -7.0
-        assert torch.equal(host[1:n + 1], ref.cpu())
-        assert bool(torch.isfinite(host).all()) and bool((host[1:n + 1] > 0).all())
-
-    one(3, torch.float32)
-    one(2000, torch.float64)                                           # 16 000 bytes: past the first 4 KB buffer
-    one(5, torch.float32)
-    errs = []
-
-    def worker():
-        try:
-            torch.cuda.set_device(0)
-            one(1500, torch.float32)
-            one(7, torch.float64)
-        except Exception as e:                                         # noqa: BLE001 -- reported to the main thread
-            errs.append(e)
-    th = threading.Thread(target=worker)
-    th.start(); th.join()
-    assert not errs, errs
+        def worker():
+            try:
+                torch.cuda.set_device(0)
+                _pageable_call(1500, torch.float32, g)
+                _pageable_call(7, torch.float64, g)
+            except Exception as e:                                     # noqa: BLE001 -- reported to the main thread
+                errs.append(e)
+        th = threading.Thread(target=worker)
+        th.start(); th.join()
+        assert not errs, errs
+        assert lib.rnnt_host_staging_bytes() == 16384 + 8192           # the second thread's own buffer
+        _pageable_call(140000, torch.float64, g)                       # 1.12 MB > cap: copied as by default
+        assert lib.rnnt_host_staging_bytes() == 16384 + 8192
+        assert lib.rnnt_host_staging_release() == 16384 + 8192 and lib.rnnt_host_staging_bytes() == 0
+        _pageable_call(9, torch.float32, g)                            # and it comes back on demand
+        assert lib.rnnt_host_staging_bytes() == 4096
+    finally:
+        lib.rnnt_host_staging(0)
+        lib.rnnt_host_staging_release()
+    assert lib.rnnt_host_staging_bytes() == 0
+    _pageable_call(4, torch.float32, g)                                # off again: nothing allocated
+    assert lib.rnnt_host_staging_bytes() == 0
 
 
 def test_concurrent_threads_on_their_own_streams():
@@ -391,8 +454,10 @@ def test_full_size_properties(oracle, name):
     costs2 = torch.zeros(N)
     assert warp_rnnt.gpu_rnnt(x, labels, tl, ll, costs2, torch.zeros(0, device=dev, dtype=dtype), 0, 0) == 0
     assert torch.equal(costs, costs2)
-    # (4) the oracle (fp64, on the rounded inputs) on two samples of this very batch
-    pick = [0, N - 1]
+    # (4) the oracle (fp64, on the rounded inputs) on eight samples spread over this very batch
+    import os
+    oracle.lib().oracle_set_num_threads(min(64, os.cpu_count() or 8))
+    pick = sorted(set(int(i) for i in np.linspace(0, N - 1, 8)))
     xs = x[pick].double().cpu().numpy()
     ref_c, ref_g = oracle.rnnt_logits(xs, labels[pick].cpu().numpy(), tl[pick].cpu().numpy(), ll[pick].cpu().numpy())
     got_c = costs[pick].double().numpy()

@@ -5,6 +5,7 @@ Tolerances (BASELINE.json north_star; SURVEY.md 8c "tolerance floor"): loss with
 oracle, gradients within 1e-3 absolute for fp32 storage; bf16 storage 4e-3 = half a bf16 ulp at |g| ~ 1 (2^-8),
 the quantum of the STORAGE type -- the arithmetic is the same fp32 as for fp32 storage."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -30,14 +31,26 @@ def _ref_stream_batch(oracle, n_ref, N, T, U, A, dev):
     return x, head, labels
 
 
-def _gpu_call(x, labels, tl, ll):
+def _gpu_call(x, labels, tl, ll, ws=None):
     from warprnnt_pytorch import warp_rnnt
     dev = x.device
-    costs = torch.zeros(x.shape[0])
+    costs = torch.zeros(x.shape[0], dtype=torch.float64 if x.dtype == torch.float64 else torch.float32)
     grads = torch.full_like(x, 7.0)
     assert warp_rnnt.gpu_rnnt(x, torch.tensor(labels, device=dev), torch.tensor(tl, device=dev),
-                              torch.tensor(ll, device=dev), costs, grads, 0, 0) == 0
+                              torch.tensor(ll, device=dev), costs, grads, 0, 0, workspace=ws) == 0
     return costs, grads
+
+
+def _likelihoods(ws, N, T, U, dtype=torch.float32):
+    """Forward / backward log-likelihoods left in the workspace by the last gradient-computing call
+    (compute_rnnt_loss_likelihoods: the reference's llForward / llBackward, include/detail/gpu_rnnt.h:92-105)."""
+    from warprnnt_pytorch import _lib
+    llf, llb = np.zeros(N), np.zeros(N)
+    opt = _lib.rnntOptions(loc=1, num_threads=0, stream=None, blank_label=0, maxT=T, maxU=U, batch_first=True)
+    st = _lib.lib().compute_rnnt_loss_likelihoods(ws.data_ptr(), N, opt, _lib.DT_F64 if dtype == torch.float64 else _lib.DT_F32,
+                                                  llf.ctypes.data, llb.ctypes.data)
+    assert st == 0, st
+    return llf, llb
 
 
 def test_c2_whole_batch_on_the_reference_stream(oracle):
@@ -61,12 +74,12 @@ def test_c2_whole_batch_on_the_reference_stream(oracle):
 
 
 @pytest.mark.parametrize("name,shape", [("c3", (128, 150, 21, 5000)), ("c4", (64, 1500, 301, 50))])
-def test_full_size_eight_samples_on_the_reference_stream(oracle, name, shape):
-    """c3 / c4 at full batch size: the first 8 samples are the reference harness's own stream and are checked
+def test_full_size_samples_on_the_reference_stream(oracle, name, shape):
+    """c3 / c4 at full batch size: the first 32 samples are the reference harness's own stream and are checked
     against the fp64 oracle, with variable lengths on top (T_b, U_b of the checked samples span the range)."""
     N, T, U, A = shape
     dev = torch.device("cuda:0")
-    K = 8
+    K = 32
     x, head, labels = _ref_stream_batch(oracle, K, N, T, U, A, dev)
     rng = np.random.default_rng(4)
     tl = rng.integers(T // 2, T + 1, size=N).astype(np.int32)
@@ -74,8 +87,15 @@ def test_full_size_eight_samples_on_the_reference_stream(oracle, name, shape):
     tl[0], ll[0] = T, U - 1
     tl[1], ll[1] = T, (U - 1) // 2
     tl[2], ll[2] = T // 2, U - 1
-    costs, grads = _gpu_call(x, labels, tl, ll)
-    oracle.lib().oracle_set_num_threads(8)
+    from warprnnt_pytorch import _lib
+    ws = torch.empty(_lib.workspace_bytes(T, U, N, True, 4), dtype=torch.uint8, device=dev)
+    costs, grads = _gpu_call(x, labels, tl, ll, ws)
+    # the forward and the backward recursion agree on log P(y|x) for EVERY sample of the batch (the reference's CPU path
+    # warns beyond 1e-1 absolute, include/detail/cpu_rnnt.h:167-170; c4 is 1800 diagonals of scaled fp32)
+    llf, llb = _likelihoods(ws, N, T, U)
+    assert np.abs(llf + costs.double().numpy()).max() <= 2e-7 * np.abs(llf).max()
+    assert np.abs(llf - llb).max() <= 1e-5 * np.abs(llf).max(), np.abs(llf - llb).max()
+    oracle.lib().oracle_set_num_threads(min(64, os.cpu_count() or 8))
     ref_c, ref_g = oracle.rnnt_logits(head.astype(np.float64), labels[:K], tl[:K], ll[:K])
     got_c, got_g = costs[:K].double().numpy(), grads[:K].double().cpu().numpy()
     assert np.abs(got_c - ref_c).max() <= 1e-4 * np.abs(ref_c).max()
@@ -150,12 +170,25 @@ def test_wide_lattices_fp64(oracle, shape):
     assert np.abs(g32 - r32g).max() < 5e-4            # ~1000 fp32 lattice steps (north_star: 1e-3)
 
 
-def test_batch_size_limit(oracle):
-    """N = 65535 runs (and is right); N = 65536 and maxT*maxU >= 2^29 are reported as INVALID_VALUE -- limits of
-    this library, not of the reference."""
+def test_batch_size_is_not_limited(oracle):
+    """The reference puts the samples on gridDim.x (include/detail/gpu_rnnt.h:127-128) and so takes any batch size;
+    here the kernels with the samples on gridDim.y run the batch in slices of 65535.  N on, just past and well past
+    that hardware limit: every sample against the oracle.  maxT*maxU >= 2^29 stays INVALID_VALUE, as
+    does N > 65535 for the additive-joint extension."""
     from warprnnt_pytorch import _lib
-    N, T, U, A = 65535, 2, 2, 3
-    rng = np.random.default_rng(65535)
+    for N in (65535, 65536, 200000):
+        T, U, A = 2, 2, 3
+        rng = np.random.default_rng(N)
+        acts = rng.standard_normal((N, T, U, A)).astype(np.float32)
+        labels = rng.integers(1, A, size=(N, U - 1))
+        tl, ll = rng.integers(1, T + 1, size=N), rng.integers(0, U, size=N)
+        tl[0], ll[0] = T, U - 1
+        ref_c, ref_g = oracle.rnnt_logits(acts.astype(np.float64), labels, tl, ll)
+        costs, grads = run_gpu(acts, labels, tl, ll)
+        assert np.abs(costs - ref_c).max() < 1e-4 and np.abs(grads - ref_g).max() < 1e-4, N
+    # the wavefront-per-row statistics kernel and the row-form gradient kernel (an unaligned tensor) across the slice edge
+    N, T, U, A = 65540, 1, 2, 1100
+    rng = np.random.default_rng(3)
     acts = rng.standard_normal((N, T, U, A)).astype(np.float32)
     labels = rng.integers(1, A, size=(N, U - 1))
     tl, ll = np.full(N, T), rng.integers(0, U, size=N)
@@ -167,11 +200,15 @@ def test_batch_size_limit(oracle):
     x = torch.zeros(8, device=dev)
     i = torch.ones(8, dtype=torch.int32, device=dev)
     host = torch.zeros(8)
-    for kw, n in ((dict(maxT=2, maxU=2), 65536), (dict(maxT=1 << 20, maxU=512), 1), (dict(maxT=1 << 28, maxU=2), 1)):
+    for kw, n in ((dict(maxT=1 << 20, maxU=512), 1), (dict(maxT=1 << 28, maxU=2), 1)):
         opt = _lib.rnntOptions(loc=1, num_threads=0, stream=None, blank_label=0, batch_first=True, **kw)
         st = lib.compute_rnnt_loss(x.data_ptr(), None, i.data_ptr(), i.data_ptr(), i.data_ptr(), 3, n, host.data_ptr(),
                                    x.data_ptr(), opt)
         assert st == 2, (kw, n, st)
+    opt = _lib.rnntOptions(loc=1, num_threads=0, stream=None, blank_label=0, batch_first=True, maxT=2, maxU=2)
+    st = lib.compute_rnnt_loss_add(x.data_ptr(), x.data_ptr(), None, None, i.data_ptr(), i.data_ptr(), i.data_ptr(), 3, 65536,
+                                   x.data_ptr(), x.data_ptr(), opt)
+    assert st == 2, st
 
 
 def test_device_side_lengths_are_validated(oracle):
@@ -179,7 +216,7 @@ def test_device_side_lengths_are_validated(oracle):
     path has no check either, this library's CPU location returns INVALID_VALUE (csrc/rnnt_cpu.cpp).  The GPU
     location now agrees: compute_rnnt_loss returns INVALID_VALUE (the sample's cost carries a marker NaN, every
     kernel clamps the lengths, nothing is touched out of bounds), the asynchronous entries leave the NaN in the
-    device costs, and the other samples of the batch are unaffected."""
+    device costs, the flagged sample's gradient is all zeros, and the other samples of the batch are unaffected."""
     from warprnnt_pytorch import _lib, warp_rnnt
     lib = _lib.lib()
     dev = torch.device("cuda:0")
@@ -209,6 +246,7 @@ def test_device_side_lengths_are_validated(oracle):
         ok = [b for b in range(N) if b != bad_b]
         assert np.isnan(dc[bad_b]) and np.abs(dc[ok] - ref_c[ok]).max() < 1e-4
         assert np.abs(grads.cpu().numpy()[ok] - ref_g[ok]).max() < 1e-4
+        assert not grads[bad_b].any()                  # the flagged sample: zero gradient, not a function of garbage
     # and the valid batch still succeeds afterwards
     costs = torch.zeros(N)
     ttl, tll = torch.tensor(good_tl, device=dev), torch.tensor(good_ll, device=dev)
@@ -216,6 +254,28 @@ def test_device_side_lengths_are_validated(oracle):
     assert lib.compute_rnnt_loss(x.data_ptr(), grads.data_ptr(), lab.data_ptr(), tll.data_ptr(), ttl.data_ptr(), A, N,
                                  costs.data_ptr(), ws.data_ptr(), opt) == 0
     assert np.abs(costs.numpy() - ref_c).max() < 1e-4
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+def test_forward_and_backward_likelihoods_agree(dtype):
+    """|llForward - llBackward| over every lattice-kernel form (one wavefront, one and two columns per lane, 3..8
+    wavefronts), ragged lengths: the two recursions share nothing but the log-probs, so their agreement checks the
+    whole lattice (reference include/detail/cpu_rnnt.h:167-170)."""
+    dev = torch.device("cuda:0")
+    from warprnnt_pytorch import _lib
+    g = torch.Generator(device=dev).manual_seed(17)
+    for N, T, U, A in ((5, 40, 33, 7), (3, 300, 64, 5), (3, 90, 130, 4), (2, 700, 257, 3), (2, 50, 301, 6), (2, 30, 700, 3),
+                       (2, 20, 1024, 2)):
+        x = (torch.randn((N, T, U, A), generator=g, device=dev) * 3.0).to(dtype)
+        labels = torch.randint(1, A, (N, U - 1), generator=g, device=dev, dtype=torch.int32).cpu().numpy()
+        tl = np.array([T] + [max(1, T - 7 * (i + 1)) for i in range(N - 1)], np.int32)
+        ll = np.array([U - 1] + [max(0, U - 1 - 11 * (i + 1)) for i in range(N - 1)], np.int32)
+        ws = torch.empty(_lib.workspace_bytes(T, U, N, True, x.element_size()), dtype=torch.uint8, device=dev)
+        costs, _ = _gpu_call(x, labels, tl, ll, ws)
+        llf, llb = _likelihoods(ws, N, T, U, dtype)
+        tol = 1e-5 if dtype == torch.float32 else 1e-12
+        assert np.abs(llf + costs.double().numpy()).max() <= 2e-7 * np.abs(llf).max(), (N, T, U, A)
+        assert np.abs(llf - llb).max() <= tol * np.abs(llf).max(), (N, T, U, A, np.abs(llf - llb).max())
 
 
 def test_wide_lattice_sweep(oracle):

@@ -150,6 +150,16 @@ def test_bench_sharded_step_on_one_rank():
     assert "all-reduce" in sh["config"]["parallelism"]
     assert abs(sh["check"]["loss_sum"] - plain["check"]["loss_sum"]) <= 1e-6 * abs(plain["check"]["loss_sum"])
     assert sh["stage_ms"]["grad"] > 0 and sh["stage_ms"]["row_stats"] > 0
+    # the multi-GPU line is self-sufficient: ranks RCCL saw, per-rank times, the same workload without the collective
+    for line in (sh, ov):
+        m = line["multi_gpu"]
+        assert m["ranks_seen"] == 1 and m["backend"] == "nccl" and len(m["per_rank_ms"]) == 1
+        assert m["single_gpu_same_workload_ms"] > 0 and 0.3 < m["scaling_efficiency"] <= 1.5
+        assert abs(m["per_rank_ms"][0] - line["value"]) <= 1e-3 * line["value"]
+    assert "multi_gpu" not in plain
+    # every line carries its own parity evidence (two samples of the timed batch against the fp64 oracle)
+    for line in lines:
+        assert line["check"]["passed"] and line["check"]["max_abs_grad_err"] <= 4e-3, line["check"]
 
 
 def test_bench_refuses_more_gpus_than_visible():

@@ -18,7 +18,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, reduction, q):
+def _worker(rank, world, port, reduction, q, ragged=False):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     for p in (root, os.path.join(root, "warp-transducer_amd")):
@@ -30,6 +30,8 @@ def _worker(rank, world, port, reduction, q):
     acts, labels, tl, ll = _batch()
     n = acts.shape[0] // world
     sl = slice(rank * n, (rank + 1) * n)
+    if ragged:                                  # rank 0 gets three of the four samples, rank 1 the last one
+        sl = slice(0, 3) if rank == 0 else slice(3, 4)
     x = acts[sl].clone().requires_grad_(True)
     loss = ShardedRNNTLoss(blank=0, reduction=reduction)(x, labels[sl].contiguous(), tl[sl].contiguous(),
                                                         ll[sl].contiguous())
@@ -72,3 +74,29 @@ def test_two_rank_shard_equals_single(reduction):
     for rank, loss, grad in got:
         assert np.allclose(loss, ref.detach().numpy(), atol=1e-5)          # global loss on every rank
         assert np.allclose(grad, x.grad[rank * 2:(rank + 1) * 2].numpy(), atol=1e-6)
+
+
+@pytest.mark.parametrize("reduction", ["mean", "none"])
+def test_ragged_shards(reduction):
+    """A last shard with fewer samples: 'mean' divides by the global count, 'none' returns all costs in batch order."""
+    from warprnnt_pytorch import RNNTLoss
+    acts, labels, tl, ll = _batch()
+    x = acts.clone().requires_grad_(True)
+    ref = RNNTLoss(reduction=reduction)(x, labels, tl, ll)
+    w = torch.arange(1, ref.numel() + 1, dtype=ref.dtype)
+    (ref * w).sum().backward()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, reduction, q, True)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted((q.get(timeout=120) for _ in procs), key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    bounds = [(0, 3), (3, 4)]
+    for rank, loss, grad in got:
+        assert np.allclose(loss, ref.detach().numpy(), atol=1e-5)
+        lo, hi = bounds[rank]
+        assert np.allclose(grad, x.grad[lo:hi].numpy(), atol=1e-6)

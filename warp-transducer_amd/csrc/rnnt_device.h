@@ -234,8 +234,12 @@ __device__ __forceinline__ double lane_get(double v, int k) {
 // Write the wave-uniform scalar `s` into lane `k` (compile-time) of `dst`: one v_writelane_b32 per dword
 // (inline assembly: this compiler has the readlane builtin but no writelane one; as a select on the lane
 // index the compiler turned the boundary hand-off of the lattice kernel into a branch per step).
+// v_writelane_b32 ignores EXEC: call it from wave-uniform control flow only (every caller is the body of an unrolled,
+// unconditional step loop).  The lane index is an inline constant when the compiler can prove it constant (the
+// unrolled loops of the optimised build) and a select on the lane index otherwise, so unoptimised / partially unrolled builds still assemble.
 __device__ __forceinline__ int lane_set_b32(int dst, int s, int k) {
-    asm("v_writelane_b32 %0, %1, %2" : "+v"(dst) : "s"(s), "n"(k));
+    if (__builtin_constant_p(k)) asm("v_writelane_b32 %0, %1, %2" : "+v"(dst) : "s"(s), "n"(k));
+    else dst = (static_cast<int>(__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u))) == k) ? s : dst;   // (select on the lane index)
     return dst;
 }
 __device__ __forceinline__ float lane_set(float dst, float s, int k) {

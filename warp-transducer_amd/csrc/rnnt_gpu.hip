@@ -7,9 +7,14 @@
 // The library never allocates memory: everything lives in the caller's workspace
 // (reference README.md:36-37).  The only host<->device traffic is the N-element copy of the
 // costs to the caller's HOST array followed by one stream synchronisation, which the
-// reference contract requires (gpu_rnnt.h:208-213).
+// reference contract requires (gpu_rnnt.h:208-213).  (One opt-in exception, off by default and
+// host memory only: the pinned staging buffer of rnnt_host_staging(), see stage_acquire below.)
 #include "rnnt_cpu.h"
 #include "rnnt_host.h"
+
+#include <atomic>
+#include <mutex>
+#include <vector>
 
 
 namespace rnnt {
@@ -56,25 +61,29 @@ static void launch_row_stats(Plan<typename Tag::comp>& p, const typename Tag::st
     // window of the tensor, which streams like a flat read (measured 6.6-6.9 TB/s vs 6.1-6.4 for the
     // wavefront-per-row form on 20-32 KB rows; no gain at 8 KB, a loss below)
     if (tn.blk && vec_ok && row_bytes >= 12288 && p.cells_per_sample <= 0x7fffffff) {
-        const dim3 bgrid(p.cells_per_sample, p.N);
+        for (int b0 = 0; b0 < p.N; b0 += kGridSamples) {      // (samples on gridDim.y: slices of the batch)
+            const dim3 bgrid(p.cells_per_sample, p.N - b0 < kGridSamples ? p.N - b0 : kGridSamples);
 #ifdef RNNT_DEV
-        if (!tn.nta)
-            hipLaunchKernelGGL((row_stats_block_kernel<Tag, false, 4>), bgrid, dim3(256), 0, p.stream, acts, p.labels,
-                               p.input_lengths, p.label_lengths, p.lp2, p.logz, p.maxT, p.maxU, p.Up, p.A, p.blank, vec_ok,
-                               p.offsets, p.packed_rows);
-        else
+            if (!tn.nta)
+                hipLaunchKernelGGL((row_stats_block_kernel<Tag, false, 4>), bgrid, dim3(256), 0, p.stream, acts, p.labels,
+                                   p.input_lengths, p.label_lengths, p.lp2, p.logz, p.maxT, p.maxU, p.Up, p.A, p.blank, vec_ok,
+                                   p.offsets, p.packed_rows, b0);
+            else
 #endif
-            hipLaunchKernelGGL((row_stats_block_kernel<Tag, true, 4>), bgrid, dim3(256), 0, p.stream, acts, p.labels,
-                               p.input_lengths, p.label_lengths, p.lp2, p.logz, p.maxT, p.maxU, p.Up, p.A, p.blank, vec_ok,
-                               p.offsets, p.packed_rows);
+                hipLaunchKernelGGL((row_stats_block_kernel<Tag, true, 4>), bgrid, dim3(256), 0, p.stream, acts, p.labels,
+                                   p.input_lengths, p.label_lengths, p.lp2, p.logz, p.maxT, p.maxU, p.Up, p.A, p.blank, vec_ok,
+                                   p.offsets, p.packed_rows, b0);
+        }
         p.check();
         return;
     }
     // long rows: one wavefront per row
 #define RNNT_STATS(WV, NT)                                                                                       \
-    hipLaunchKernelGGL((row_stats_kernel<Tag, WV, NT>), dim3((p.cells_per_sample + WV - 1) / WV, p.N), dim3(WV * 64), \
-                       0, p.stream, acts, p.labels, p.input_lengths, p.label_lengths, p.lp2, p.logz, p.maxT, p.maxU, \
-                       p.Up, p.A, p.blank, vec_ok, p.offsets, p.packed_rows)
+    for (int b0 = 0; b0 < p.N; b0 += kGridSamples)                                                               \
+        hipLaunchKernelGGL((row_stats_kernel<Tag, WV, NT>),                                                      \
+                           dim3((p.cells_per_sample + WV - 1) / WV, p.N - b0 < kGridSamples ? p.N - b0 : kGridSamples), \
+                           dim3(WV * 64), 0, p.stream, acts, p.labels, p.input_lengths, p.label_lengths, p.lp2,  \
+                           p.logz, p.maxT, p.maxU, p.Up, p.A, p.blank, vec_ok, p.offsets, p.packed_rows, b0)
     // (the forms a release build never selects exist in the development build only: less device code to load)
 #ifdef RNNT_DEV
     if (tn.nta) { if (tn.sw == 8) RNNT_STATS(8, true); else if (tn.sw == 2) RNNT_STATS(2, true); else RNNT_STATS(4, true); }
@@ -137,47 +146,93 @@ static void launch_grad(Plan<typename Tag::comp>& p, const typename Tag::store* 
         else RNNT_FLAT(0, 2, false);
 #undef RNNT_FLAT
     } else {
-        const dim3 rg((p.cells_per_sample + 3) / 4, p.N);
-        if (grad_scale)
-            hipLaunchKernelGGL((grad_rows_kernel<Tag, 4, true>), rg, dim3(256), 0, p.stream, acts, grads, p.rowtab,
-                               grad_scale, p.maxT, p.maxU, p.A, p.blank, vec_ok);
-        else
-            hipLaunchKernelGGL((grad_rows_kernel<Tag, 4, false>), rg, dim3(256), 0, p.stream, acts, grads, p.rowtab,
-                               grad_scale, p.maxT, p.maxU, p.A, p.blank, vec_ok);
+        for (int b0 = 0; b0 < p.N; b0 += kGridSamples) {
+            const dim3 rg((p.cells_per_sample + 3) / 4, p.N - b0 < kGridSamples ? p.N - b0 : kGridSamples);
+            if (grad_scale)
+                hipLaunchKernelGGL((grad_rows_kernel<Tag, 4, true>), rg, dim3(256), 0, p.stream, acts, grads, p.rowtab,
+                                   grad_scale, p.maxT, p.maxU, p.A, p.blank, vec_ok, b0);
+            else
+                hipLaunchKernelGGL((grad_rows_kernel<Tag, 4, false>), rg, dim3(256), 0, p.stream, acts, grads, p.rowtab,
+                                   grad_scale, p.maxT, p.maxU, p.A, p.blank, vec_ok, b0);
+        }
     }
     p.check();
 }
 
-// The materialised path.  phases: bit 0 = forward part (row statistics, lattice and -- when gradients
-// are wanted -- the coefficient table), bit 1 = gradient kernel; the two-call form
-// Pageable host costs (what the reference's callers pass): the lattice kernel writes them into a small PINNED staging
-// buffer of the calling thread -- N values, allocated on the thread's first such call, grown when a larger batch comes
-// along, host memory only -- and the call copies them out after its stream synchronisation.  The alternative, a
-// hipMemcpyAsync into pageable memory behind the last kernel, stages through the runtime's own pinned buffers and
-// costs ~10 us of a 50 us call.  (Never freed: a thread_local destructor would call into the HIP runtime while the
-// process tears it down.)
-struct HostStage { void* host = nullptr; void* dev = nullptr; size_t cap = 0; };
-static void* host_stage(size_t bytes, void** host_out) {
-    static thread_local HostStage st;
-    if (st.cap < bytes) {
-        if (st.host != nullptr) (void)hipHostFree(st.host);
-        st = HostStage{};
+// Host costs.  The contract of the reference (and the default here): costs is a HOST array, the library allocates
+// nothing, the N values are copied behind the last kernel (hipMemcpyAsync, then the stream synchronisation:
+// gpu_rnnt.h:208-213).  Two faster routes exist, neither of which allocates by default:
+//   * costs in PINNED memory (hipHostMalloc / hipHostRegister, a torch tensor with pin_memory=True): the lattice
+//     kernel writes them directly, no copy at all;
+//   * OPT-IN staging (rnnt_host_staging(1) or WARPRNNT_HOST_STAGING=1): pageable costs go through a small pinned
+//     buffer of the calling thread (the copy into pageable memory stages through the runtime's own pinned buffers and
+//     costs ~10 us of a 50 us call).  This is the ONLY memory the library can ever allocate, host memory only,
+//     at most kStageCap bytes per calling thread, counted (rnnt_host_staging_bytes) and releasable
+//     (rnnt_host_staging_release); larger batches fall back to the copy.
+struct HostStage {
+    void* host = nullptr; void* dev = nullptr; size_t cap = 0; int device = -1;
+    std::atomic<bool> busy{false};
+};
+constexpr size_t kStageCap = 1u << 20;                 // bytes per calling thread
+static std::mutex g_stage_mu;
+static std::vector<HostStage*> g_stage_all;            // every thread's buffer (for the release call); entries are never removed
+static std::atomic<int> g_stage_mode{-1};              // -1: not decided yet (environment), 0 off, 1 on
+static std::atomic<long long> g_stage_bytes{0};
+
+static bool stage_enabled() {
+    int m = g_stage_mode.load(std::memory_order_relaxed);
+    if (m < 0) {
+        const char* e = getenv("WARPRNNT_HOST_STAGING");
+        m = (e != nullptr && atoi(e) > 0) ? 1 : 0;
+        g_stage_mode.store(m, std::memory_order_relaxed);
+    }
+    return m == 1;
+}
+
+static void stage_free(HostStage* st) {                // (g_stage_mu held, or the owner thread with busy set)
+    if (st->host != nullptr) {
+        (void)hipHostFree(st->host);
+        g_stage_bytes.fetch_sub(static_cast<long long>(st->cap), std::memory_order_relaxed);
+    }
+    st->host = st->dev = nullptr; st->cap = 0; st->device = -1;
+}
+
+// Returns the thread's staging record with `busy` set (the caller clears it), or nullptr: staging off, batch too
+// large, or the allocation failed -- the caller then uses the asynchronous copy.
+static HostStage* stage_acquire(size_t bytes) {
+    if (!stage_enabled() || bytes > kStageCap) return nullptr;
+    static thread_local HostStage* st = nullptr;
+    if (st == nullptr) {
+        st = new HostStage;                             // lives as long as the process: a thread_local destructor would
+        std::lock_guard<std::mutex> g(g_stage_mu);      // call into the HIP runtime while the process tears it down
+        g_stage_all.push_back(st);
+    }
+    std::lock_guard<std::mutex> g(g_stage_mu);          // (uncontended: taken per call only while staging is on)
+    int device = 0;
+    if (hipGetDevice(&device) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    if (st->cap < bytes) {
+        stage_free(st);
         size_t cap = 4096;
         while (cap < bytes) cap <<= 1;
         void* h = nullptr;
-        void* d = nullptr;
-        if (hipHostMalloc(&h, cap, hipHostMallocPortable | hipHostMallocMapped) != hipSuccess ||
-            hipHostGetDevicePointer(&d, h, 0) != hipSuccess) {
-            if (h != nullptr) (void)hipHostFree(h);
+        if (hipHostMalloc(&h, cap, hipHostMallocPortable | hipHostMallocMapped) != hipSuccess) {
             (void)hipGetLastError();
-            return nullptr;                            // the caller falls back to the asynchronous copy
+            return nullptr;
         }
-        st.host = h; st.dev = d; st.cap = cap;
+        st->host = h; st->cap = cap; st->device = -1;
+        g_stage_bytes.fetch_add(static_cast<long long>(cap), std::memory_order_relaxed);
     }
-    *host_out = st.host;
-    return st.dev;
+    if (st->device != device) {                         // the device alias belongs to the CURRENT device
+        void* d = nullptr;
+        if (hipHostGetDevicePointer(&d, st->host, 0) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        st->dev = d; st->device = device;
+    }
+    st->busy.store(true, std::memory_order_relaxed);
+    return st;
 }
 
+// The materialised path.  phases: bit 0 = forward part (row statistics, lattice and -- when gradients
+// are wanted -- the coefficient table), bit 1 = gradient kernel; the two-call form
 // (compute_rnnt_loss_fwd / _bwd) keeps only the workspace alive in between.  want_grad < 0: decided by
 // `grads != nullptr` (the reference's "gradients == NULL means score only").
 template <typename Tag>
@@ -190,12 +245,13 @@ static rnntStatus_t run_gpu(const typename Tag::store* acts, typename Tag::store
     using S = typename Tag::store;
     using C = typename Tag::comp;
     Plan<C> p;
-    // Host costs in PINNED memory (hipHostMalloc / hipHostRegister, e.g. a torch tensor with pin_memory=True) are
-    // written by the lattice kernel directly: no copy behind the last kernel, only the stream synchronisation the
-    // contract asks for.  Pageable memory, which the reference's callers pass, goes through the thread's pinned staging
-    // buffer (host_stage above); the hipMemcpyAsync below is the fallback when that cannot be allocated.
+    // Host costs in PINNED memory are written by the lattice kernel directly: no copy behind the last kernel, only the
+    // stream synchronisation the contract asks for.  Pageable memory, which the reference's callers pass, is copied
+    // behind the last kernel as the reference does -- or, when the caller has opted in, goes through the thread's
+    // pinned staging buffer (stage_acquire above).
     C* costs_direct = nullptr;
-    C* costs_staged = nullptr;                         // host view of the staging buffer, when it is in use
+    HostStage* stage = nullptr;                        // the staging record, when it is in use
+    struct StageGuard { HostStage*& s; ~StageGuard() { if (s != nullptr) s->busy.store(false, std::memory_order_relaxed); } } stage_guard{stage};
     if (costs_host != nullptr && costs_device_out == nullptr) {
         hipPointerAttribute_t attr;
         if (hipPointerGetAttributes(&attr, costs_host) == hipSuccess && attr.type == hipMemoryTypeHost &&
@@ -203,9 +259,8 @@ static rnntStatus_t run_gpu(const typename Tag::store* acts, typename Tag::store
             costs_direct = static_cast<C*>(attr.devicePointer);
         (void)hipGetLastError();                       // (the query of a pageable pointer reports an error: not ours)
         if (costs_direct == nullptr && N > 0) {
-            void* h = nullptr;
-            costs_direct = static_cast<C*>(host_stage(sizeof(C) * static_cast<size_t>(N), &h));
-            if (costs_direct != nullptr) costs_staged = static_cast<C*>(h);
+            stage = stage_acquire(sizeof(C) * static_cast<size_t>(N));
+            if (stage != nullptr) costs_direct = static_cast<C*>(stage->dev);
         }
     }
     if (!make_plan(p, A, N, opt, workspace, labels, label_lengths, input_lengths,
@@ -253,7 +308,7 @@ static rnntStatus_t run_gpu(const typename Tag::store* acts, typename Tag::store
             hipMemcpyAsync(costs_host, p.costs_dev, sizeof(C) * N, hipMemcpyDeviceToHost, p.stream) != hipSuccess)
             return RNNT_STATUS_MEMOPS_FAILED;
         if (hipStreamSynchronize(p.stream) != hipSuccess) return RNNT_STATUS_EXECUTION_FAILED;
-        if (costs_staged != nullptr) std::memcpy(costs_host, costs_staged, sizeof(C) * static_cast<size_t>(N));
+        if (stage != nullptr) std::memcpy(costs_host, stage->host, sizeof(C) * static_cast<size_t>(N));
         if (prof) prof_accumulate();
         // device-side lengths that do not fit the tensor (lattice_kernel marks the sample's cost): the same
         // status the CPU location returns for them (rnnt_cpu.cpp)
@@ -275,6 +330,7 @@ using namespace rnnt;
 extern "C" {
 
 int get_warprnnt_version() { return 1; }
+int get_warprnnt_extension_version(void) { return 3; }
 
 const char* rnntGetStatusString(rnntStatus_t status) {
     // Same strings as the reference (src/rnnt_entrypoint.cpp:18-35) so log scrapers keep working.
@@ -418,6 +474,23 @@ rnntStatus_t compute_rnnt_loss_bwd(const void* activations, void* gradients, con
                      grad_scale_device, workspace, options, dtype_code, 2, 1);
 }
 
+rnntStatus_t compute_rnnt_loss_likelihoods(const void* workspace, int minibatch, rnntOptions options, int dtype_code,
+                                           double* ll_forward_host, double* ll_backward_host) {
+    if (workspace == nullptr || minibatch <= 0 || options.maxT <= 0 || options.maxU <= 0 || options.loc != RNNT_GPU ||
+        ll_forward_host == nullptr || ll_backward_host == nullptr || dtype_code < 0 || dtype_code > 3)
+        return RNNT_STATUS_INVALID_VALUE;
+    const Layout lay = make_layout(options.maxT, options.maxU, minibatch, dtype_code == 1 ? 8 : 4, false);
+    const char* ws = reinterpret_cast<const char*>(align_up(reinterpret_cast<size_t>(workspace)));
+    hipStream_t stream = reinterpret_cast<hipStream_t>(options.stream);
+    const size_t bytes = sizeof(double) * static_cast<size_t>(minibatch);
+    if (hipMemcpyAsync(ll_forward_host, ws + lay.llf, bytes, hipMemcpyDeviceToHost, stream) != hipSuccess ||
+        hipMemcpyAsync(ll_backward_host, ws + lay.llb, bytes, hipMemcpyDeviceToHost, stream) != hipSuccess)
+        return RNNT_STATUS_MEMOPS_FAILED;
+    if (hipStreamSynchronize(stream) != hipSuccess) return RNNT_STATUS_EXECUTION_FAILED;
+    for (int b = 0; b < minibatch; ++b) ll_forward_host[b] *= kLn2;       // the lattice keeps the forward one in base 2
+    return RNNT_STATUS_SUCCESS;
+}
+
 rnntStatus_t compute_rnnt_loss_fastemit(const void* activations, void* gradients, const int* const flat_labels,
                                         const int* const label_lengths, const int* const input_lengths,
                                         int alphabet_size, int minibatch, void* costs_device,
@@ -489,6 +562,22 @@ rnntStatus_t compute_rnnt_loss_packed_bwd(const void* activations, void* gradien
         return RNNT_STATUS_INVALID_VALUE;
     return run_async(activations, gradients, nullptr, nullptr, nullptr, alphabet_size, minibatch, nullptr,
                      grad_scale_device, workspace, options, dtype_code, 2, 1, 0.0f, row_offsets, total_rows);
+}
+
+int rnnt_host_staging(int mode) {
+    const int before = stage_enabled() ? 1 : 0;
+    if (mode == 0 || mode == 1) g_stage_mode.store(mode, std::memory_order_relaxed);
+    return before;
+}
+
+long long rnnt_host_staging_bytes(void) { return g_stage_bytes.load(std::memory_order_relaxed); }
+
+long long rnnt_host_staging_release(void) {
+    std::lock_guard<std::mutex> g(g_stage_mu);
+    const long long before = g_stage_bytes.load(std::memory_order_relaxed);
+    for (HostStage* st : g_stage_all)
+        if (!st->busy.load(std::memory_order_relaxed)) stage_free(st);
+    return before - g_stage_bytes.load(std::memory_order_relaxed);
 }
 
 void rnnt_profile_enable(int on) { g_prof.on = on != 0; }

@@ -189,7 +189,8 @@ static bool make_plan(Plan<C>& p, int A, int N, const rnntOptions& opt, void* wo
     if (p.blank < 0 || p.blank >= A) return false;
     if (p.maxU > 1024) return false;               // one lane per label position (as the reference)
     if (static_cast<long long>(p.maxT) * p.maxU > 0x7fffffffLL / 4) return false;
-    if (N > 65535) return false;
+    if (joint && N > kGridSamples) return false;   // (the additive-joint kernels keep the samples on ONE grid dimension)
+    if (static_cast<long long>(N) * 2 > 0x7fffffffLL) return false;   // lattice kernel: 2 N blocks on gridDim.x
     p.Up = ((p.maxU + 63) / 64) * 64;
     // one sample's skewed lp2 array is addressed through a buffer descriptor with a 32-bit size
     if (lat_rows(p.maxT, p.maxU) * p.Up * sizeof(LogPair<C>) >= (1ull << 31)) return false;
@@ -247,17 +248,22 @@ template <typename C> static void launch_coef(Plan<C>& p, bool joint = false, bo
     if (p.maxU <= 48 || !tune().ctile) {
         // small lattices: one thread per skewed cell, scattered record store
         const long long skew_cells = static_cast<long long>(p.maxT + p.maxU - 1) * p.Up;
-        const dim3 cgrid(static_cast<unsigned>(((skew_cells + 255) / 256 + 7) / 8 * 8), p.N);   // multiple of 8: XCD-aware remap
-        hipLaunchKernelGGL((coef_cell_kernel<C>), cgrid, dim3(256), 0, p.stream, p.lp2, p.logz, p.alpha, p.beta, p.offa,
-                           p.offb, p.llf, p.labels, p.input_lengths, p.label_lengths, p.rowtab, p.maxT, p.maxU, p.Up,
-                           wmat, Upad, p.fastemit, planes, p.offsets, p.lat_w, p.lat_sh);
+        for (int b0 = 0; b0 < p.N; b0 += kGridSamples) {       // (samples on gridDim.y: slices of the batch)
+            const dim3 cgrid(static_cast<unsigned>(((skew_cells + 255) / 256 + 7) / 8 * 8),    // multiple of 8: XCD-aware remap
+                             p.N - b0 < kGridSamples ? p.N - b0 : kGridSamples);
+            hipLaunchKernelGGL((coef_cell_kernel<C>), cgrid, dim3(256), 0, p.stream, p.lp2, p.logz, p.alpha, p.beta, p.offa,
+                               p.offb, p.llf, p.labels, p.input_lengths, p.label_lengths, p.rowtab, p.maxT, p.maxU, p.Up,
+                               wmat, Upad, p.fastemit, planes, p.offsets, p.lat_w, p.lat_sh, b0, p.N);
+        }
     } else {
         const int DN = sizeof(C) == 4 ? 32 : 16;           // diagonals per tile (coef_kernel)
         const int tilesU = (p.maxU + 63) / 64, tilesN = (p.maxT + p.maxU - 1 + DN - 1) / DN;
-        const dim3 cgrid(static_cast<unsigned>(tilesU * tilesN), p.N);
-        hipLaunchKernelGGL((coef_kernel<C>), cgrid, dim3(256), 0, p.stream, p.lp2, p.logz, p.alpha, p.beta, p.offa,
-                           p.offb, p.llf, p.labels, p.input_lengths, p.label_lengths, p.rowtab, p.maxT, p.maxU, p.Up,
-                           wmat, Upad, tilesU, p.fastemit, planes, p.offsets, p.lat_w, p.lat_sh);
+        for (int b0 = 0; b0 < p.N; b0 += kGridSamples) {
+            const dim3 cgrid(static_cast<unsigned>(tilesU * tilesN), p.N - b0 < kGridSamples ? p.N - b0 : kGridSamples);
+            hipLaunchKernelGGL((coef_kernel<C>), cgrid, dim3(256), 0, p.stream, p.lp2, p.logz, p.alpha, p.beta, p.offa,
+                               p.offb, p.llf, p.labels, p.input_lengths, p.label_lengths, p.rowtab, p.maxT, p.maxU, p.Up,
+                               wmat, Upad, tilesU, p.fastemit, planes, p.offsets, p.lat_w, p.lat_sh, b0, p.N);
+        }
     }
     p.check();
 }

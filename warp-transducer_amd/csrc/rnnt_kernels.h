@@ -75,7 +75,21 @@ template <typename L> inline bool is_cost_invalid(L v) {
 // Device-side lengths clamped to the tensor (see lattice_kernel: such a sample is flagged through its cost;
 // every kernel clamps so that nothing is read or written outside the caller's arrays).
 __device__ __forceinline__ int clamp_len(int v, int hi) { return v > hi ? hi : v; }
+// The coefficient kernels' view of a sample: lengths that do not fit the tensor (the lattice kernel has marked its
+// cost) make EVERY cell of the sample a padded one, so its gradient is zero instead of a function of workspace
+// cells nobody wrote (T_b <= 0: the statistics kernels skip the sample altogether).
+__device__ __forceinline__ void coef_lens(const int* __restrict__ xlen, const int* __restrict__ ylen, int b, int maxT,
+                                          int maxU, int& Tb, int& Ub) {
+    const int T = xlen[b], U = ylen[b] + 1;
+    const bool bad = T < 1 || U < 1 || T > maxT || U > maxU;
+    Tb = bad ? 0 : T;
+    Ub = bad ? 0 : U;
+}
 
+// Kernels that put the samples on gridDim.y are launched in slices of at most kGridSamples samples (the hardware
+// limit of that dimension is 65535; the reference puts the samples on gridDim.x, gpu_rnnt.h:127-128, and so takes
+// any batch size): `b0` = first sample of the slice.
+constexpr int kGridSamples = 65535;
 constexpr int kLatPad = 16;
 __host__ __device__ inline size_t lat_rows(int maxT, int maxU) { return static_cast<size_t>(maxT) + maxU - 1 + 2 * kLatPad; }
 // element index of (b, n, u) in a skewed array with row stride Up
@@ -119,11 +133,11 @@ __global__ __launch_bounds__(WAVES * 64) void row_stats_kernel(
         const int* __restrict__ xlen, const int* __restrict__ ylen,
         LogPair<typename Tag::comp>* __restrict__ lp2, typename Tag::comp* __restrict__ logz,
         int maxT, int maxU, int Up, int A, int blank, int vec_ok, const long long* __restrict__ offsets,
-        unsigned long long total_rows) {                     // packed layout: rows of the tensor (offsets are device data: never read past it)
+        unsigned long long total_rows, int b0) {             // packed layout: rows of the tensor (offsets are device data: never read past it); b0 = first sample of this launch
     using S = typename Tag::store;
     using C = typename Tag::comp;
     constexpr int V = Vec<Tag>::N;
-    const int b = blockIdx.y;
+    const int b = b0 + blockIdx.y;
     const int lane = threadIdx.x & 63;
     const int q = uniform(blockIdx.x * WAVES + (threadIdx.x >> 6));
     if (q >= maxT * maxU) return;
@@ -249,12 +263,12 @@ __global__ __launch_bounds__(256) void row_stats_block_kernel(
         const int* __restrict__ xlen, const int* __restrict__ ylen,
         LogPair<typename Tag::comp>* __restrict__ lp2, typename Tag::comp* __restrict__ logz,
         int maxT, int maxU, int Up, int A, int blank, int vec_ok, const long long* __restrict__ offsets,
-        unsigned long long total_rows) {                     // packed layout: rows of the tensor (offsets are device data: never read past it)
+        unsigned long long total_rows, int b0) {             // packed layout: rows of the tensor (offsets are device data: never read past it); b0 = first sample of this launch
     using S = typename Tag::store;
     using C = typename Tag::comp;
     constexpr int V = Vec<Tag>::N;
     __shared__ C red_m[4], red_s[4];
-    const int b = blockIdx.y;
+    const int b = b0 + blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int q = blockIdx.x;
     const int Tb = clamp_len(xlen[b], maxT), Ub = clamp_len(ylen[b] + 1, maxU);
@@ -709,9 +723,14 @@ __host__ __device__ inline int lat_col_shift(int cols) { return cols == 2 ? 7 : 
 // Block barrier that orders LDS traffic only.  __syncthreads() also waits for every outstanding GLOBAL access of the
 // wavefront (s_waitcnt vmcnt(0)): here that would be the next chunk's prefetch and the acknowledgement of the last
 // chunk's stores, neither of which the other wavefronts of the block ever look at (they meet in the LDS ring only).
+// The two LDS-only fences make the ordering visible to the compiler as well (both builtins alone are "no memory" to
+// LLVM, which could move the ring accesses across them); restricted to the local address space they emit nothing
+// beyond the lgkmcnt wait.
 __device__ __forceinline__ void lds_barrier() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
     __builtin_amdgcn_s_waitcnt(0xc07f);                    // lgkmcnt(0); vmcnt and expcnt left alone
     __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
 
 template <typename L, int MAXW, int COLS>
@@ -1068,11 +1087,11 @@ __global__ __launch_bounds__(256) void coef_cell_kernel(
         const double* __restrict__ offb, const double* __restrict__ ll_fwd,
         const int* __restrict__ labels, const int* __restrict__ xlen, const int* __restrict__ ylen,
         Cell<L>* __restrict__ rowtab, int maxT, int maxU, int Up, float* __restrict__ wmat, int Upad, float fastemit,
-        int planes, const long long* __restrict__ offsets, int lw, int lsh) {   // offsets: packed row order (see row_stats_kernel)   // planes: 1 = W only; 2 = W and CL (third plane); 3 = W, CB, CL (one-hot df corrections); 4 = W, CB, CL and a plane of c
+        int planes, const long long* __restrict__ offsets, int lw, int lsh, int b0, int N) {   // offsets: packed row order (see row_stats_kernel); b0 = first sample of this launch, N = samples of the batch   // planes: 1 = W only; 2 = W and CL (third plane); 3 = W, CB, CL (one-hot df corrections); 4 = W, CB, CL and a plane of c
                         // that is written INTO the record table's memory (stride Upad <= 4 maxU floats) instead of
                         // the records -- with the one-hot DF nothing reads cb / cl / label per record any more,
                         // and 16 instead of 28 bytes leave per cell
-    const int b = blockIdx.y;
+    const int b = b0 + blockIdx.y;
     const unsigned per = gridDim.x >> 3;
     const unsigned blk = (blockIdx.x & 7u) * per + (blockIdx.x >> 3);
     const int D = maxT + maxU - 1;
@@ -1081,15 +1100,16 @@ __global__ __launch_bounds__(256) void coef_cell_kernel(
     const int n = uniform(static_cast<int>(i0 / Up));
     const int u = static_cast<int>(i0 - static_cast<long long>(n) * Up) + (threadIdx.x & 63);
     const int t = n - u;
-    const size_t plane = static_cast<size_t>(gridDim.y) * maxT * Upad;      // gridDim.y = N
+    const size_t plane = static_cast<size_t>(N) * maxT * Upad;
     if (u >= maxU || t < 0 || t >= maxT) return;              // not a row of the tensor
-    const int Tb = clamp_len(xlen[b], maxT), Ub = clamp_len(ylen[b] + 1, maxU);
+    int Tb, Ub;
+    coef_lens(xlen, ylen, b, maxT, maxU, Tb, Ub);
     const int wu = uniform(static_cast<int>(i0 - static_cast<long long>(n) * Up) >> lsh);    // this wavefront's 64 columns share it
     const CoefRaw<L> raw = coef_fetch<L>(lp2, logz, alpha_arr, beta, offa, offb, labels, b, n, u, maxT, maxU, Up, lw, lsh, wu);
     const Cell<L> o = coef_eval<L>(raw, ll_fwd[b], t, u, Tb, Ub, fastemit);
     if (offsets != nullptr) {
         const size_t at = static_cast<size_t>(offsets[b]) + static_cast<size_t>(t) * Ub + u;
-        if (t < Tb && u < Ub && at < static_cast<size_t>(gridDim.y) * maxT * maxU) rowtab[at] = o;   // (inside the table whatever the offsets say)
+        if (t < Tb && u < Ub && at < static_cast<size_t>(N) * maxT * maxU) rowtab[at] = o;   // (inside the table whatever the offsets say)
     } else if (planes != 4) {
         rowtab[(static_cast<size_t>(b) * maxT + t) * maxU + u] = o;
     }
@@ -1130,15 +1150,16 @@ __global__ __launch_bounds__(256) void coef_kernel(
         const double* __restrict__ offb, const double* __restrict__ ll_fwd,
         const int* __restrict__ labels, const int* __restrict__ xlen, const int* __restrict__ ylen,
         Cell<L>* __restrict__ rowtab, int maxT, int maxU, int Up, float* __restrict__ wmat, int Upad, int tilesU,
-        float fastemit, int planes, const long long* __restrict__ offsets, int lw, int lsh) {
+        float fastemit, int planes, const long long* __restrict__ offsets, int lw, int lsh, int b0, int N) {
     constexpr int DN = sizeof(L) == 4 ? 32 : 16;           // diagonals per tile (LDS: DN * 64 records)
     __shared__ Cell<L> recs[DN][64];
-    const int b = blockIdx.y;
+    const int b = b0 + blockIdx.y;
     const int lane = threadIdx.x & 63, wave = uniform(threadIdx.x >> 6);
     const int tu = static_cast<int>(blockIdx.x) % tilesU, tn = static_cast<int>(blockIdx.x) / tilesU;
     const int n0 = tn * DN, u0 = tu * 64;
     const int D = maxT + maxU - 1;
-    const int Tb = clamp_len(xlen[b], maxT), Ub = clamp_len(ylen[b] + 1, maxU);
+    int Tb, Ub;
+    coef_lens(xlen, ylen, b, maxT, maxU, Tb, Ub);
 
     // ---- compute, skewed order: the operands of COEF_KB of the wavefront's DN/4 cells are requested together
     {
@@ -1169,7 +1190,7 @@ __global__ __launch_bounds__(256) void coef_kernel(
     }
     __syncthreads();
     // ---- store, natural order: groups of DN lanes take one time row each
-    const size_t plane = static_cast<size_t>(gridDim.y) * maxT * Upad;      // gridDim.y = N
+    const size_t plane = static_cast<size_t>(N) * maxT * Upad;
     constexpr int GROUPS = 256 / DN;
     const int grp = threadIdx.x / DN, c = threadIdx.x % DN;
     const int t_lo = n0 - (u0 + 63);                       // first time row that meets the tile
@@ -1182,7 +1203,7 @@ __global__ __launch_bounds__(256) void coef_kernel(
         const Cell<L> o = recs[t + u - n0][u - u0];
         if (offsets != nullptr) {                          // packed row order: the run of a time row stays contiguous
             const size_t at = static_cast<size_t>(offsets[b]) + static_cast<size_t>(t) * Ub + u;
-            if (t < Tb && u < Ub && at < static_cast<size_t>(gridDim.y) * maxT * maxU) rowtab[at] = o;
+            if (t < Tb && u < Ub && at < static_cast<size_t>(N) * maxT * maxU) rowtab[at] = o;
         } else if (planes != 4) {
             rowtab[(static_cast<size_t>(b) * maxT + t) * maxU + u] = o;
         }
@@ -1445,11 +1466,11 @@ template <typename Tag, int WAVES, bool SCALED>
 __global__ __launch_bounds__(WAVES * 64) void grad_rows_kernel(
         const typename Tag::store* __restrict__ acts, typename Tag::store* __restrict__ grads,
         const Cell<typename Tag::comp>* __restrict__ rowtab, const typename Tag::comp* __restrict__ grad_scale,
-        int maxT, int maxU, int A, int blank, int vec_ok) {
+        int maxT, int maxU, int A, int blank, int vec_ok, int b0) {
     using S = typename Tag::store;
     using C = typename Tag::comp;
     constexpr int V = Vec<Tag>::N;
-    const int b = blockIdx.y;
+    const int b = b0 + blockIdx.y;
     const int lane = threadIdx.x & 63;
     const int q = uniform(blockIdx.x * WAVES + (threadIdx.x >> 6));
     if (q >= maxT * maxU) return;

@@ -42,6 +42,7 @@ EXPORTS = {
     "compute_rnnt_loss_fwd": (C.c_int, [_PTR, _PTR, _PTR, _PTR, C.c_int, C.c_int, _PTR, _PTR, rnntOptions,
                                         C.c_int, C.c_int]),
     "compute_rnnt_loss_bwd": (C.c_int, [_PTR, _PTR, _PTR, C.c_int, C.c_int, _PTR, rnntOptions, C.c_int]),
+    "compute_rnnt_loss_likelihoods": (C.c_int, [_PTR, C.c_int, rnntOptions, C.c_int, _PTR, _PTR]),
     "compute_rnnt_loss_fastemit": (C.c_int, [_PTR, _PTR, _PTR, _PTR, _PTR, C.c_int, C.c_int, _PTR,
                                              _PTR, _PTR, rnntOptions, C.c_int, C.c_float]),
     "compute_rnnt_loss_fwd_fastemit": (C.c_int, [_PTR, _PTR, _PTR, _PTR, C.c_int, C.c_int, _PTR, _PTR, rnntOptions,
@@ -65,6 +66,10 @@ EXPORTS = {
                                                C.c_int, C.c_int, C.c_float]),
     "compute_rnnt_loss_add_bwd_dt": (C.c_int, [_PTR, _PTR, _PTR, _PTR, _PTR, _PTR, _PTR, _PTR, C.c_int, C.c_int, _PTR,
                                                rnntOptions, C.c_int]),
+    "get_warprnnt_extension_version": (C.c_int, []),
+    "rnnt_host_staging": (C.c_int, [C.c_int]),
+    "rnnt_host_staging_bytes": (C.c_longlong, []),
+    "rnnt_host_staging_release": (C.c_longlong, []),
     "rnnt_profile_enable": (None, [C.c_int]),
     "rnnt_profile_reset": (None, []),
     "rnnt_profile_collect": (None, []),

@@ -4,7 +4,8 @@ Not in the reference (it has no multi-device layer: SURVEY.md 2.1/8e).  Samples 
 so every rank runs the single-GPU hot path on its own contiguous slab of the batch with its own
 workspace and stream; gradients stay local (data parallel).  The data path needs exactly ONE
 collective: an all-reduce(sum) of the 2-element vector [local summed loss, local sample count]
-('sum'/'mean'), or one all-gather of the per-sample costs ('none').  The payload is 8 bytes, so
+('sum'/'mean': shards may be ragged, 'mean' divides by the GLOBAL sample count), or an all-gather of the
+per-sample costs ('none'; ragged shards are padded to the largest, their sizes gathered first).  The payload is 8 bytes, so
 the collective is latency-bound and is enqueued on the compute stream -- nothing is staged
 through the host.  On CPU tensors (tests: gloo, world_size 2) the same code runs the library's
 RNNT_CPU location.
@@ -42,18 +43,27 @@ class _ShardedRNNT(Function):
         distributed = dist.is_available() and dist.is_initialized()
         ctx.scale = 1.0
         if reduction == "none":
+            ctx.rank_offset, ctx.local_n = 0, n
+            out = costs
             if distributed:
-                world = dist.get_world_size(group)
-                parts = [torch.empty_like(costs) for _ in range(world)]
-                dist.all_gather(parts, costs, group=group)      # equal shards
-                out = torch.cat(parts)
-            else:
-                out = costs
-            ctx.rank_offset = (dist.get_rank(group) if distributed else 0) * n
-            ctx.local_n = n
+                world, rank = dist.get_world_size(group), dist.get_rank(group)
+                # shards may be ragged (a last shard with fewer samples): one tiny all-gather of the shard sizes first,
+                # then the per-sample costs padded to the largest shard (all_gather wants equal shapes)
+                mine = torch.full((1,), n, dtype=torch.int64, device=costs.device)
+                sizes = [torch.empty_like(mine) for _ in range(world)]
+                dist.all_gather(sizes, mine, group=group)
+                sizes = [int(t.item()) for t in sizes]
+                top = max(sizes)
+                padded = costs if n == top else torch.cat([costs, costs.new_zeros(top - n)])
+                parts = [torch.empty_like(padded) for _ in range(world)]
+                dist.all_gather(parts, padded, group=group)
+                out = torch.cat([p[:k] for p, k in zip(parts, sizes)])
+                ctx.rank_offset = sum(sizes[:rank])
         else:
-            packed = torch.stack([costs.sum(dtype=torch.float64),
-                                  torch.tensor(float(n), dtype=torch.float64, device=costs.device)])
+            # [local summed loss, local sample count] built on the device: one fill and one reduction, no host-to-device
+            # copy and no synchronisation in front of the collective
+            packed = torch.full((2,), float(n), dtype=torch.float64, device=costs.device)
+            torch.sum(costs, dim=0, keepdim=True, dtype=torch.float64, out=packed[0:1])
             if distributed:
                 dist.all_reduce(packed, op=dist.ReduceOp.SUM, group=group)   # the single collective
             out = packed[0:1].to(costs.dtype)

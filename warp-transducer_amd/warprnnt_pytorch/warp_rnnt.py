@@ -47,9 +47,11 @@ def cpu_rnnt(acts, labels, input_lengths, label_lengths, costs, grads, blank_lab
     return 0
 
 
-def gpu_rnnt(acts, labels, input_lengths, label_lengths, costs, grads, blank_label, num_threads):
+def gpu_rnnt(acts, labels, input_lengths, label_lengths, costs, grads, blank_label, num_threads, workspace=None):
     """RNNT_GPU: acts are raw LOGITS on an MI355X, grads the dense d/d(logits);
-    labels/lengths are device tensors, ``costs`` is a HOST tensor.  Returns 0 / -1."""
+    labels/lengths are device tensors, ``costs`` is a HOST tensor.  Returns 0 / -1.
+    (``workspace``: optional caller-owned uint8 device tensor of get_workspace_size bytes; the
+    reference's 8-argument form allocates a temporary one from the framework allocator, binding.cpp:120,128.)"""
     lib = _lib.lib()
     if not acts.is_cuda:
         raise ValueError("gpu_rnnt needs device tensors")
@@ -62,7 +64,8 @@ def gpu_rnnt(acts, labels, input_lengths, label_lengths, costs, grads, blank_lab
         return -1
     fn, esz = table[acts.dtype]
     with torch.cuda.device(acts.device):
-        ws = torch.empty(_lib.workspace_bytes(T, U, N, True, esz), dtype=torch.uint8, device=acts.device)
+        ws = workspace if workspace is not None else torch.empty(_lib.workspace_bytes(T, U, N, True, esz),
+                                                                 dtype=torch.uint8, device=acts.device)
         stream = torch.cuda.current_stream(acts.device).cuda_stream
         opt = _options(_lib.RNNT_GPU, acts, blank_label, num_threads, stream)
         st = fn(acts.data_ptr(), _ptr(grads), labels.data_ptr(), label_lengths.data_ptr(),

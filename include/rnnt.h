@@ -435,7 +435,12 @@ int rnnt_host_staging(int mode);
 long long rnnt_host_staging_bytes(void);
 long long rnnt_host_staging_release(void);
 
-/* Stage timing for benchmarks.  rnnt_profile_enable(1) makes every following
+/* Stage timing and stage markers.  rnnt_profile_enable(on): bit 0 = stage timers, bit 1 = roctx RANGES around the
+ * enqueue of each stage ("warprnnt:row_stats", ":lattice", ":coefficients", ":gradient"; the additive-joint path:
+ * ":joint_partition", ":lattice", ":coefficients", ":joint_gradients") for `rocprofv3 --marker-trace --kernel-trace` --
+ * the counterpart of the reference's DEBUG_TIME stage timers (include/detail/gpu_rnnt.h:112-122).  The marker library
+ * is looked up at run time (no link dependency); WARPRNNT_ROCTX=1 in the environment switches the ranges on without
+ * code.  rnnt_profile_enable(1) makes every following
  * GPU call record HIP events around its kernels on options.stream (no extra
  * synchronisation); rnnt_profile_read() fills `ms` with the accumulated
  * milliseconds per stage since the last rnnt_profile_reset() and returns the

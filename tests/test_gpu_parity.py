@@ -736,3 +736,43 @@ def test_label_equal_to_blank_is_the_true_derivative(oracle):
     c32, g32 = run_gpu(acts.astype(np.float32), labels, tl, ll, blank)
     assert np.abs(g32 - num).max() < 1e-5
 
+
+
+def test_stage_ranges_for_external_profilers(tmp_path):
+    """rnnt_profile_enable(2) / WARPRNNT_ROCTX=1: every call brackets the enqueue of its stages with roctx ranges (the
+    counterpart of the reference's DEBUG_TIME stage timers, include/detail/gpu_rnnt.h:112-122).  Results are the same
+    with the ranges on; under `rocprofv3 --marker-trace` the four stage names appear in the marker trace."""
+    import os
+    import shutil
+    import subprocess
+    import sys
+    from warprnnt_pytorch import _lib
+    acts, labels, tl, ll, blank = case_inputs("var_a40")
+    base_c, base_g = run_gpu(acts, labels, tl, ll, blank)
+    lib = _lib.lib()
+    lib.rnnt_profile_enable(2)
+    try:
+        c, g = run_gpu(acts, labels, tl, ll, blank)
+    finally:
+        lib.rnnt_profile_enable(0)
+    assert np.array_equal(c, base_c) and np.array_equal(g, base_g)
+    prof = shutil.which("rocprofv3")
+    if prof is None:
+        pytest.skip("rocprofv3 not installed")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys; sys.path[:0] = [%r, %r]\n"
+            "import numpy as np, torch\n"
+            "from tests.test_gpu_parity import run_gpu, case_inputs\n"
+            "a, l, t, u, b = case_inputs('var_a40')\n"
+            "run_gpu(a, l, t, u, b)\n" % (root, os.path.join(root, "warp-transducer_amd")))
+    env = dict(os.environ, WARPRNNT_ROCTX="1", TMPDIR=str(tmp_path))
+    out = subprocess.run([prof, "--marker-trace", "--kernel-trace", "--output-format", "csv", "-d", str(tmp_path / "prof"), "--",
+                          sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env, cwd=str(tmp_path))
+    assert out.returncode == 0, out.stderr[-2000:]
+    text = ""
+    for dirpath, _, files in os.walk(str(tmp_path / "prof")):
+        for fn in files:
+            if fn.endswith(".csv") and "marker" in fn:
+                text += open(os.path.join(dirpath, fn)).read()
+    for name in ("warprnnt:row_stats", "warprnnt:lattice", "warprnnt:coefficients", "warprnnt:gradient"):
+        assert name in text, (name, text[:500])

@@ -34,3 +34,12 @@ for name in sys.argv[1:] or ["c2", "c3", "c5"]:
         t0 = time.perf_counter(); step(); ts.append((time.perf_counter() - t0) * 1e3)
     print("%s N=%d T=%d U=%d A=%d %s: RNNTLoss forward + backward median %.4f ms (p10 %.4f, p90 %.4f)"
           % (name, N, T, U, A, str(dt).replace("torch.", ""), np.median(ts), np.percentile(ts, 10), np.percentile(ts, 90)))
+    if name == "c2":       # the same step without the device-to-host read of the lengths (RNNTLoss(validate=False))
+        crit = RNNTLoss(reduction="mean", validate=False)
+        for _ in range(10):
+            step()
+        ts = []
+        for _ in range(100):
+            t0 = time.perf_counter(); step(); ts.append((time.perf_counter() - t0) * 1e3)
+        print("%s validate=False: RNNTLoss forward + backward median %.4f ms (p10 %.4f, p90 %.4f)"
+              % (name, np.median(ts), np.percentile(ts, 10), np.percentile(ts, 90)))

@@ -20,6 +20,7 @@
 namespace rnnt {
 
 Profile g_prof;
+Ranges g_ranges;
 
 // Stage 1 (materialised path): log-softmax statistics of every (b,t,u) row.
 template <typename Tag>
@@ -289,7 +290,12 @@ static rnntStatus_t run_gpu(const typename Tag::store* acts, typename Tag::store
         return RNNT_STATUS_INVALID_VALUE;
 
     const bool prof = prof_prepare();
-    auto mark = [&](int i) { if (prof) prof_mark(i, do_fwd, do_bwd, p.stream); };
+    const bool ranges = ranges_prepare();
+    static const char* const kStages[4] = {"warprnnt:row_stats", "warprnnt:lattice", "warprnnt:coefficients", "warprnnt:gradient"};
+    auto mark = [&](int i) {
+        if (prof) prof_mark(i, do_fwd, do_bwd, p.stream);
+        if (ranges) ranges_mark(i, do_fwd, do_bwd, kStages);
+    };
 
     mark(0);
     if (do_fwd) launch_row_stats<Tag>(p, acts, vec_ok);
@@ -580,7 +586,10 @@ long long rnnt_host_staging_release(void) {
     return before - g_stage_bytes.load(std::memory_order_relaxed);
 }
 
-void rnnt_profile_enable(int on) { g_prof.on = on != 0; }
+void rnnt_profile_enable(int on) {
+    g_prof.on = (on & 1) != 0;            // bit 0: stage timers (HIP events)
+    g_ranges.mode = (on & 2) ? 1 : 0;     // bit 1: roctx ranges around the stages
+}
 
 void rnnt_profile_collect(void) {
     if (g_prof.on && g_prof.ready && g_prof.pending) prof_accumulate();

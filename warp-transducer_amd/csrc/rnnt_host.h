@@ -9,6 +9,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include <dlfcn.h>
+
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -109,6 +111,47 @@ static inline void prof_accumulate() {
         g_prof.ms[4] += ms;
     g_prof.calls++;
     g_prof.pending = g_prof.has_fwd = g_prof.has_bwd = false;
+}
+
+// ----------------------------------------------------------------------------- stage ranges for external profilers
+// rocprofv3 --kernel-trace shows kernel names only; with ranges on (rnnt_profile_enable bit 1, or WARPRNNT_ROCTX=1 in the
+// environment) every call brackets the ENQUEUE of its four stages with roctx ranges -- the counterpart of the reference's
+// DEBUG_TIME stage timers (include/detail/gpu_rnnt.h:112-122) -- which `rocprofv3 --marker-trace` puts on the same
+// timeline as the kernels.  The marker library is looked up at run time (librocprofiler-sdk-roctx, else libroctx64):
+// the library does not link against a profiler, and without one the switch does nothing.
+struct Ranges {
+    int mode = -1;                 // -1: not decided (environment), 0 off, 1 on
+    bool tried = false;
+    int (*push)(const char*) = nullptr;
+    int (*pop)() = nullptr;
+};
+extern Ranges g_ranges;            // one instance for the library (defined in rnnt_gpu.hip)
+
+static bool ranges_prepare() {
+    if (g_ranges.mode < 0) {
+        const char* e = getenv("WARPRNNT_ROCTX");
+        g_ranges.mode = (e != nullptr && atoi(e) > 0) ? 1 : 0;
+    }
+    if (g_ranges.mode != 1) return false;
+    if (!g_ranges.tried) {
+        g_ranges.tried = true;
+        for (const char* name : {"librocprofiler-sdk-roctx.so.1", "librocprofiler-sdk-roctx.so", "libroctx64.so.4", "libroctx64.so"}) {
+            void* h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+            if (h == nullptr) continue;
+            g_ranges.push = reinterpret_cast<int (*)(const char*)>(dlsym(h, "roctxRangePushA"));
+            g_ranges.pop = reinterpret_cast<int (*)()>(dlsym(h, "roctxRangePop"));
+            if (g_ranges.push != nullptr && g_ranges.pop != nullptr) break;
+            g_ranges.push = nullptr; g_ranges.pop = nullptr;
+        }
+    }
+    return g_ranges.push != nullptr;
+}
+
+// boundary i of a call (the same five as prof_mark): closes stage i-1, opens stage i
+static void ranges_mark(int i, bool do_fwd, bool do_bwd, const char* const names[4]) {
+    auto active = [&](int stage) { return stage >= 0 && stage < 4 && (stage < 3 ? do_fwd : do_bwd); };
+    if (active(i - 1)) (void)g_ranges.pop();
+    if (active(i)) (void)g_ranges.push(names[i]);
 }
 
 // ----------------------------------------------------------------------------- tuning knobs

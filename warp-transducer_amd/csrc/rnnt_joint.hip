@@ -35,7 +35,13 @@ static rnntStatus_t run_gpu_joint(const typename Tag::store* f, const typename T
         return RNNT_STATUS_INVALID_VALUE;
     const bool training = want_grad;
     const bool prof = prof_prepare();
-    auto mark = [&](int i) { if (prof) prof_mark(i, do_fwd, do_bwd, p.stream); };
+    const bool ranges = ranges_prepare();
+    static const char* const kStages[4] = {"warprnnt:joint_partition", "warprnnt:lattice", "warprnnt:coefficients",
+                                           "warprnnt:joint_gradients"};
+    auto mark = [&](int i) {
+        if (prof) prof_mark(i, do_fwd, do_bwd, p.stream);
+        if (ranges) ranges_mark(i, do_fwd, do_bwd, kStages);
+    };
 
     const int maxT = p.maxT, maxU = p.maxU;
     // rows made of whole 16-byte packets (row-maximum kernel) and 4-element loads aligned (Z kernel)

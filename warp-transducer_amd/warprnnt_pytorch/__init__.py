@@ -24,7 +24,7 @@ _ASYNC_GPU = _os.environ.get("WARPRNNT_SYNC_API", "0") != "1"
 
 class _RNNT(Function):
     @staticmethod
-    def forward(ctx, acts, labels, act_lens, label_lens, blank, reduction, fastemit_lambda=0.0):
+    def forward(ctx, acts, labels, act_lens, label_lens, blank, reduction, fastemit_lambda=0.0, validate=True):
         """
         acts:       (batch, T, U, vocab) joint-network output; raw logits on the GPU,
                     log-probabilities on the CPU (the wrappers below apply log_softmax there)
@@ -33,7 +33,7 @@ class _RNNT(Function):
         label_lens: (batch,) int32 number of valid labels per sample
         """
         is_cuda = acts.is_cuda
-        certify_inputs(acts, labels, act_lens, label_lens)
+        certify_inputs(acts, labels, act_lens, label_lens, read_lengths=validate)
 
         minibatch_size = acts.size(0)
         cost_dtype = acts.dtype if acts.dtype in (torch.float32, torch.float64) else torch.float32
@@ -48,14 +48,21 @@ class _RNNT(Function):
             # the workspace (lattice + coefficient table) behind; backward runs the gradient kernel
             # once with the 1/N and grad_output factors folded in.  Same values, costs stay on device.
             costs = torch.empty(minibatch_size, dtype=cost_dtype, device=acts.device)
+            # (the workspace is allocated on, and only ever used on, the stream that is current here: the allocator's
+            # own stream bookkeeping covers it, no record_stream)
             ws = warp_rnnt.gpu_rnnt_fwd(acts, labels, act_lens, label_lens, costs, blank, acts.requires_grad,
                                         fastemit_lambda)
-            ws.record_stream(torch.cuda.current_stream(acts.device))
             ctx.save_for_backward(acts)
             ctx.workspace = ws if acts.requires_grad else None
             ctx.blank = blank
             ctx.mean_scale = 1.0 / minibatch_size if reduction == 'mean' else 1.0
-            grads = None
+            ctx.grads = None
+            # one reduction kernel ('mean' = sum / N, as the reference divides: __init__.py:36-40)
+            if reduction == 'sum':
+                return costs.sum(0, keepdim=True)
+            if reduction == 'mean':
+                return costs.mean(0, keepdim=True)
+            return costs
         else:
             # The library overwrites every element of grads (zeros in the padded region), so no
             # zero-fill is needed (the reference allocates zeros_like: __init__.py:24).
@@ -90,17 +97,22 @@ class _RNNT(Function):
             (acts,) = ctx.saved_tensors
             n = acts.size(0)
             sdt = torch.float64 if acts.dtype == torch.float64 else torch.float32
-            scale = (grad_output.reshape(-1).to(device=acts.device, dtype=sdt) * ctx.mean_scale).expand(n).contiguous()
+            g = grad_output.reshape(-1)
+            if g.dtype != sdt or g.device != acts.device:
+                g = g.to(device=acts.device, dtype=sdt)
+            # the per-sample factor of the gradient kernel in ONE elementwise kernel (broadcast of a (1,) grad_output
+            # for 'sum' / 'mean'; the 1/N of 'mean' folded in)
+            scale = g.expand(n) * ctx.mean_scale
             grads = torch.empty_like(acts)
             warp_rnnt.gpu_rnnt_bwd(acts, grads, scale, ctx.workspace, ctx.blank)
-            return grads, None, None, None, None, None, None
+            return grads, None, None, None, None, None, None, None
         # out of place (the reference scales the saved tensor in place, __init__.py:47-50, so a second
         # backward through a retained graph compounds the factors and gradcheck fails)
         grad_output = grad_output.view(-1, 1, 1, 1).to(ctx.grads)
-        return ctx.grads * grad_output, None, None, None, None, None, None
+        return ctx.grads * grad_output, None, None, None, None, None, None, None
 
 
-def rnnt_loss(acts, labels, act_lens, label_lens, blank=0, reduction='mean', fastemit_lambda=0.0):
+def rnnt_loss(acts, labels, act_lens, label_lens, blank=0, reduction='mean', fastemit_lambda=0.0, validate=True):
     """RNN Transducer loss.
 
     Args:
@@ -115,10 +127,14 @@ def rnnt_loss(acts, labels, act_lens, label_lens, blank=0, reduction='mean', fas
         fastemit_lambda (float, optional): extension, GPU only -- FastEmit regularisation (Yu et al.
             2021): the gradient of every label transition is scaled by (1 + fastemit_lambda); the
             returned loss is the plain negative log-likelihood. Default: 0.0 (the reference's loss)
+        validate (bool, optional): extension -- False skips the two checks that need the VALUES of the lengths
+            (T == max(act_lens), U == max(label_lens) + 1: reference __init__.py:134-139), which cost a device-to-host
+            read and a stream synchronisation per call when the lengths live on the GPU; everything else is still
+            checked, and lengths that do not fit the tensor make the sample's loss NaN. Default: True
     """
     if not acts.is_cuda:
         acts = torch.nn.functional.log_softmax(acts, -1)
-    return _RNNT.apply(acts, labels, act_lens, label_lens, blank, reduction, fastemit_lambda)
+    return _RNNT.apply(acts, labels, act_lens, label_lens, blank, reduction, fastemit_lambda, validate)
 
 
 class RNNTLoss(Module):
@@ -127,13 +143,16 @@ class RNNTLoss(Module):
         blank (int, optional): blank label. Default: 0.
         reduction (string, optional): 'none' | 'mean' | 'sum' (see `rnnt_loss`). Default: 'mean'
         fastemit_lambda (float, optional): extension, GPU only (see `rnnt_loss`). Default: 0.0
+        validate (bool, optional): extension (see `rnnt_loss`): False = no device-to-host read of the lengths per
+            call. Default: True (the reference's behaviour)
     """
 
-    def __init__(self, blank=0, reduction='mean', fastemit_lambda=0.0):
+    def __init__(self, blank=0, reduction='mean', fastemit_lambda=0.0, validate=True):
         super(RNNTLoss, self).__init__()
         self.blank = blank
         self.reduction = reduction
         self.fastemit_lambda = fastemit_lambda
+        self.validate = validate
         self.loss = _RNNT.apply
 
     def forward(self, acts, labels, act_lens, label_lens):
@@ -141,4 +160,4 @@ class RNNTLoss(Module):
             # The CPU location of the library takes log-probabilities; log_softmax runs inside
             # the kernels only on the GPU (reference __init__.py:95-98).
             acts = torch.nn.functional.log_softmax(acts, -1)
-        return self.loss(acts, labels, act_lens, label_lens, self.blank, self.reduction, self.fastemit_lambda)
+        return self.loss(acts, labels, act_lens, label_lens, self.blank, self.reduction, self.fastemit_lambda, self.validate)

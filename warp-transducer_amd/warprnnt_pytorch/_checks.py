@@ -22,9 +22,11 @@ def check_dim(var, dim, name):
         raise ValueError("%s must be %dD" % (name, dim))
 
 
-def certify_inputs(log_probs, labels, lengths, label_lengths):
+def certify_inputs(log_probs, labels, lengths, label_lengths, read_lengths=True):
     """(N,T,U,V) activations, (N,U-1) int32 labels, (N,) int32 lengths: dtype, contiguity, one length per sample,
-    ranks, and T == max(lengths), U == max(label_lengths) + 1 (one device-to-host read for both)."""
+    ranks, and T == max(lengths), U == max(label_lengths) + 1 (one device-to-host read for both).
+    read_lengths=False skips that last pair of checks -- the only ones that need the VALUES of the lengths, i.e. a
+    device-to-host read and a stream synchronisation per call when they live on the GPU (`RNNTLoss(validate=False)`)."""
     arg = {"log_probs": log_probs, "labels": labels, "lengths": lengths, "label_lengths": label_lengths}
     for name in ("labels", "label_lengths", "lengths"):
         check_type(arg[name], torch.int32, name)
@@ -38,10 +40,12 @@ def certify_inputs(log_probs, labels, lengths, label_lengths):
     for name, rank, shown in (("log_probs", 4, "log_probs"), ("labels", 2, "labels"),
                               ("lengths", 1, "lenghts"), ("label_lengths", 1, "label_lenghts")):
         check_dim(arg[name], rank, shown)
+    if not read_lengths:
+        return
     # the reference reads the two maxima back one after the other (two device synchronisations per forward when
-    # the lengths live on the GPU); one read of both keeps its checks and their order at half the stalls
+    # the lengths live on the GPU); one reduction over both vectors and one read keep its checks and their order
     if lengths.device == label_lengths.device:
-        max_t, max_l = torch.stack((lengths.max(), label_lengths.max())).tolist()
+        max_t, max_l = torch.stack((lengths, label_lengths)).amax(1).tolist()
     else:
         max_t, max_l = int(lengths.max()), int(label_lengths.max())
     if log_probs.shape[1] != max_t:

@@ -108,6 +108,43 @@ _DT = {torch.float32: (_lib.DT_F32, 4), torch.float64: (_lib.DT_F64, 8),
        torch.bfloat16: (_lib.DT_BF16, 2), torch.float16: (_lib.DT_F16, 2)}
 
 
+# Host-side cost of the two-phase entries (what a PyTorch user of SMALL problems sees: on N=16,T=150,U=41,A=28 the
+# kernels take ~30 us, tools/autograd_profile.py): the workspace size is queried once per (T, U, N, element size),
+# the raw stream handle comes straight from the allocator's stream table, and the device guard is only entered when
+# the tensors do not live on the thread's current device.
+_WS_BYTES = {}
+
+
+def _workspace_bytes_cached(T, U, N, esz):
+    key = (T, U, N, esz)
+    n = _WS_BYTES.get(key)
+    if n is None:
+        n = _WS_BYTES[key] = _lib.workspace_bytes(T, U, N, True, esz)
+    return n
+
+
+def _raw_stream(index):
+    return torch._C._cuda_getCurrentRawStream(index)
+
+
+class _on_device(object):
+    """`with torch.cuda.device(d)` only when d is not already the current device (the library launches on the
+    calling thread's current HIP device)."""
+    __slots__ = ("guard",)
+
+    def __init__(self, index):
+        self.guard = None if torch._C._cuda_getDevice() == index else torch.cuda.device(index)
+
+    def __enter__(self):
+        if self.guard is not None:
+            self.guard.__enter__()
+
+    def __exit__(self, *exc):
+        if self.guard is not None:
+            self.guard.__exit__(*exc)
+        return False
+
+
 def gpu_rnnt_fwd(acts, labels, input_lengths, label_lengths, costs_device, blank_label, prepare_backward,
                  fastemit_lambda=0.0):
     """Extension: forward phase only (compute_rnnt_loss_fwd; compute_rnnt_loss_fwd_fastemit when
@@ -115,12 +152,14 @@ def gpu_rnnt_fwd(acts, labels, input_lengths, label_lengths, costs_device, blank
     gradient-coefficient table `gpu_rnnt_bwd` needs and must be kept (untouched) until then.  Enqueue only."""
     lib = _lib.lib()
     N, T, U, A = acts.shape
-    if acts.dtype not in _DT:
+    dt = _DT.get(acts.dtype)
+    if dt is None:
         raise TypeError("rnnt_loss: unsupported dtype %s for the GPU location" % acts.dtype)
-    code, esz = _DT[acts.dtype]
-    with torch.cuda.device(acts.device):
-        ws = torch.empty(_lib.workspace_bytes(T, U, N, True, esz), dtype=torch.uint8, device=acts.device)
-        opt = _options(_lib.RNNT_GPU, acts, blank_label, 0, torch.cuda.current_stream(acts.device).cuda_stream)
+    code, esz = dt
+    index = acts.device.index
+    with _on_device(index):
+        ws = torch.empty(_workspace_bytes_cached(T, U, N, esz), dtype=torch.uint8, device=acts.device)
+        opt = _lib.rnntOptions(_lib.RNNT_GPU, 0, _raw_stream(index), int(blank_label), T, U, True)
         lab_ptr = labels.data_ptr() if labels.numel() else costs_device.data_ptr()   # maxU == 1: never read
         if fastemit_lambda:
             st = lib.compute_rnnt_loss_fwd_fastemit(acts.data_ptr(), lab_ptr, label_lengths.data_ptr(),
@@ -131,7 +170,8 @@ def gpu_rnnt_fwd(acts, labels, input_lengths, label_lengths, costs_device, blank
             st = lib.compute_rnnt_loss_fwd(acts.data_ptr(), lab_ptr, label_lengths.data_ptr(),
                                            input_lengths.data_ptr(), A, N, costs_device.data_ptr(), ws.data_ptr(), opt,
                                            code, 1 if prepare_backward else 0)
-    _lib.check(st, "compute_rnnt_loss_fwd")
+    if st != 0:
+        _lib.check(st, "compute_rnnt_loss_fwd")
     return ws
 
 
@@ -141,9 +181,11 @@ def gpu_rnnt_bwd(acts, grads, grad_scale, workspace, blank_label):
     lib = _lib.lib()
     N, T, U, A = acts.shape
     code, _ = _DT[acts.dtype]
-    with torch.cuda.device(acts.device):
-        opt = _options(_lib.RNNT_GPU, acts, blank_label, 0, torch.cuda.current_stream(acts.device).cuda_stream)
+    index = acts.device.index
+    with _on_device(index):
+        opt = _lib.rnntOptions(_lib.RNNT_GPU, 0, _raw_stream(index), int(blank_label), T, U, True)
         st = lib.compute_rnnt_loss_bwd(acts.data_ptr(), grads.data_ptr(), _ptr(grad_scale), A, N,
                                        workspace.data_ptr(), opt, code)
-    _lib.check(st, "compute_rnnt_loss_bwd")
+    if st != 0:
+        _lib.check(st, "compute_rnnt_loss_bwd")
     return 0

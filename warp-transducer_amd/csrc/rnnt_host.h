@@ -166,10 +166,11 @@ static void ranges_mark(int i, bool do_fwd, bool do_bwd, const char* const names
 // xcd = XCD-aware tile order of the short-row statistics kernel on/off, ctile = tiled coefficient kernel on/off,
 // pskip = the gradient kernel's skip-padded-rows form for rows >= 8 KB on/off, joh = one-hot df corrections in the
 // additive-joint DF kernel (-1: vocabularies <= 256), lat2 = two lattice columns per lane (-1: maxU > 256),
-// jsamp = additive joint: sampled row references + guard instead of the row-maximum pass (rnnt_joint_kernels.h) on/off.
+// jsamp = additive joint: sampled row references + guard instead of the row-maximum pass (rnnt_joint_kernels.h) on/off,
+// j16 = bf16 storage on the bf16 matrix cores (rnnt_joint16_kernels.h), bit 0 DG, bit 1 DF, bit 2 Z; j16pf = operand ping-pong there, j16nt = columns per lane of its DF / DG (8 | 4).
 struct Tune { int sw = 4, nta = 1, gmax = 4194304, rows = 0, tile = 1, tilekb = 52, ppt = 2;
               int jfnk = 0, jfpf = 1, jgnk = 0, jgpf = 1, blk = 1, jzs = 0, xcd = 1, ctile = 1, pskip = 1, joh = -1;
-              int lat2 = -1, xst = 0, jsamp = 1, tilemax = kTileMaxRowBytes; };
+              int lat2 = -1, xst = 0, jsamp = 1, tilemax = kTileMaxRowBytes, j16 = 7, j16pf = 1, j16nt = 4; };
 #ifdef RNNT_DEV
 static Tune read_tune() {
     Tune t;
@@ -179,7 +180,8 @@ static Tune read_tune() {
         {"sw", &t.sw}, {"nta", &t.nta}, {"gmax", &t.gmax}, {"rows", &t.rows}, {"tile", &t.tile},
         {"tilekb", &t.tilekb}, {"ppt", &t.ppt}, {"jfnk", &t.jfnk}, {"jfpf", &t.jfpf}, {"jgnk", &t.jgnk},
         {"jgpf", &t.jgpf}, {"blk", &t.blk}, {"jzs", &t.jzs}, {"xcd", &t.xcd}, {"ctile", &t.ctile},
-        {"pskip", &t.pskip}, {"joh", &t.joh}, {"lat2", &t.lat2}, {"xst", &t.xst}, {"jsamp", &t.jsamp}, {"tilemax", &t.tilemax}};
+        {"pskip", &t.pskip}, {"joh", &t.joh}, {"lat2", &t.lat2}, {"xst", &t.xst}, {"jsamp", &t.jsamp}, {"tilemax", &t.tilemax},
+        {"j16", &t.j16}, {"j16pf", &t.j16pf}, {"j16nt", &t.j16nt}};
     // tokens are separated by ',', a token is key=value with the WHOLE key compared
     for (const char* p = e; *p;) {
         const char* end = strchr(p, ',');

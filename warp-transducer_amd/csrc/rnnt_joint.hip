@@ -3,8 +3,11 @@
 // unit, hence its own code object: see rnnt_host.h.
 #include <atomic>
 
+#include <type_traits>
+
 #include "rnnt_host.h"
 #include "rnnt_joint_kernels.h"
+#include "rnnt_joint16_kernels.h"
 
 namespace rnnt {
 
@@ -62,6 +65,9 @@ static rnntStatus_t run_gpu_joint(const typename Tag::store* f, const typename T
         // sampled row references + guard (rnnt_joint_kernels.h): no row-maximum pass in front of the Z kernel; the exact
         // pair runs behind it only when a row tripped the guard
         const bool sampled = !small && A >= 64 && tune().jsamp != 0;
+        const bool z16 = std::is_same<Tag, BF16>::value && (tune().j16 & 4) != 0 && !small && A % 8 == 0 && A >= 512 &&
+                         ((reinterpret_cast<uintptr_t>(f) | reinterpret_cast<uintptr_t>(g)) & 15u) == 0;
+        (void)z16;
         int* const gate = reinterpret_cast<int*>(p.rowmax + rows + 1);
         static std::atomic<int> call_counter{1};
         const int seq = call_counter.fetch_add(1, std::memory_order_relaxed);
@@ -79,8 +85,19 @@ static rnntStatus_t run_gpu_joint(const typename Tag::store* f, const typename T
     hipLaunchKernelGGL((joint_z_kernel<Tag, SS, VV, SAMP>), dim3(SS == 1 ? ((tiles + 3) / 4 + 7) / 8 * 8 : tiles, N),               \
                        dim3(SS == 1 ? 256 : SS * 64), 0, p.stream, f, g, p.rowmax, labels, input_lengths,        \
                        label_lengths, p.lp2, p.logz, maxT, maxU, p.Up, A, p.blank, tilesU, tiles, N, GATE, seq)
+#define RNNT_JZ16(SS, SAMP, GATE)                                                                                \
+    hipLaunchKernelGGL((joint_z16_kernel<SS, SAMP>), dim3(SS == 1 ? ((tiles + 3) / 4 + 7) / 8 * 8 : tiles, N),    \
+                       dim3(SS == 1 ? 256 : SS * 64), 0, p.stream, f, g, p.rowmax, labels, input_lengths,        \
+                       label_lengths, p.lp2, p.logz, maxT, maxU, p.Up, A, p.blank, tilesU, tiles, N, GATE, seq)
 #define RNNT_JZ_ALL(SAMP, GATE)                                                                                  \
         do {                                                                                                    \
+            if constexpr (std::is_same<Tag, BF16>::value) {                                                      \
+                if (z16) {     /* bf16 storage on the bf16 matrix cores (rnnt_joint16_kernels.h) */              \
+                    if (S == 8) RNNT_JZ16(8, SAMP, GATE); else if (S == 4) RNNT_JZ16(4, SAMP, GATE);            \
+                    else RNNT_JZ16(1, SAMP, GATE);                                                              \
+                    break;                                                                                      \
+                }                                                                                               \
+            }                                                                                                   \
             if (S == 8) { if (vec) RNNT_JZ(8, true, SAMP, GATE); else RNNT_JZ(8, false, SAMP, GATE); }          \
             else if (S == 4) { if (vec) RNNT_JZ(4, true, SAMP, GATE); else RNNT_JZ(4, false, SAMP, GATE); }     \
             else { if (vec) RNNT_JZ(1, true, SAMP, GATE); else RNNT_JZ(1, false, SAMP, GATE); }                 \
@@ -108,6 +125,7 @@ static rnntStatus_t run_gpu_joint(const typename Tag::store* f, const typename T
 #undef RNNT_JMAX_ALL
 #undef RNNT_JZ
 #undef RNNT_JZ_ALL
+#undef RNNT_JZ16
         p.check();
     }
     mark(1);
@@ -155,10 +173,39 @@ static rnntStatus_t run_gpu_joint(const typename Tag::store* f, const typename T
         // 16-bit storage: the operand ping-pong doubles the AGPR count of these kernels (172 + 128 registers: one wavefront
         // per SIMD at four columns per lane); without it they keep two (DF) / three (DG) wavefronts per SIMD
         const bool pf_f = tn.jfpf != 0 && (sizeof(S) == 4 || NKf < 4), pf_g = tn.jgpf != 0 && (sizeof(S) == 4 || NKg < 4);
-        if (onehot)       { if (NKf == 4) RNNT_JDF(4, true, true); else if (NKf == 2) RNNT_JDF(2, true, true); else RNNT_JDF(1, true, true); }
+        bool df16 = false;
+        if constexpr (std::is_same<Tag, BF16>::value) {
+            df16 = (tn.j16 & 2) != 0 && A % 8 == 0 && (all4 & 15u) == 0 && A >= 512;
+            if (df16) {
+#define RNNT_JDF16(NN, PP)                                                                                       \
+    hipLaunchKernelGGL((joint_df16_kernel<NN, PP>), dim3((A + 128 * NN - 1) / (128 * NN), tilesT, N), dim3(256), 0, p.stream, \
+                       f, g, p.rowmax, p.wmat, grad_scale, labels, input_lengths, label_lengths, df, maxT, maxU, Upad, A, N, \
+                       p.blank, sfb)
+                if (tn.j16nt == 8) { if (tn.j16pf) RNNT_JDF16(8, true); else RNNT_JDF16(8, false); }
+                else { if (tn.j16pf) RNNT_JDF16(4, true); else RNNT_JDF16(4, false); }
+#undef RNNT_JDF16
+            }
+        }
+        if (df16) { /* launched above */ }
+        else if (onehot)  { if (NKf == 4) RNNT_JDF(4, true, true); else if (NKf == 2) RNNT_JDF(2, true, true); else RNNT_JDF(1, true, true); }
         else if (pf_f) { if (NKf == 4) RNNT_JDF(4, true, false); else if (NKf == 2) RNNT_JDF(2, true, false); else RNNT_JDF(1, true, false); }
         else              { if (NKf == 4) RNNT_JDF(4, false, false); else if (NKf == 2) RNNT_JDF(2, false, false); else RNNT_JDF(1, false, false); }
-        if (pf_g) { if (NKg == 4) RNNT_JDG(4, true); else if (NKg == 2) RNNT_JDG(2, true); else RNNT_JDG(1, true); }
+        // bf16 storage, rows of whole 16-byte packets: the bf16 matrix-core forms (rnnt_joint16_kernels.h)
+        bool dg16 = false;
+        if constexpr (std::is_same<Tag, BF16>::value) {
+            dg16 = (tn.j16 & 1) != 0 && A % 8 == 0 && (all4 & 15u) == 0 && A >= 512;
+            if (dg16) {
+#define RNNT_JDG16(NN, PP)                                                                                       \
+    hipLaunchKernelGGL((joint_dg16_kernel<NN, PP>), dim3((A + 128 * NN - 1) / (128 * NN), tilesU, N), dim3(256), 0, p.stream, \
+                       f, g, p.rowmax, p.wmat, grad_scale, input_lengths, label_lengths, dg, maxT, maxU, Upad, A, N,  \
+                       labels, p.blank, sgb, sgl)
+                if (tn.j16nt == 8) { if (tn.j16pf) RNNT_JDG16(8, true); else RNNT_JDG16(8, false); }
+                else { if (tn.j16pf) RNNT_JDG16(4, true); else RNNT_JDG16(4, false); }
+#undef RNNT_JDG16
+            }
+        }
+        if (dg16) { /* launched above */ }
+        else if (pf_g) { if (NKg == 4) RNNT_JDG(4, true); else if (NKg == 2) RNNT_JDG(2, true); else RNNT_JDG(1, true); }
         else         { if (NKg == 4) RNNT_JDG(4, false); else if (NKg == 2) RNNT_JDG(2, false); else RNNT_JDG(1, false); }
 #undef RNNT_JDF
 #undef RNNT_JDG

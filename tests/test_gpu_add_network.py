@@ -357,3 +357,71 @@ def test_sixteen_bit_far_cells_and_scale(oracle, dtype):
     rdf, rdg = ref_gz.sum(axis=2), ref_gz.sum(axis=1)
     assert (np.abs(tf.grad.double().cpu().numpy() - rdf) <= 1e-3 + ulp * (np.abs(rdf) + 1.0)).all()
     assert (np.abs(tg.grad.double().cpu().numpy() - rdg) <= 1e-3 + ulp * (np.abs(rdg) + 1.0)).all()
+
+
+def _bf16_case(oracle, f, g, labels, tl, ll, blank, weights=None):
+    """RNNTLossAdd on bf16 tensors against the oracle on the ROUNDED inputs (loss 1e-4 relative; gradients within the
+    storage rounding of the exact sums, the bound of test_sixteen_bit_activations)."""
+    from warprnnt_pytorch.add_network import RNNTLossAdd
+    dev = torch.device("cuda:0")
+    tf = torch.tensor(f, device=dev).to(torch.bfloat16).requires_grad_(True)
+    tg = torch.tensor(g, device=dev).to(torch.bfloat16).requires_grad_(True)
+    loss = RNNTLossAdd(blank=blank, reduction="none")(tf, tg, torch.tensor(labels, device=dev), torch.tensor(tl, device=dev),
+                                                      torch.tensor(ll, device=dev))
+    w = torch.ones_like(loss) if weights is None else torch.tensor(weights, device=dev, dtype=loss.dtype)
+    (loss * w).sum().backward()
+    fr, gr = tf.detach().double().cpu().numpy(), tg.detach().double().cpu().numpy()
+    ref_c, ref_gz = oracle.rnnt_logits(fr[:, :, None, :] + gr[:, None, :, :], labels, tl, ll, blank)
+    ref_gz = ref_gz * w.double().cpu().numpy()[:, None, None, None]
+    assert np.abs(loss.detach().double().cpu().numpy() - ref_c).max() <= 1e-4 * max(1.0, np.abs(ref_c).max())
+    T, U = f.shape[1], g.shape[1]
+    rdf, rdg = ref_gz.sum(axis=2), ref_gz.sum(axis=1)
+    scale = float(np.abs(w.cpu().numpy()).max())
+    edf = np.abs(tf.grad.double().cpu().numpy() - rdf) - (2e-4 * scale * max(1.0, U / 32) + 2.0 ** -8 * np.abs(rdf) + 1e-6)
+    edg = np.abs(tg.grad.double().cpu().numpy() - rdg) - (2e-4 * scale * max(1.0, T / 32) + 2.0 ** -8 * np.abs(rdg) + 1e-6)
+    assert edf.max() <= 0, (edf.max(), np.unravel_index(edf.argmax(), edf.shape))
+    assert edg.max() <= 0, (edg.max(), np.unravel_index(edg.argmax(), edg.shape))
+    return tf.grad, tg.grad
+
+
+@pytest.mark.parametrize("shape", [
+    (2, 33, 21, 512),      # smallest vocabulary of the bf16 matrix-core kernels; second contraction step half masked
+    (3, 17, 9, 520),       # a partial last column block (520 = 4 x 128 + 8), T and U below one step
+    (2, 50, 41, 1024),     # three steps over the label rows, the last one clamped to the weight row's end (Upad = 48)
+    (2, 16, 16, 640),      # exactly one step either way
+    (2, 47, 33, 2048),     # one label row past two steps; vocabulary split over wavefronts in the Z kernel
+    (1, 150, 21, 5000),    # the benchmark shape of one sample
+    (2, 130, 70, 768),     # several tiles of Z in both directions, ragged lengths
+    (4, 9, 3, 4096),       # tiny lattice, wide vocabulary
+])
+def test_bf16_matrix_core_kernels(oracle, shape):
+    """bf16 storage with rows of whole 16-byte packets and 512 symbols or more runs Z, DF and DG on v_mfma_f32_32x32x16_bf16
+    (rnnt_joint16_kernels.h: operands split into hi + lo, fragments packed from the packets).  Structural edges of those
+    kernels: contraction steps of sixteen rows with masked halves, the clamped second half of a weight row, partial
+    column blocks, labels that fall -- or do not fall -- into a wavefront's columns (dense labels on a small range
+    included), blank at the first / a middle / the last column, ragged lengths, per-sample grad_output."""
+    N, T, U, A = shape
+    f, g, labels, tl, ll, blank = problem(shape, sum(shape) + 11)
+    _bf16_case(oracle, f, g, labels, tl, ll, blank)
+    # labels crowded into one column block (every step of DF's label pass hits), blank in the last column, weighted samples
+    rng = np.random.default_rng(A + U)
+    labels2 = rng.integers(128, 128 + 40, size=labels.shape).astype(np.int32)
+    labels2[:, ::3] = labels2[:, :1]                               # repeated labels
+    _bf16_case(oracle, f, g, labels2, tl, ll, A - 1, weights=np.linspace(0.5, -1.5, N))
+    # blank in the first column
+    labels3 = labels.copy(); labels3[labels3 == 0] = 1
+    _bf16_case(oracle, f, g, labels3, tl, ll, 0)
+
+
+def test_bf16_matrix_core_kernels_on_peaked_rows(oracle):
+    """Peaked distributions are where a single bf16 operand would show (few significant terms in Z, cancellation between the
+    GEMM term and its correction in the blank / label columns): logits scaled by 6, and rows that exceed their sampled
+    reference -- inside the guard (sampled reference kept) and beyond it (exact pass), both through the bf16 kernels."""
+    shape = (2, 40, 24, 1024)
+    f, g, labels, tl, ll, blank = problem(shape, 5)
+    _bf16_case(oracle, f * 4.0, g * 4.0, labels, tl, ll, blank)
+    for bump in (20.0, 70.0):
+        f2, g2 = f.copy(), g.copy()
+        f2[:, ::3, 700] += bump                                     # beyond the first 32 columns: not in the sampled reference
+        g2[:, 1::2, 900] += bump
+        _bf16_case(oracle, f2, g2, labels, tl, ll, blank)

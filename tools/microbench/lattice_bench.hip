@@ -14,7 +14,7 @@ __global__ __launch_bounds__(256) void hog_copy(const u32x4* __restrict__ in, u3
 }
 int main(int argc, char** argv) {
     const int N = argc > 1 ? atoi(argv[1]) : 16, T = argc > 2 ? atoi(argv[2]) : 1500, U = argc > 3 ? atoi(argv[3]) : 41;
-    const int Up = (U + 63) / 64 * 64, W = Up / 64;
+    const int Up = lat_stride(U), W = (Up + 63) / 64;
     const size_t Dp = lat_rows(T, U);
     LogPair<float>* cells; float* alpha; float* beta; double *offa, *offb, *llf, *llb; float* costs; int *xlen, *ylen;
     CK(hipMalloc(&cells, N * Dp * Up * 8)); CK(hipMalloc(&beta, (N * Dp * Up + Up + 64) * 4)); CK(hipMalloc(&alpha, (N * Dp * Up + Up + 64) * 4));
@@ -31,7 +31,7 @@ int main(int argc, char** argv) {
     auto launch = [&] {
         const int cols = argc > 4 ? atoi(argv[4]) : 2;          // columns per lane for U > 64
         if (W == 1) hipLaunchKernelGGL((lattice_kernel<float, 1, 1>), dim3(N * 2), dim3(64), 0, ls, cells, alpha, beta, offa, offb, llf, llb, costs, xlen, ylen, T, U, Up, 2);
-        else if (cols == 1) hipLaunchKernelGGL((lattice_kernel<float, 8, 1>), dim3(N * 2), dim3(Up), 0, ls, cells, alpha, beta, offa, offb, llf, llb, costs, xlen, ylen, T, U, Up, 2);
+        else if (cols == 1) hipLaunchKernelGGL((lattice_kernel<float, 8, 1>), dim3(N * 2), dim3(W * 64), 0, ls, cells, alpha, beta, offa, offb, llf, llb, costs, xlen, ylen, T, U, Up, 2);
         else if (lat_waves(Up, 2) <= 4) hipLaunchKernelGGL((lattice_kernel<float, 4, 2>), dim3(N * 2), dim3(lat_waves(Up, 2) * 64), 0, ls, cells, alpha, beta, offa, offb, llf, llb, costs, xlen, ylen, T, U, Up, 2);
         else hipLaunchKernelGGL((lattice_kernel<float, 8, 2>), dim3(N * 2), dim3(lat_waves(Up, 2) * 64), 0, ls, cells, alpha, beta, offa, offb, llf, llb, costs, xlen, ylen, T, U, Up, 2);
     };

@@ -33,8 +33,8 @@ struct Layout {
 // materialised path uses, so a plan carved with joint = true is valid for both.
 static Layout make_layout(int maxT, int maxU, int N, size_t lat, bool joint) {
     const size_t D = lat_rows(maxT, maxU);      // diagonals + padding rows
-    const size_t Up = (static_cast<size_t>(maxU) + 63) / 64 * 64;   // one 64-lane row per wavefront
-    const size_t W = Up / 64;
+    const size_t Up = lat_stride(maxU);         // row stride of the skewed arrays
+    const size_t W = (Up + 63) / 64;            // wavefronts of a lattice block at one column per lane
     const size_t sk = D * Up * N;               // skewed lattice cells
     Layout l{};
     size_t o = 0;
@@ -236,14 +236,14 @@ static bool make_plan(Plan<C>& p, int A, int N, const rnntOptions& opt, void* wo
     if (static_cast<long long>(p.maxT) * p.maxU > 0x7fffffffLL / 4) return false;
     if (joint && N > kGridSamples) return false;   // (the additive-joint kernels keep the samples on ONE grid dimension)
     if (static_cast<long long>(N) * 2 > 0x7fffffffLL) return false;   // lattice kernel: 2 N blocks on gridDim.x
-    p.Up = ((p.maxU + 63) / 64) * 64;
+    p.Up = lat_stride(p.maxU);
     // one sample's skewed lp2 array is addressed through a buffer descriptor with a 32-bit size
     if (lat_rows(p.maxT, p.maxU) * p.Up * sizeof(LogPair<C>) >= (1ull << 31)) return false;
     // lattice kernel form: one wavefront for maxU <= 64; one column per lane while every wavefront of the block
     // has a SIMD to itself (maxU <= 256), two columns per lane beyond (measured, ns per diagonal at T = 1500,
     // one / two columns: U=128 79 / 97, U=192 93 / 111, U=256 120 / 117, U=301 148 / 139, U=512 205 / 188)
     const int lat2 = tune().lat2 >= 0 ? tune().lat2 : (p.Up > 256 ? 1 : 0);
-    p.lat_cols = p.Up == 64 ? 1 : ((p.Up > 512 || lat2) ? 2 : 1);
+    p.lat_cols = p.Up <= 64 ? 1 : ((p.Up > 512 || lat2) ? 2 : 1);
     p.lat_w = lat_waves(p.Up, p.lat_cols);
     p.lat_sh = lat_col_shift(p.lat_cols);
     p.cells_per_sample = p.maxT * p.maxU;
@@ -275,7 +275,7 @@ template <typename C> static void launch_lattice(Plan<C>& p, bool with_beta) {
     hipLaunchKernelGGL((lattice_kernel<C, MW, CC>), dim3(p.N * dirs), dim3(p.lat_w * 64), 0, p.stream, p.lp2,          \
                        p.alpha, p.beta, p.offa, p.offb, p.llf, p.llb, p.costs_dev, p.input_lengths, p.label_lengths,  \
                        p.maxT, p.maxU, p.Up, dirs)
-    if (p.Up == 64) RNNT_LATTICE(1, 1);                            // one wavefront, no synchronisation
+    if (p.Up <= 64) RNNT_LATTICE(1, 1);                            // one wavefront, no synchronisation
     else if (p.lat_cols == 1) RNNT_LATTICE(8, 1);                  // maxU <= 512, one column per lane
     else if (p.lat_w <= 4) RNNT_LATTICE(4, 2);                     // two columns per lane, one wavefront per SIMD
     else RNNT_LATTICE(8, 2);                                       // maxU <= 1024 in at most 8 wavefronts
@@ -292,7 +292,7 @@ template <typename C> static void launch_coef(Plan<C>& p, bool joint = false, bo
     const int planes = onehot ? joint_planes_onehot(p.maxU) : (joint ? 2 : 1);
     if (p.maxU <= 48 || !tune().ctile) {
         // small lattices: one thread per skewed cell, scattered record store
-        const long long skew_cells = static_cast<long long>(p.maxT + p.maxU - 1) * p.Up;
+        const long long skew_cells = static_cast<long long>(p.maxT + p.maxU - 1) * ((p.Up + 63) / 64) * 64;   // whole 64-column segments
         for (int b0 = 0; b0 < p.N; b0 += kGridSamples) {       // (samples on gridDim.y: slices of the batch)
             const dim3 cgrid(static_cast<unsigned>(((skew_cells + 255) / 256 + 7) / 8 * 8),    // multiple of 8: XCD-aware remap
                              p.N - b0 < kGridSamples ? p.N - b0 : kGridSamples);

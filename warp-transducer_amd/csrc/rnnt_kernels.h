@@ -24,7 +24,7 @@
 //
 // Lattice side data lives in the caller's workspace in a DIAGONAL-SKEWED layout:
 //   cell(b, t, u) -> ((b * Dp + kLatPad + (t + u)) * Up + u),  Dp = maxT + maxU - 1 + 2*kLatPad,
-//   Up = 64*ceil(maxU/64)                                         (lat_index below)
+//   Up = 8*ceil(maxU/8)                                           (lat_index below)
 // so that the lanes of the lattice wavefront (consecutive u on one anti-diagonal t+u = n)
 // touch consecutive addresses.  All indices are 64-bit (the reference's are 32-bit int:
 // gpu_rnnt_kernel.h:7-8,161,174).
@@ -91,6 +91,10 @@ __device__ __forceinline__ void coef_lens(const int* __restrict__ xlen, const in
 // any batch size): `b0` = first sample of the slice.
 constexpr int kGridSamples = 65535;
 constexpr int kLatPad = 16;
+// Row stride of the skewed arrays: maxU rounded up to 8 cells (16-byte aligned rows for every element type; the
+// lattice lanes past the row are parked on an out-of-range buffer offset, see lattice_kernel).  Until round 3 rows
+// were padded to whole 64-lane wavefronts, which tripled the lattice workspace at U = 21.
+__host__ __device__ inline int lat_stride(int maxU) { return (maxU + 7) & ~7; }
 __host__ __device__ inline size_t lat_rows(int maxT, int maxU) { return static_cast<size_t>(maxT) + maxU - 1 + 2 * kLatPad; }
 // element index of (b, n, u) in a skewed array with row stride Up
 __host__ __device__ inline size_t lat_index(int b, int n, int u, int maxT, int maxU, int Up) {
@@ -1095,16 +1099,19 @@ __global__ __launch_bounds__(256) void coef_cell_kernel(
     const unsigned per = gridDim.x >> 3;
     const unsigned blk = (blockIdx.x & 7u) * per + (blockIdx.x >> 3);
     const int D = maxT + maxU - 1;
-    const long long i0 = (static_cast<long long>(blk) * 4 + uniform(threadIdx.x >> 6)) * 64;   // this wavefront's first cell
-    if (i0 >= static_cast<long long>(D) * Up) return;
-    const int n = uniform(static_cast<int>(i0 / Up));
-    const int u = static_cast<int>(i0 - static_cast<long long>(n) * Up) + (threadIdx.x & 63);
+    // a wavefront takes one 64-column segment of one skewed row (rows are Up = 8 ceil(maxU / 8) cells long)
+    const int segs = (Up + 63) >> 6;
+    const long long w = static_cast<long long>(blk) * 4 + uniform(threadIdx.x >> 6);
+    if (w >= static_cast<long long>(D) * segs) return;
+    const int n = uniform(static_cast<int>(w / segs));
+    const int useg = uniform(static_cast<int>(w - static_cast<long long>(n) * segs)) * 64;
+    const int u = useg + static_cast<int>(threadIdx.x & 63);
     const int t = n - u;
     const size_t plane = static_cast<size_t>(N) * maxT * Upad;
     if (u >= maxU || t < 0 || t >= maxT) return;              // not a row of the tensor
     int Tb, Ub;
     coef_lens(xlen, ylen, b, maxT, maxU, Tb, Ub);
-    const int wu = uniform(static_cast<int>(i0 - static_cast<long long>(n) * Up) >> lsh);    // this wavefront's 64 columns share it
+    const int wu = uniform(useg >> lsh);                      // this wavefront's 64 columns share it
     const CoefRaw<L> raw = coef_fetch<L>(lp2, logz, alpha_arr, beta, offa, offb, labels, b, n, u, maxT, maxU, Up, lw, lsh, wu);
     const Cell<L> o = coef_eval<L>(raw, ll_fwd[b], t, u, Tb, Ub, fastemit);
     if (offsets != nullptr) {

@@ -455,7 +455,9 @@ long long rnnt_host_staging_release(void);
  * (compute_rnnt_loss_fwd ... compute_rnnt_loss_bwd, one collect after both) counts as ONE call:
  * ms[0..2] come from the forward call, ms[3] from the backward call, and what the caller
  * enqueued between the two is inside ms[4] only.
- * Process-global, not thread-safe; meant for bench.py only. */
+ * Process-global: ONE set of timers and events for the library.  Calls from several threads are safe (a profiled call
+ * holds the library's profiling mutex while it records, so profiled calls are serialised), but the accumulated times only
+ * mean something with one calling thread at a time; meant for bench.py. */
 void rnnt_profile_enable(int on);
 void rnnt_profile_collect(void);   /* after synchronising a compute_rnnt_loss_async call: add its times */
 void rnnt_profile_reset(void);

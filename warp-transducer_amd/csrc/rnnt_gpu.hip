@@ -20,6 +20,7 @@
 namespace rnnt {
 
 Profile g_prof;
+std::mutex g_prof_mu;
 Ranges g_ranges;
 
 // Stage 1 (materialised path): log-softmax statistics of every (b,t,u) row.
@@ -28,6 +29,29 @@ static void launch_row_stats(Plan<typename Tag::comp>& p, const typename Tag::st
     using S = typename Tag::store;
     const Tune& tn = tune();
     const size_t row_bytes = static_cast<size_t>(p.A) * sizeof(S);
+    // short rows under a wide lattice (c4): 2-D cell tiles, results stored along the anti-diagonals
+    if (tn.tile2d && p.offsets == nullptr && row_bytes % 8 == 0 && (reinterpret_cast<uintptr_t>(acts) & 7u) == 0 &&
+        row_bytes <= 208 && p.maxU >= 64) {
+        // tile shape: 8 x 32 (64-byte runs along the anti-diagonals, pieces of 32 rows) | 16 x 16 (128-byte runs, pieces of 16 rows)
+        const bool sq = tn.tile2d == 2;
+        const int TT = sq ? 16 : 8, TU = sq ? 16 : 32;
+        const int tilesT = (p.maxT + TT - 1) / TT, tilesU = (p.maxU + TU - 1) / TU;
+        const unsigned long long ntile = static_cast<unsigned long long>(p.N) * tilesT * tilesU;
+        const int piece = (static_cast<int>(TU * row_bytes) + 15 + 15) / 16 * 16;      // covering packets of a piece at any phase
+        if (ntile < (1ull << 31)) {
+            const unsigned xgrid = static_cast<unsigned>((ntile + 7) / 8 * 8);
+            // (the 256 results overlay the tile: TT rows of TU + 1 {pair, log Z} records of the lattice type)
+            const size_t lds2 = static_cast<size_t>(TT) * piece > 8192 ? static_cast<size_t>(TT) * piece : 8192;
+#define RNNT_TILE2D(T1, U1)                                                                                       \
+    hipLaunchKernelGGL((row_stats_tile2d_kernel<Tag, T1, U1>), dim3(xgrid), dim3(256), lds2, p.stream, acts, p.labels, \
+                       p.input_lengths, p.label_lengths, p.lp2, p.logz, p.maxT, p.maxU, p.Up, p.A, p.blank, p.N, tilesT, \
+                       tilesU, piece)
+            if (sq) RNNT_TILE2D(16, 16); else RNNT_TILE2D(8, 32);
+#undef RNNT_TILE2D
+            p.check();
+            return;
+        }
+    }
     if (tn.tile && vec_ok && row_bytes <= static_cast<size_t>(tn.tilemax)) {
         // short rows: LDS-tile kernel; smallest lane group G whose tile of 256/G rows fits the budget
         const size_t budget = static_cast<size_t>(tn.tilekb) * 1024;
@@ -289,6 +313,8 @@ static rnntStatus_t run_gpu(const typename Tag::store* acts, typename Tag::store
     if (p.offsets != nullptr && do_bwd && (!vec_ok || (pa & 15u) || (pg & 15u) || A > (1 << 23)))
         return RNNT_STATUS_INVALID_VALUE;
 
+    std::unique_lock<std::mutex> prof_lock;
+    if (g_prof.on) prof_lock = std::unique_lock<std::mutex>(g_prof_mu);
     const bool prof = prof_prepare();
     const bool ranges = ranges_prepare();
     static const char* const kStages[4] = {"warprnnt:row_stats", "warprnnt:lattice", "warprnnt:coefficients", "warprnnt:gradient"};
@@ -587,20 +613,24 @@ long long rnnt_host_staging_release(void) {
 }
 
 void rnnt_profile_enable(int on) {
+    std::lock_guard<std::mutex> g(g_prof_mu);
     g_prof.on = (on & 1) != 0;            // bit 0: stage timers (HIP events)
     g_ranges.mode = (on & 2) ? 1 : 0;     // bit 1: roctx ranges around the stages
 }
 
 void rnnt_profile_collect(void) {
+    std::lock_guard<std::mutex> g(g_prof_mu);
     if (g_prof.on && g_prof.ready && g_prof.pending) prof_accumulate();
 }
 
 void rnnt_profile_reset(void) {
+    std::lock_guard<std::mutex> g(g_prof_mu);
     for (double& m : g_prof.ms) m = 0.0;
     g_prof.calls = 0;
 }
 
 int rnnt_profile_read(double* ms, int n) {
+    std::lock_guard<std::mutex> g(g_prof_mu);
     for (int i = 0; i < n && i < 5; ++i) ms[i] = g_prof.ms[i];
     return g_prof.calls;
 }

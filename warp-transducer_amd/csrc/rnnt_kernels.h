@@ -604,6 +604,120 @@ __global__ __launch_bounds__(256) void row_stats_tile_kernel(
 }
 
 // ------------------------------------------------------------------------------------------
+// Pass A, 2-D CELL-TILE form for short rows under wide lattices (c4: 200-byte rows, U = 301).  The flat tile kernel
+// above streams 256 consecutive rows -- less than one time row of such a lattice -- so its 256 results belong to 256
+// different anti-diagonals and leave as two scattered stores per row, 64 distinct lines per store instruction: request
+// rate, not bytes, is what bounds it there (1.05 ms as shipped, 0.90 with coalesced stores, 0.78 with
+// none).  Here a block owns TT time rows x TU label rows of ONE sample: TT contiguous pieces of TU rows each, loaded as
+// the aligned 16-byte packets that cover them (all requested before the first is stored, as above), one lane per row
+// for the reduction, and the 256 results are turned through LDS so that they leave ALONG the anti-diagonals: the
+// cells (t0 + i, u0 + d - i), i = 0 .. TT-1, of a tile's diagonal d are TT consecutive elements of a skewed row.
+// Rows are whole 8-byte words (A * s % 8 == 0, 8-byte aligned tensor); non-packed layout; LDS = TT * piece + results.
+// grid = (8 * ceil(tiles / 8), 1, 1) with tiles = N * ceil(maxT / TT) * ceil(maxU / TU), XCD-aware tile order, block = 256.
+template <typename Tag, int TT, int TU>
+__global__ __launch_bounds__(256) void row_stats_tile2d_kernel(
+        const typename Tag::store* __restrict__ acts, const int* __restrict__ labels,
+        const int* __restrict__ xlen, const int* __restrict__ ylen,
+        LogPair<typename Tag::comp>* __restrict__ lp2, typename Tag::comp* __restrict__ logz,
+        int maxT, int maxU, int Up, int A, int blank, int N, int tilesT, int tilesU, int piece_bytes) {
+    using S = typename Tag::store;
+    using C = typename Tag::comp;
+    static_assert(TT * TU == 256, "one lane per row");
+    constexpr int H = 8 / sizeof(S);                           // elements per 8-byte word
+    constexpr int PK = (TU * 208 + 30 + 4095) / 4096;          // packets per thread and piece (rows <= 208 bytes: host check)
+    extern __shared__ uint4 tile2_raw[];
+    // (the results overlay the tile once every lane has finished reading it: 3 KB less LDS, three blocks per CU at c4's size)
+    LogPair<C> (*out_lp)[TU + 1] = reinterpret_cast<LogPair<C> (*)[TU + 1]>(tile2_raw);
+    C (*out_lz)[TU + 1] = reinterpret_cast<C (*)[TU + 1]>(reinterpret_cast<char*>(tile2_raw) + sizeof(LogPair<C>) * TT * (TU + 1));
+    const unsigned ntile = static_cast<unsigned>(N) * tilesT * tilesU;
+    const unsigned per = (ntile + 7u) >> 3;
+    const unsigned tile_id = (blockIdx.x & 7u) * per + (blockIdx.x >> 3);
+    if (tile_id >= ntile) return;                              // grid is rounded up to a multiple of 8
+    const int tu = static_cast<int>(tile_id % tilesU), tt = static_cast<int>((tile_id / tilesU) % tilesT);
+    const int b = static_cast<int>(tile_id / (static_cast<unsigned>(tilesU) * tilesT));
+    const int t0 = tt * TT, u0 = tu * TU;
+    const int Tb = clamp_len(xlen[b], maxT), Ub = clamp_len(ylen[b] + 1, maxU);
+    if (t0 >= Tb || u0 >= Ub) return;                          // tile of padding: never read
+    const int nu = Ub - u0 < TU ? Ub - u0 : TU;                // label rows of this tile inside the sample
+    const int nt = Tb - t0 < TT ? Tb - t0 : TT;
+    const size_t row_bytes = static_cast<size_t>(A) * sizeof(S);
+    const int span = nu * static_cast<int>(row_bytes);         // bytes of one piece
+
+    // ---- global -> LDS: piece i = rows (t0 + i, u0 .. u0 + nu - 1), kept at the 16-byte phase of its global address
+    const char* base0 = reinterpret_cast<const char*>(acts) + ((static_cast<size_t>(b) * maxT + t0) * maxU + u0) * row_bytes;
+    const size_t tstride = static_cast<size_t>(maxU) * row_bytes;
+    uint4 pk[TT][PK];
+#pragma unroll
+    for (int i = 0; i < TT; ++i) {
+        const char* start = base0 + static_cast<size_t>(i < nt ? i : nt - 1) * tstride;
+        const int phase = static_cast<int>(reinterpret_cast<uintptr_t>(start) & 15u);
+        const u32x4* src = reinterpret_cast<const u32x4*>(start - phase);
+        const int npk = (phase + span + 15) >> 4;              // <= piece_bytes / 16 <= 256 PK
+#pragma unroll
+        for (int k = 0; k < PK; ++k) {
+            const int pi = k * 256 + static_cast<int>(threadIdx.x);
+            pk[i][k] = load_packet<true>(src + (pi < npk ? pi : npk - 1));
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    const int i_row = threadIdx.x / TU, j_row = threadIdx.x % TU;     // this lane's row of the tile
+    const int u = u0 + j_row, t = t0 + i_row;
+    int lab = labels[maxU > 1 ? static_cast<size_t>(b) * (maxU - 1) + (u < maxU - 1 ? u : maxU - 2) : 0];
+    char* lds = reinterpret_cast<char*>(tile2_raw);
+#pragma unroll
+    for (int i = 0; i < TT; ++i) {
+        const char* start = base0 + static_cast<size_t>(i < nt ? i : nt - 1) * tstride;
+        const int phase = static_cast<int>(reinterpret_cast<uintptr_t>(start) & 15u);
+        const int npk = (phase + span + 15) >> 4;
+        uint4* dst = reinterpret_cast<uint4*>(lds + static_cast<size_t>(i) * piece_bytes);
+#pragma unroll
+        for (int k = 0; k < PK; ++k) {
+            const int pi = k * 256 + static_cast<int>(threadIdx.x);
+            if (pi < npk) dst[pi] = pk[i][k];
+        }
+    }
+    __syncthreads();
+
+    // ---- one lane per row: rows are whole 8-byte words at any 8-byte phase
+    const bool live = i_row < nt && j_row < nu;
+    C m = neg_inf<C>(), sum = 0, shift = 0;
+    {
+        const char* start = base0 + static_cast<size_t>(i_row < nt ? i_row : nt - 1) * tstride;
+        const int phase = static_cast<int>(reinterpret_cast<uintptr_t>(start) & 15u);
+        const char* rowp = lds + static_cast<size_t>(i_row) * piece_bytes + phase + static_cast<size_t>(j_row < nu ? j_row : nu - 1) * row_bytes;
+        constexpr int KW = sizeof(S) == 2 ? kTileRegWords / 2 : kTileRegWords;
+        tile_reduce_words<Tag, uint2, H, KW>(reinterpret_cast<const uint2*>(rowp), A / H, 0, 1, m, shift, sum,
+                                             [](const uint2& w, C* v, int) { unpack_half<Tag>(w, v); });
+        const C logZ = shift + fast_log(sum);
+        const bool has_lab = u < Ub - 1;
+        lab = has_lab ? (lab < 0 ? 0 : (lab >= A ? A - 1 : lab)) : blank;
+        const S* rp = reinterpret_cast<const S*>(rowp);
+        LogPair<C> rec;                                // lattice log-probs are kept in base 2
+        rec.x = vmax((load1<Tag>(rp + blank) - logZ) * C(kLog2e), log_zero<C>());
+        rec.y = has_lab ? vmax((load1<Tag>(rp + lab) - logZ) * C(kLog2e), log_zero<C>()) : log_zero<C>();
+        __syncthreads();                               // every lane is done with the tile: the results may overlay it
+        if (live) {
+            out_lp[i_row][j_row] = rec;
+            out_lz[i_row][j_row] = logZ;
+        }
+    }
+    __syncthreads();
+    // ---- results leave along the anti-diagonals: slot = (diagonal d of the tile, time row i), TT consecutive lanes per diagonal
+    constexpr int NSLOT = (TT + TU - 1) * TT;
+#pragma unroll
+    for (int s0 = 0; s0 < NSLOT; s0 += 256) {
+        const int slot = s0 + static_cast<int>(threadIdx.x);
+        const int d = slot / TT, i = slot % TT, j = d - i;
+        if (slot < NSLOT && j >= 0 && j < nu && i < nt) {
+            const size_t idx = lat_index(b, t0 + u0 + d, u0 + j, maxT, maxU, Up);
+            lp2[idx] = out_lp[i][j];
+            logz[idx] = out_lz[i][j];
+        }
+    }
+    (void)t;
+}
+
+// ------------------------------------------------------------------------------------------
 // Lattice recursion.  grid = N * dirs (dirs = 2: the alpha block and the beta block of a sample
 // run concurrently; dirs = 1: alpha only, forward scoring), block = Up = 64*ceil(maxU/64)
 // threads; thread u owns lattice column u, a wavefront owns 64 columns.

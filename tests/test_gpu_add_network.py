@@ -359,13 +359,14 @@ def test_sixteen_bit_far_cells_and_scale(oracle, dtype):
     assert (np.abs(tg.grad.double().cpu().numpy() - rdg) <= 1e-3 + ulp * (np.abs(rdg) + 1.0)).all()
 
 
-def _bf16_case(oracle, f, g, labels, tl, ll, blank, weights=None):
+def _bf16_case(oracle, f, g, labels, tl, ll, blank, weights=None, dtype=torch.bfloat16):
     """RNNTLossAdd on bf16 tensors against the oracle on the ROUNDED inputs (loss 1e-4 relative; gradients within the
     storage rounding of the exact sums, the bound of test_sixteen_bit_activations)."""
     from warprnnt_pytorch.add_network import RNNTLossAdd
     dev = torch.device("cuda:0")
-    tf = torch.tensor(f, device=dev).to(torch.bfloat16).requires_grad_(True)
-    tg = torch.tensor(g, device=dev).to(torch.bfloat16).requires_grad_(True)
+    tf = torch.tensor(f, device=dev).to(dtype).requires_grad_(True)
+    tg = torch.tensor(g, device=dev).to(dtype).requires_grad_(True)
+    ulp = 2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11          # half an ulp of the STORED gradient, relative
     loss = RNNTLossAdd(blank=blank, reduction="none")(tf, tg, torch.tensor(labels, device=dev), torch.tensor(tl, device=dev),
                                                       torch.tensor(ll, device=dev))
     w = torch.ones_like(loss) if weights is None else torch.tensor(weights, device=dev, dtype=loss.dtype)
@@ -377,8 +378,8 @@ def _bf16_case(oracle, f, g, labels, tl, ll, blank, weights=None):
     T, U = f.shape[1], g.shape[1]
     rdf, rdg = ref_gz.sum(axis=2), ref_gz.sum(axis=1)
     scale = float(np.abs(w.cpu().numpy()).max())
-    edf = np.abs(tf.grad.double().cpu().numpy() - rdf) - (2e-4 * scale * max(1.0, U / 32) + 2.0 ** -8 * np.abs(rdf) + 1e-6)
-    edg = np.abs(tg.grad.double().cpu().numpy() - rdg) - (2e-4 * scale * max(1.0, T / 32) + 2.0 ** -8 * np.abs(rdg) + 1e-6)
+    edf = np.abs(tf.grad.double().cpu().numpy() - rdf) - (2e-4 * scale * max(1.0, U / 32) + ulp * np.abs(rdf) + 1e-6)
+    edg = np.abs(tg.grad.double().cpu().numpy() - rdg) - (2e-4 * scale * max(1.0, T / 32) + ulp * np.abs(rdg) + 1e-6)
     assert edf.max() <= 0, (edf.max(), np.unravel_index(edf.argmax(), edf.shape))
     assert edg.max() <= 0, (edg.max(), np.unravel_index(edg.argmax(), edg.shape))
     return tf.grad, tg.grad
@@ -394,23 +395,25 @@ def _bf16_case(oracle, f, g, labels, tl, ll, blank, weights=None):
     (2, 130, 70, 768),     # several tiles of Z in both directions, ragged lengths
     (4, 9, 3, 4096),       # tiny lattice, wide vocabulary
 ])
-def test_bf16_matrix_core_kernels(oracle, shape):
-    """bf16 storage with rows of whole 16-byte packets and 512 symbols or more runs Z, DF and DG on v_mfma_f32_32x32x16_bf16
-    (rnnt_joint16_kernels.h: operands split into hi + lo, fragments packed from the packets).  Structural edges of those
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_bf16_matrix_core_kernels(oracle, shape, dtype):
+    """16-bit storage (bf16 or fp16) with rows of whole 16-byte packets and 512 symbols or more runs Z, DF and DG on
+    v_mfma_f32_32x32x16_bf16 (rnnt_joint16_kernels.h: operands split into bf16 hi + lo whatever the storage type, fragments
+    packed from the packets).  Structural edges of those
     kernels: contraction steps of sixteen rows with masked halves, the clamped second half of a weight row, partial
     column blocks, labels that fall -- or do not fall -- into a wavefront's columns (dense labels on a small range
     included), blank at the first / a middle / the last column, ragged lengths, per-sample grad_output."""
     N, T, U, A = shape
     f, g, labels, tl, ll, blank = problem(shape, sum(shape) + 11)
-    _bf16_case(oracle, f, g, labels, tl, ll, blank)
+    _bf16_case(oracle, f, g, labels, tl, ll, blank, dtype=dtype)
     # labels crowded into one column block (every step of DF's label pass hits), blank in the last column, weighted samples
     rng = np.random.default_rng(A + U)
     labels2 = rng.integers(128, 128 + 40, size=labels.shape).astype(np.int32)
     labels2[:, ::3] = labels2[:, :1]                               # repeated labels
-    _bf16_case(oracle, f, g, labels2, tl, ll, A - 1, weights=np.linspace(0.5, -1.5, N))
+    _bf16_case(oracle, f, g, labels2, tl, ll, A - 1, weights=np.linspace(0.5, -1.5, N), dtype=dtype)
     # blank in the first column
     labels3 = labels.copy(); labels3[labels3 == 0] = 1
-    _bf16_case(oracle, f, g, labels3, tl, ll, 0)
+    _bf16_case(oracle, f, g, labels3, tl, ll, 0, dtype=dtype)
 
 
 def test_bf16_matrix_core_kernels_on_peaked_rows(oracle):

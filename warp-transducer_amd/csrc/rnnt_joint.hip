@@ -25,6 +25,7 @@ static rnntStatus_t run_gpu_joint(const typename Tag::store* f, const typename T
                                   float* costs_device, const float* grad_scale, void* workspace,
                                   const rnntOptions& opt, int phases, bool want_grad, float fastemit = 0.0f) {
     using S = typename Tag::store;
+    constexpr bool k16 = sizeof(typename Tag::store) == 2;    // bf16 / fp16 storage: the bf16 matrix-core kernels apply
     Plan<float> p;
     if (!make_plan(p, A, N, opt, workspace, labels, label_lengths, input_lengths, costs_device, /*joint=*/true))
         return RNNT_STATUS_INVALID_VALUE;
@@ -67,7 +68,7 @@ static rnntStatus_t run_gpu_joint(const typename Tag::store* f, const typename T
         // sampled row references + guard (rnnt_joint_kernels.h): no row-maximum pass in front of the Z kernel; the exact
         // pair runs behind it only when a row tripped the guard
         const bool sampled = !small && A >= 64 && tune().jsamp != 0;
-        const bool z16 = std::is_same<Tag, BF16>::value && (tune().j16 & 4) != 0 && !small && A % 8 == 0 && A >= 512 &&
+        const bool z16 = k16 && (tune().j16 & 4) != 0 && !small && A % 8 == 0 && A >= 512 &&
                          ((reinterpret_cast<uintptr_t>(f) | reinterpret_cast<uintptr_t>(g)) & 15u) == 0;
         (void)z16;
         int* const gate = reinterpret_cast<int*>(p.rowmax + rows + 1);
@@ -88,12 +89,12 @@ static rnntStatus_t run_gpu_joint(const typename Tag::store* f, const typename T
                        dim3(SS == 1 ? 256 : SS * 64), 0, p.stream, f, g, p.rowmax, labels, input_lengths,        \
                        label_lengths, p.lp2, p.logz, maxT, maxU, p.Up, A, p.blank, tilesU, tiles, N, GATE, seq)
 #define RNNT_JZ16(SS, SAMP, GATE)                                                                                \
-    hipLaunchKernelGGL((joint_z16_kernel<SS, SAMP>), dim3(SS == 1 ? ((tiles + 3) / 4 + 7) / 8 * 8 : tiles, N),    \
+    hipLaunchKernelGGL((joint_z16_kernel<Tag, SS, SAMP>), dim3(SS == 1 ? ((tiles + 3) / 4 + 7) / 8 * 8 : tiles, N),    \
                        dim3(SS == 1 ? 256 : SS * 64), 0, p.stream, f, g, p.rowmax, labels, input_lengths,        \
                        label_lengths, p.lp2, p.logz, maxT, maxU, p.Up, A, p.blank, tilesU, tiles, N, GATE, seq)
 #define RNNT_JZ_ALL(SAMP, GATE)                                                                                  \
         do {                                                                                                    \
-            if constexpr (std::is_same<Tag, BF16>::value) {                                                      \
+            if constexpr (k16) {                                                      \
                 if (z16) {     /* bf16 storage on the bf16 matrix cores (rnnt_joint16_kernels.h) */              \
                     if (S == 8) RNNT_JZ16(8, SAMP, GATE); else if (S == 4) RNNT_JZ16(4, SAMP, GATE);            \
                     else RNNT_JZ16(1, SAMP, GATE);                                                              \
@@ -176,11 +177,11 @@ static rnntStatus_t run_gpu_joint(const typename Tag::store* f, const typename T
         // per SIMD at four columns per lane); without it they keep two (DF) / three (DG) wavefronts per SIMD
         const bool pf_f = tn.jfpf != 0 && (sizeof(S) == 4 || NKf < 4), pf_g = tn.jgpf != 0 && (sizeof(S) == 4 || NKg < 4);
         bool df16 = false;
-        if constexpr (std::is_same<Tag, BF16>::value) {
+        if constexpr (k16) {
             df16 = (tn.j16 & 2) != 0 && A % 8 == 0 && (all4 & 15u) == 0 && A >= 512;
             if (df16) {
 #define RNNT_JDF16(NN, PP)                                                                                       \
-    hipLaunchKernelGGL((joint_df16_kernel<NN, PP>), dim3((A + 128 * NN - 1) / (128 * NN), tilesT, N), dim3(256), 0, p.stream, \
+    hipLaunchKernelGGL((joint_df16_kernel<Tag, NN, PP>), dim3((A + 128 * NN - 1) / (128 * NN), tilesT, N), dim3(256), 0, p.stream, \
                        f, g, p.rowmax, p.wmat, grad_scale, labels, input_lengths, label_lengths, df, maxT, maxU, Upad, A, N, \
                        p.blank, sfb)
                 if (tn.j16nt == 8) { if (tn.j16pf) RNNT_JDF16(8, true); else RNNT_JDF16(8, false); }
@@ -194,11 +195,11 @@ static rnntStatus_t run_gpu_joint(const typename Tag::store* f, const typename T
         else              { if (NKf == 4) RNNT_JDF(4, false, false); else if (NKf == 2) RNNT_JDF(2, false, false); else RNNT_JDF(1, false, false); }
         // bf16 storage, rows of whole 16-byte packets: the bf16 matrix-core forms (rnnt_joint16_kernels.h)
         bool dg16 = false;
-        if constexpr (std::is_same<Tag, BF16>::value) {
+        if constexpr (k16) {
             dg16 = (tn.j16 & 1) != 0 && A % 8 == 0 && (all4 & 15u) == 0 && A >= 512;
             if (dg16) {
 #define RNNT_JDG16(NN, PP)                                                                                       \
-    hipLaunchKernelGGL((joint_dg16_kernel<NN, PP>), dim3((A + 128 * NN - 1) / (128 * NN), tilesU, N), dim3(256), 0, p.stream, \
+    hipLaunchKernelGGL((joint_dg16_kernel<Tag, NN, PP>), dim3((A + 128 * NN - 1) / (128 * NN), tilesU, N), dim3(256), 0, p.stream, \
                        f, g, p.rowmax, p.wmat, grad_scale, input_lengths, label_lengths, dg, maxT, maxU, Upad, A, N,  \
                        labels, p.blank, sgb, sgl)
                 if (tn.j16nt == 8) { if (tn.j16pf) RNNT_JDG16(8, true); else RNNT_JDG16(8, false); }

@@ -1,4 +1,7 @@
-// rnnt_joint16_kernels.h -- the additive-joint GEMMs on the bf16 matrix cores, for bf16 STORAGE of f, g, df, dg.
+// rnnt_joint16_kernels.h -- the additive-joint GEMMs on the bf16 matrix cores, for 16-bit STORAGE (bf16 or fp16) of f, g,
+// df, dg: the operands of the matrix cores are bf16 hi + lo pairs of fp32 values whatever the storage type is (fp16 has
+// neither the range for W <= e^40 nor for the sampled references), the storage type only decides how a packet is
+// unpacked and how a result is rounded.
 //
 // rnnt_joint_kernels.h runs the three contractions (Z = Ef Eg^T, DF = Ef .* (W Eg), DG = Eg .* (W^T Ef)) on
 // v_mfma_f32_32x32x2_f32, which issues at the fp32 VALU rate and does not overlap with VALU work: with 16-bit
@@ -50,31 +53,33 @@ __device__ __forceinline__ f32x16 mma_split(const u32x4& ah, const u32x4& al, co
 
 // A lane's packet of NT adjacent bf16 columns: 16 bytes (NT = 8: a wavefront owns 256 columns as eight tiles) or 8 bytes
 // (NT = 4: 128 columns, four tiles -- half the accumulators and operand registers, two wavefronts per SIMD).
-template <int NT> struct Packet16;
-template <> struct Packet16<8> {
+template <typename Tag, int NT> struct Packet16;
+template <typename Tag> struct Packet16<Tag, 8> {
     typedef uint4 type;
     static __device__ __forceinline__ uint4 load(const uint16_t* p) { return load_packet<false>(reinterpret_cast<const u32x4*>(p)); }
-    static __device__ __forceinline__ void unpack_to(const uint4& r, float* v) { unpack<BF16>(r, v); }
-    static __device__ __forceinline__ void store(uint16_t* p, const float* v) { store_packet<false>(reinterpret_cast<u32x4*>(p), pack<BF16>(v)); }
+    static __device__ __forceinline__ void unpack_to(const uint4& r, float* v) { unpack<Tag>(r, v); }
+    static __device__ __forceinline__ void store(uint16_t* p, const float* v) { store_packet<false>(reinterpret_cast<u32x4*>(p), pack<Tag>(v)); }
     static __device__ __forceinline__ void store_zero(uint16_t* p) { store_packet<false>(reinterpret_cast<u32x4*>(p), make_uint4(0, 0, 0, 0)); }
 };
-template <> struct Packet16<4> {
+template <typename Tag> struct Packet16<Tag, 4> {
     typedef uint2 type;
     static __device__ __forceinline__ uint2 load(const uint16_t* p) { return *reinterpret_cast<const uint2*>(p); }
-    static __device__ __forceinline__ void unpack_to(const uint2& r, float* v) { unpack_half<BF16>(r, v); }
+    static __device__ __forceinline__ void unpack_to(const uint2& r, float* v) { unpack_half<Tag>(r, v); }
     static __device__ __forceinline__ void store(uint16_t* p, const float* v) {
-        *reinterpret_cast<uint2*>(p) = make_uint2(cvt_pk_bf16(v[0], v[1]), cvt_pk_bf16(v[2], v[3]));
+        const float w[8] = {v[0], v[1], v[2], v[3], 0.0f, 0.0f, 0.0f, 0.0f};
+        const uint4 q = pack<Tag>(w);
+        *reinterpret_cast<uint2*>(p) = make_uint2(q.x, q.y);
     }
     static __device__ __forceinline__ void store_zero(uint16_t* p) { *reinterpret_cast<uint2*>(p) = make_uint2(0, 0); }
 };
 
 // Operands of one contraction step of DF / DG: eight rows per lane half.
-template <int NT> struct Joint16Operands { float w[8], m[8]; typename Packet16<NT>::type x[8]; };
+template <typename Tag, int NT> struct Joint16Operands { float w[8], m[8]; typename Packet16<Tag, NT>::type x[8]; };
 
 // B fragments of the NT output tiles from eight packets (rows j = 0..7 of the lane's block, NT columns each):
 // exp(x - reference) in fp32, split, packed down the columns; one split-MFMA group per tile.
-template <int NT>
-__device__ __forceinline__ void joint16_mma(const Joint16Operands<NT>& s, f32x16 (&acc)[NT]) {
+template <typename Tag, int NT>
+__device__ __forceinline__ void joint16_mma(const Joint16Operands<Tag, NT>& s, f32x16 (&acc)[NT]) {
     uint32_t ahw[4], alw[4];
 #pragma unroll
     for (int d = 0; d < 4; ++d) split_pair(s.w[2 * d], s.w[2 * d + 1], ahw[d], alw[d]);
@@ -83,8 +88,8 @@ __device__ __forceinline__ void joint16_mma(const Joint16Operands<NT>& s, f32x16
 #pragma unroll
     for (int d = 0; d < 4; ++d) {
         float e0[NT], e1[NT];
-        Packet16<NT>::unpack_to(s.x[2 * d], e0);
-        Packet16<NT>::unpack_to(s.x[2 * d + 1], e1);
+        Packet16<Tag, NT>::unpack_to(s.x[2 * d], e0);
+        Packet16<Tag, NT>::unpack_to(s.x[2 * d + 1], e1);
 #pragma unroll
         for (int m = 0; m < NT; ++m)
             split_pair(joint_exp(e0[m], s.m[2 * d]), joint_exp(e1[m], s.m[2 * d + 1]), bh[m][d], bl[m][d]);
@@ -101,7 +106,7 @@ __device__ __forceinline__ void joint16_mma(const Joint16Operands<NT>& s, f32x16
 // columns; the contraction runs over the time rows in steps of sixteen (lane half h takes t = t2 + 8h + j):
 // A operand = W[t][u0 + col] (coalesced along u), B operand = exp(f[t, k0 + 8 col ..] - mf[t]), the streaming read
 // of f as whole 512-byte row segments.  grid = (ceil(A / (128 NT)), ceil(maxU / 32), N), block = 256.
-template <int NT, bool PF>
+template <typename Tag, int NT, bool PF>
 __global__ __launch_bounds__(256, NT == 4 ? 2 : 1) void joint_dg16_kernel(
         const uint16_t* __restrict__ f, const uint16_t* __restrict__ g, const float* __restrict__ rowmax,
         const float* __restrict__ wmat, const float* __restrict__ scale, const int* __restrict__ xlen,
@@ -109,7 +114,7 @@ __global__ __launch_bounds__(256, NT == 4 ? 2 : 1) void joint_dg16_kernel(
         const int* __restrict__ labels, int blank, const float* __restrict__ sgb, const float* __restrict__ sgl) {
     const int b = blockIdx.z;
     const int lane = threadIdx.x & 63, wave = uniform(threadIdx.x >> 6), half = lane >> 5, col = lane & 31;
-    using PK = Packet16<NT>;
+    using PK = Packet16<Tag, NT>;
     const int k0 = (static_cast<int>(blockIdx.x) * 4 + wave) * (32 * NT);
     if (k0 >= A) return;
     const int kc = k0 + NT * col;                          // first of this lane's NT columns
@@ -131,7 +136,7 @@ __global__ __launch_bounds__(256, NT == 4 ? 2 : 1) void joint_dg16_kernel(
         const unsigned Au = static_cast<unsigned>(A), Upu = static_cast<unsigned>(Upad);   // 32-bit offsets (host check)
         const unsigned mf0 = static_cast<unsigned>(b) * maxT;
         const unsigned sentinel = static_cast<unsigned>(N) * (maxT + maxU);
-        auto load = [&](Joint16Operands<NT>& s, int t2) {
+        auto load = [&](Joint16Operands<Tag, NT>& s, int t2) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const int t = t2 + 8 * half + j;
@@ -143,27 +148,27 @@ __global__ __launch_bounds__(256, NT == 4 ? 2 : 1) void joint_dg16_kernel(
             }
         };
         if constexpr (PF) {
-            Joint16Operands<NT> s0, s1;
+            Joint16Operands<Tag, NT> s0, s1;
             load(s0, 0);
             int t2 = 0;
             while (t2 + 16 < Tb) {
                 load(s1, t2 + 16);
                 __builtin_amdgcn_sched_barrier(0);
-                joint16_mma<NT>(s0, acc);
+                joint16_mma<Tag, NT>(s0, acc);
                 __builtin_amdgcn_sched_barrier(0);
                 load(s0, t2 + 32);
                 __builtin_amdgcn_sched_barrier(0);
-                joint16_mma<NT>(s1, acc);
+                joint16_mma<Tag, NT>(s1, acc);
                 __builtin_amdgcn_sched_barrier(0);
                 t2 += 32;
             }
-            if (t2 < Tb) joint16_mma<NT>(s0, acc);
+            if (t2 < Tb) joint16_mma<Tag, NT>(s0, acc);
         } else {
             for (int t2 = 0; t2 < Tb; t2 += 16) {
-                Joint16Operands<NT> s0;
+                Joint16Operands<Tag, NT> s0;
                 load(s0, t2);
                 __builtin_amdgcn_sched_barrier(0);
-                joint16_mma<NT>(s0, acc);
+                joint16_mma<Tag, NT>(s0, acc);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -211,7 +216,7 @@ __global__ __launch_bounds__(256, NT == 4 ? 2 : 1) void joint_dg16_kernel(
 // (exact in bf16) against -CL split into hi + lo -- built and issued only for the (step, tile) pairs a label of the
 // step falls into --, the per-sample factor, one 16-byte store per row.  No atomics on the output.
 // grid = (ceil(A / (128 NT)), ceil(maxT / 32), N), block = 256.
-template <int NT, bool PF>
+template <typename Tag, int NT, bool PF>
 __global__ __launch_bounds__(256, NT == 4 ? 2 : 1) void joint_df16_kernel(
         const uint16_t* __restrict__ f, const uint16_t* __restrict__ g, const float* __restrict__ rowmax,
         const float* __restrict__ wmat, const float* __restrict__ scale, const int* __restrict__ labels,
@@ -219,7 +224,7 @@ __global__ __launch_bounds__(256, NT == 4 ? 2 : 1) void joint_df16_kernel(
         int Upad, int A, int N, int blank, const float* __restrict__ sfb) {
     const int b = blockIdx.z;
     const int lane = threadIdx.x & 63, wave = uniform(threadIdx.x >> 6), half = lane >> 5, col = lane & 31;
-    using PK = Packet16<NT>;
+    using PK = Packet16<Tag, NT>;
     const int k0 = (static_cast<int>(blockIdx.x) * 4 + wave) * (32 * NT);
     if (k0 >= A) return;
     const int kc = k0 + NT * col;
@@ -256,7 +261,7 @@ __global__ __launch_bounds__(256, NT == 4 ? 2 : 1) void joint_df16_kernel(
     const unsigned sentinel = static_cast<unsigned>(N) * (maxT + maxU);
     const size_t plane = static_cast<size_t>(N) * maxT * Upad;              // W | CB | CL
     const size_t labs0 = static_cast<size_t>(b) * (maxU > 1 ? maxU - 1 : 1);
-    auto load = [&](Joint16Operands<NT>& s, int u2) {
+    auto load = [&](Joint16Operands<Tag, NT>& s, int u2) {
         const int ub = u2 + 8 * half;
         const int ubc = ub + 8 <= Upad ? ub : Upad - 8;
         const float4 w0 = *reinterpret_cast<const float4*>(wrow + ubc), w1 = *reinterpret_cast<const float4*>(wrow + ubc + 4);
@@ -271,27 +276,27 @@ __global__ __launch_bounds__(256, NT == 4 ? 2 : 1) void joint_df16_kernel(
         }
     };
     if constexpr (PF) {
-        Joint16Operands<NT> s0, s1;
+        Joint16Operands<Tag, NT> s0, s1;
         load(s0, 0);
         int u2 = 0;
         while (u2 + 16 < Ub) {
             load(s1, u2 + 16);
             __builtin_amdgcn_sched_barrier(0);
-            joint16_mma<NT>(s0, acc);
+            joint16_mma<Tag, NT>(s0, acc);
             __builtin_amdgcn_sched_barrier(0);
             load(s0, u2 + 32);
             __builtin_amdgcn_sched_barrier(0);
-            joint16_mma<NT>(s1, acc);
+            joint16_mma<Tag, NT>(s1, acc);
             __builtin_amdgcn_sched_barrier(0);
             u2 += 32;
         }
-        if (u2 < Ub) joint16_mma<NT>(s0, acc);
+        if (u2 < Ub) joint16_mma<Tag, NT>(s0, acc);
     } else {
         for (int u2 = 0; u2 < Ub; u2 += 16) {
-            Joint16Operands<NT> s0;
+            Joint16Operands<Tag, NT> s0;
             load(s0, u2);
             __builtin_amdgcn_sched_barrier(0);
-            joint16_mma<NT>(s0, acc);
+            joint16_mma<Tag, NT>(s0, acc);
             __builtin_amdgcn_sched_barrier(0);
         }
     }
@@ -385,13 +390,12 @@ __global__ __launch_bounds__(256, NT == 4 ? 2 : 1) void joint_df16_kernel(
 // along k) -- no LDS staging, no cross-lane traffic; four packets of each operand per chunk consume a 128-byte line of
 // every row.  S wavefronts of a block split the chunks of ONE tile and add their fragments through LDS at the end.
 // grid = (tiles or ceil(tiles/4) rounded up to 8, N), block = 64 * max(S, 4).
-template <int S, bool SAMPLED>
+template <typename Tag, int S, bool SAMPLED>
 __global__ __launch_bounds__(S == 1 ? 256 : S * 64) void joint_z16_kernel(
         const uint16_t* __restrict__ f, const uint16_t* __restrict__ g, float* rowmax,
         const int* __restrict__ labels, const int* __restrict__ xlen, const int* __restrict__ ylen,
         LogPair<float>* __restrict__ lp2, float* __restrict__ logz, int maxT, int maxU, int Up, int A,
         int blank, int tilesU, int tiles, int N, int* gate, int seq) {
-    using Tag = BF16;
     using ST = uint16_t;
     constexpr int WAVES = S == 1 ? 4 : S;
     __shared__ float xch[S == 1 ? 1 : S * 1024];           // S > 1: the wavefronts' fragments meet here

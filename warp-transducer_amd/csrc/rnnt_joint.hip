@@ -25,7 +25,12 @@ static rnntStatus_t run_gpu_joint(const typename Tag::store* f, const typename T
                                   float* costs_device, const float* grad_scale, void* workspace,
                                   const rnntOptions& opt, int phases, bool want_grad, float fastemit = 0.0f) {
     using S = typename Tag::store;
-    constexpr bool k16 = sizeof(typename Tag::store) == 2;    // bf16 / fp16 storage: the bf16 matrix-core kernels apply
+    // 16-bit storage runs the three GEMMs on the bf16 matrix cores (rnnt_joint16_kernels.h).  fp32 storage does not: with the
+    // operands split into THREE bf16 parts (what fp32-class results need: six MFMAs and three roundings per element) the
+    // same kernels were measured at the speed of the fp32-MFMA ones (c3 shape 0.556 vs 0.545 ms, N=128,T=200,U=41,A=1024
+    // 0.302 vs 0.308: profiles/r03k_joint_fp32_on_bf16_cores.log) -- the fp32 forms stay.
+    constexpr bool k16 = sizeof(typename Tag::store) == 2;
+    const int jbits = tune().j16;                          // which stages take the matrix-core form (bit 0 DG, 1 DF, 2 Z)
     Plan<float> p;
     if (!make_plan(p, A, N, opt, workspace, labels, label_lengths, input_lengths, costs_device, /*joint=*/true))
         return RNNT_STATUS_INVALID_VALUE;
@@ -68,7 +73,7 @@ static rnntStatus_t run_gpu_joint(const typename Tag::store* f, const typename T
         // sampled row references + guard (rnnt_joint_kernels.h): no row-maximum pass in front of the Z kernel; the exact
         // pair runs behind it only when a row tripped the guard
         const bool sampled = !small && A >= 64 && tune().jsamp != 0;
-        const bool z16 = k16 && (tune().j16 & 4) != 0 && !small && A % 8 == 0 && A >= 512 &&
+        const bool z16 = k16 && (jbits & 4) != 0 && !small && A % 8 == 0 && A >= 512 &&
                          ((reinterpret_cast<uintptr_t>(f) | reinterpret_cast<uintptr_t>(g)) & 15u) == 0;
         (void)z16;
         int* const gate = reinterpret_cast<int*>(p.rowmax + rows + 1);
@@ -178,7 +183,7 @@ static rnntStatus_t run_gpu_joint(const typename Tag::store* f, const typename T
         const bool pf_f = tn.jfpf != 0 && (sizeof(S) == 4 || NKf < 4), pf_g = tn.jgpf != 0 && (sizeof(S) == 4 || NKg < 4);
         bool df16 = false;
         if constexpr (k16) {
-            df16 = (tn.j16 & 2) != 0 && A % 8 == 0 && (all4 & 15u) == 0 && A >= 512;
+            df16 = (jbits & 2) != 0 && A % 8 == 0 && (all4 & 15u) == 0 && A >= 512;
             if (df16) {
 #define RNNT_JDF16(NN, PP)                                                                                       \
     hipLaunchKernelGGL((joint_df16_kernel<Tag, NN, PP>), dim3((A + 128 * NN - 1) / (128 * NN), tilesT, N), dim3(256), 0, p.stream, \
@@ -196,7 +201,7 @@ static rnntStatus_t run_gpu_joint(const typename Tag::store* f, const typename T
         // bf16 storage, rows of whole 16-byte packets: the bf16 matrix-core forms (rnnt_joint16_kernels.h)
         bool dg16 = false;
         if constexpr (k16) {
-            dg16 = (tn.j16 & 1) != 0 && A % 8 == 0 && (all4 & 15u) == 0 && A >= 512;
+            dg16 = (jbits & 1) != 0 && A % 8 == 0 && (all4 & 15u) == 0 && A >= 512;
             if (dg16) {
 #define RNNT_JDG16(NN, PP)                                                                                       \
     hipLaunchKernelGGL((joint_dg16_kernel<Tag, NN, PP>), dim3((A + 128 * NN - 1) / (128 * NN), tilesU, N), dim3(256), 0, p.stream, \

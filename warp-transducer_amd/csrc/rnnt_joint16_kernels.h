@@ -27,6 +27,8 @@
 // (A % 8 == 0, 16-byte aligned tensors), which the host checks.
 #pragma once
 
+#include <type_traits>
+
 #include "rnnt_joint_kernels.h"
 
 namespace rnnt {
@@ -38,39 +40,74 @@ __device__ __forceinline__ bf16x8_t as_bf16x8(const u32x4& v) {
     __builtin_memcpy(&r, &v, 16);
     return r;
 }
-// two fp32 values -> one packed pair of their bf16 heads and one of the bf16 residuals
-__device__ __forceinline__ void split_pair(float a, float b, uint32_t& hi, uint32_t& lo) {
-    hi = cvt_pk_bf16(a, b);
-    lo = cvt_pk_bf16(a - __uint_as_float(hi << 16), b - __uint_as_float(hi & 0xffff0000u));
+// Parts of the bf16 expansion of an fp32 operand: NS = 2 (hi + lo, ~2^-17 relative per product: enough for 16-bit
+// storage, whose results are rounded to 2^-9 / 2^-12) or NS = 3 (hi + mid + lo, ~2^-25: fp32 storage keeps fp32-class
+// results, "fp32 on the bf16 matrix cores").
+template <typename Tag> struct JointSplit { static constexpr int NS = sizeof(typename Tag::store) == 4 ? 3 : 2; };
+
+// two fp32 values -> NS packed pairs: their bf16 heads, the bf16 heads of the residuals, ...
+template <int NS>
+__device__ __forceinline__ void split_pair(float a, float b, uint32_t (&part)[NS]) {
+#pragma unroll
+    for (int i = 0; i < NS; ++i) {
+        part[i] = cvt_pk_bf16(a, b);
+        if (i + 1 < NS) {
+            a -= __uint_as_float(part[i] << 16);
+            b -= __uint_as_float(part[i] & 0xffff0000u);
+        }
+    }
 }
-// acc += A B with A = ah + al, B = bh + bl (the al*bl term, 2^-18 relative, is dropped)
-__device__ __forceinline__ f32x16 mma_split(const u32x4& ah, const u32x4& al, const u32x4& bh, const u32x4& bl, f32x16 acc) {
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(ah), as_bf16x8(bh), acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(ah), as_bf16x8(bl), acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(al), as_bf16x8(bh), acc, 0, 0, 0);
+// One operand of the MFMA as NS fragments (eight contraction indices per lane, four packed pairs each).
+template <int NS> struct JointFrag { u32x4 p[NS]; };
+template <int NS>
+__device__ __forceinline__ void set_pair(JointFrag<NS>& fr, int d, float a, float b) {    // contraction indices 2d, 2d + 1
+    uint32_t part[NS];
+    split_pair<NS>(a, b, part);
+#pragma unroll
+    for (int i = 0; i < NS; ++i) fr.p[i][d] = part[i];
+}
+__device__ __forceinline__ f32x16 mma_bf16(const u32x4& a, const u32x4& b, f32x16 acc) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(a), as_bf16x8(b), acc, 0, 0, 0);
+}
+// acc += A B over the products whose order (sum of the two part indices) is below NS: hi*hi, hi*lo, lo*hi (NS = 2; the
+// dropped lo*lo is 2^-18 relative) or all six products up to mid*mid (NS = 3; the dropped ones are 2^-26 and below)
+template <int NS>
+__device__ __forceinline__ f32x16 mma_split(const JointFrag<NS>& a, const JointFrag<NS>& b, f32x16 acc) {
+#pragma unroll
+    for (int o = 0; o < NS; ++o)                               // smallest terms last would be nicer numerically; fp32
+#pragma unroll                                                  // accumulation of <= 6 terms per step does not care
+        for (int i = 0; i <= o; ++i) acc = mma_bf16(a.p[i], b.p[o - i], acc);
     return acc;
 }
 
-// A lane's packet of NT adjacent bf16 columns: 16 bytes (NT = 8: a wavefront owns 256 columns as eight tiles) or 8 bytes
-// (NT = 4: 128 columns, four tiles -- half the accumulators and operand registers, two wavefronts per SIMD).
-template <typename Tag, int NT> struct Packet16;
-template <typename Tag> struct Packet16<Tag, 8> {
-    typedef uint4 type;
-    static __device__ __forceinline__ uint4 load(const uint16_t* p) { return load_packet<false>(reinterpret_cast<const u32x4*>(p)); }
-    static __device__ __forceinline__ void unpack_to(const uint4& r, float* v) { unpack<Tag>(r, v); }
-    static __device__ __forceinline__ void store(uint16_t* p, const float* v) { store_packet<false>(reinterpret_cast<u32x4*>(p), pack<Tag>(v)); }
-    static __device__ __forceinline__ void store_zero(uint16_t* p) { store_packet<false>(reinterpret_cast<u32x4*>(p), make_uint4(0, 0, 0, 0)); }
-};
-template <typename Tag> struct Packet16<Tag, 4> {
-    typedef uint2 type;
-    static __device__ __forceinline__ uint2 load(const uint16_t* p) { return *reinterpret_cast<const uint2*>(p); }
-    static __device__ __forceinline__ void unpack_to(const uint2& r, float* v) { unpack_half<Tag>(r, v); }
-    static __device__ __forceinline__ void store(uint16_t* p, const float* v) {
-        const float w[8] = {v[0], v[1], v[2], v[3], 0.0f, 0.0f, 0.0f, 0.0f};
-        const uint4 q = pack<Tag>(w);
-        *reinterpret_cast<uint2*>(p) = make_uint2(q.x, q.y);
+// A lane's packet of NT adjacent columns: one 16-byte or 8-byte access (16-bit storage: NT = 8 -> a wavefront owns 256
+// columns as eight tiles, NT = 4 -> 128 columns, half the accumulators and operand registers, two wavefronts per SIMD;
+// fp32 storage: NT = 4, 16 bytes).
+template <typename Tag, int NT> struct Packet16 {
+    using ST = typename Tag::store;
+    static constexpr int BYTES = NT * static_cast<int>(sizeof(ST));
+    static_assert(BYTES == 16 || BYTES == 8, "a packet is one 16-byte or 8-byte access");
+    typedef typename std::conditional<BYTES == 16, uint4, uint2>::type type;
+    static __device__ __forceinline__ type load(const ST* p) {
+        if constexpr (BYTES == 16) return load_packet<false>(reinterpret_cast<const u32x4*>(p));
+        else return *reinterpret_cast<const uint2*>(p);
     }
-    static __device__ __forceinline__ void store_zero(uint16_t* p) { *reinterpret_cast<uint2*>(p) = make_uint2(0, 0); }
+    static __device__ __forceinline__ void unpack_to(const type& r, float* v) {
+        if constexpr (BYTES == 16) unpack<Tag>(r, v); else unpack_half<Tag>(r, v);
+    }
+    static __device__ __forceinline__ void store(ST* p, const float* v) {
+        if constexpr (BYTES == 16) {
+            store_packet<false>(reinterpret_cast<u32x4*>(p), pack<Tag>(v));
+        } else {
+            const float w[8] = {v[0], v[1], v[2], v[3], 0.0f, 0.0f, 0.0f, 0.0f};
+            const uint4 q = pack<Tag>(w);
+            *reinterpret_cast<uint2*>(p) = make_uint2(q.x, q.y);
+        }
+    }
+    static __device__ __forceinline__ void store_zero(ST* p) {
+        if constexpr (BYTES == 16) store_packet<false>(reinterpret_cast<u32x4*>(p), make_uint4(0, 0, 0, 0));
+        else *reinterpret_cast<uint2*>(p) = make_uint2(0, 0);
+    }
 };
 
 // Operands of one contraction step of DF / DG: eight rows per lane half.
@@ -80,25 +117,20 @@ template <typename Tag, int NT> struct Joint16Operands { float w[8], m[8]; typen
 // exp(x - reference) in fp32, split, packed down the columns; one split-MFMA group per tile.
 template <typename Tag, int NT>
 __device__ __forceinline__ void joint16_mma(const Joint16Operands<Tag, NT>& s, f32x16 (&acc)[NT]) {
-    uint32_t ahw[4], alw[4];
+    constexpr int NS = JointSplit<Tag>::NS;
+    JointFrag<NS> a, bf[NT];
 #pragma unroll
-    for (int d = 0; d < 4; ++d) split_pair(s.w[2 * d], s.w[2 * d + 1], ahw[d], alw[d]);
-    const u32x4 ah = {ahw[0], ahw[1], ahw[2], ahw[3]}, al = {alw[0], alw[1], alw[2], alw[3]};
-    uint32_t bh[NT][4], bl[NT][4];
+    for (int d = 0; d < 4; ++d) set_pair<NS>(a, d, s.w[2 * d], s.w[2 * d + 1]);
 #pragma unroll
     for (int d = 0; d < 4; ++d) {
         float e0[NT], e1[NT];
         Packet16<Tag, NT>::unpack_to(s.x[2 * d], e0);
         Packet16<Tag, NT>::unpack_to(s.x[2 * d + 1], e1);
 #pragma unroll
-        for (int m = 0; m < NT; ++m)
-            split_pair(joint_exp(e0[m], s.m[2 * d]), joint_exp(e1[m], s.m[2 * d + 1]), bh[m][d], bl[m][d]);
+        for (int m = 0; m < NT; ++m) set_pair<NS>(bf[m], d, joint_exp(e0[m], s.m[2 * d]), joint_exp(e1[m], s.m[2 * d + 1]));
     }
 #pragma unroll
-    for (int m = 0; m < NT; ++m) {
-        const u32x4 h4 = {bh[m][0], bh[m][1], bh[m][2], bh[m][3]}, l4 = {bl[m][0], bl[m][1], bl[m][2], bl[m][3]};
-        acc[m] = mma_split(ah, al, h4, l4, acc[m]);
-    }
+    for (int m = 0; m < NT; ++m) acc[m] = mma_split<NS>(a, bf[m], acc[m]);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -108,9 +140,9 @@ __device__ __forceinline__ void joint16_mma(const Joint16Operands<Tag, NT>& s, f
 // of f as whole 512-byte row segments.  grid = (ceil(A / (128 NT)), ceil(maxU / 32), N), block = 256.
 template <typename Tag, int NT, bool PF>
 __global__ __launch_bounds__(256, NT == 4 ? 2 : 1) void joint_dg16_kernel(
-        const uint16_t* __restrict__ f, const uint16_t* __restrict__ g, const float* __restrict__ rowmax,
+        const typename Tag::store* __restrict__ f, const typename Tag::store* __restrict__ g, const float* __restrict__ rowmax,
         const float* __restrict__ wmat, const float* __restrict__ scale, const int* __restrict__ xlen,
-        const int* __restrict__ ylen, uint16_t* __restrict__ dg, int maxT, int maxU, int Upad, int A, int N,
+        const int* __restrict__ ylen, typename Tag::store* __restrict__ dg, int maxT, int maxU, int Upad, int A, int N,
         const int* __restrict__ labels, int blank, const float* __restrict__ sgb, const float* __restrict__ sgl) {
     const int b = blockIdx.z;
     const int lane = threadIdx.x & 63, wave = uniform(threadIdx.x >> 6), half = lane >> 5, col = lane & 31;
@@ -132,7 +164,7 @@ __global__ __launch_bounds__(256, NT == 4 ? 2 : 1) void joint_dg16_kernel(
         // unconditional operand loads, masking through the +inf sentinel (joint_df_kernel); label rows past the sample
         // read column 0 and produce accumulator rows nobody stores
         const float* wcol = wmat + static_cast<size_t>(b) * maxT * Upad + (u0 + col < Ub ? u0 + col : 0);
-        const uint16_t* fb = f + static_cast<size_t>(b) * maxT * A + (kin ? kc : A - NT);
+        const typename Tag::store* fb = f + static_cast<size_t>(b) * maxT * A + (kin ? kc : A - NT);
         const unsigned Au = static_cast<unsigned>(A), Upu = static_cast<unsigned>(Upad);   // 32-bit offsets (host check)
         const unsigned mf0 = static_cast<unsigned>(b) * maxT;
         const unsigned sentinel = static_cast<unsigned>(N) * (maxT + maxU);
@@ -218,9 +250,9 @@ __global__ __launch_bounds__(256, NT == 4 ? 2 : 1) void joint_dg16_kernel(
 // grid = (ceil(A / (128 NT)), ceil(maxT / 32), N), block = 256.
 template <typename Tag, int NT, bool PF>
 __global__ __launch_bounds__(256, NT == 4 ? 2 : 1) void joint_df16_kernel(
-        const uint16_t* __restrict__ f, const uint16_t* __restrict__ g, const float* __restrict__ rowmax,
+        const typename Tag::store* __restrict__ f, const typename Tag::store* __restrict__ g, const float* __restrict__ rowmax,
         const float* __restrict__ wmat, const float* __restrict__ scale, const int* __restrict__ labels,
-        const int* __restrict__ xlen, const int* __restrict__ ylen, uint16_t* __restrict__ df, int maxT, int maxU,
+        const int* __restrict__ xlen, const int* __restrict__ ylen, typename Tag::store* __restrict__ df, int maxT, int maxU,
         int Upad, int A, int N, int blank, const float* __restrict__ sfb) {
     const int b = blockIdx.z;
     const int lane = threadIdx.x & 63, wave = uniform(threadIdx.x >> 6), half = lane >> 5, col = lane & 31;
@@ -232,8 +264,8 @@ __global__ __launch_bounds__(256, NT == 4 ? 2 : 1) void joint_df16_kernel(
     const int t0 = blockIdx.y * 32;
     const int Tb = clamp_len(xlen[b], maxT), Ub = clamp_len(ylen[b] + 1, maxU);
     const float* mf = rowmax + static_cast<size_t>(b) * maxT;
-    const uint16_t* fb = f + static_cast<size_t>(b) * maxT * A + (kin ? kc : A - NT);
-    uint16_t* dfb = df + static_cast<size_t>(b) * maxT * A + kc;
+    const typename Tag::store* fb = f + static_cast<size_t>(b) * maxT * A + (kin ? kc : A - NT);
+    typename Tag::store* dfb = df + static_cast<size_t>(b) * maxT * A + kc;
     if (t0 >= Tb || Ub <= 0) {                             // time rows of the padding: zeros
         if (!kin) return;
 #pragma unroll
@@ -255,7 +287,7 @@ __global__ __launch_bounds__(256, NT == 4 ? 2 : 1) void joint_df16_kernel(
     // the +inf sentinel as their reference (B operand exactly 0; W is finite everywhere), a step's second half that
     // would leave the weight row reads its last eight columns instead
     const float* wrow = wmat + (static_cast<size_t>(b) * maxT + (tin ? t0 + col : Tb - 1)) * Upad;
-    const uint16_t* gb = g + static_cast<size_t>(b) * maxU * A + (kin ? kc : A - NT);
+    const typename Tag::store* gb = g + static_cast<size_t>(b) * maxU * A + (kin ? kc : A - NT);
     const unsigned Au = static_cast<unsigned>(A);          // maxU * A < 2^31 (host check): 32-bit offsets
     const unsigned mg0 = static_cast<unsigned>(N) * maxT + static_cast<unsigned>(b) * maxU;
     const unsigned sentinel = static_cast<unsigned>(N) * (maxT + maxU);
@@ -347,11 +379,11 @@ __global__ __launch_bounds__(256, NT == 4 ? 2 : 1) void joint_df16_kernel(
         const float4 c0 = *reinterpret_cast<const float4*>(wrow + 2 * plane + ubc), c1 = *reinterpret_cast<const float4*>(wrow + 2 * plane + ubc + 4);
         const float cl[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
         const bool shifted = ubc != ub;                        // (clamped second half: its rows lie past the sample, d = -1)
-        uint32_t ahw[4], alw[4];
+        constexpr int NS = JointSplit<Tag>::NS;
+        JointFrag<NS> ac;
 #pragma unroll
         for (int q = 0; q < 4; ++q)
-            split_pair((tin && !shifted) ? -cl[2 * q] : 0.0f, (tin && !shifted) ? -cl[2 * q + 1] : 0.0f, ahw[q], alw[q]);
-        const u32x4 ah = {ahw[0], ahw[1], ahw[2], ahw[3]}, al = {alw[0], alw[1], alw[2], alw[3]};
+            set_pair<NS>(ac, q, (tin && !shifted) ? -cl[2 * q] : 0.0f, (tin && !shifted) ? -cl[2 * q + 1] : 0.0f);
 #pragma unroll
         for (int m = 0; m < NT; ++m) {
             uint32_t one[4];
@@ -364,8 +396,8 @@ __global__ __launch_bounds__(256, NT == 4 ? 2 : 1) void joint_df16_kernel(
             }
             if (__ballot(hit) == 0) continue;
             const u32x4 bo = {one[0], one[1], one[2], one[3]};
-            acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(ah), as_bf16x8(bo), acc[m], 0, 0, 0);
-            acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(al), as_bf16x8(bo), acc[m], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < NS; ++i) acc[m] = mma_bf16(ac.p[i], bo, acc[m]);
         }
     }
     if (!kin) return;
@@ -384,7 +416,7 @@ __global__ __launch_bounds__(256, NT == 4 ? 2 : 1) void joint_df16_kernel(
 // ------------------------------------------------------------------------------------------
 // Partition function (joint_z_kernel's contract: relative log Z into `logz`, blank / label log2-probs into `lp2`, skewed
 // lattice layout; exact or SAMPLED row references with the guard and the gate).  A wavefront owns a 32 (t) x 32 (u) tile
-// and contracts over its share of the vocabulary in chunks of 64 columns.  The contraction index IS the packet
+// and contracts over its share of the vocabulary in chunks of 64 columns (32 for fp32 storage).  The contraction index IS the packet
 // direction here: lane (row = lane & 31, half = lane >> 5) loads the 16-byte packets f[t0 + row][k + 8 half ..] and
 // g[u0 + row][k + 8 half ..] and they become the A and B fragments as they are (exp, hi / lo split, packed pairwise
 // along k) -- no LDS staging, no cross-lane traffic; four packets of each operand per chunk consume a 128-byte line of
@@ -392,11 +424,11 @@ __global__ __launch_bounds__(256, NT == 4 ? 2 : 1) void joint_df16_kernel(
 // grid = (tiles or ceil(tiles/4) rounded up to 8, N), block = 64 * max(S, 4).
 template <typename Tag, int S, bool SAMPLED>
 __global__ __launch_bounds__(S == 1 ? 256 : S * 64) void joint_z16_kernel(
-        const uint16_t* __restrict__ f, const uint16_t* __restrict__ g, float* rowmax,
+        const typename Tag::store* __restrict__ f, const typename Tag::store* __restrict__ g, float* rowmax,
         const int* __restrict__ labels, const int* __restrict__ xlen, const int* __restrict__ ylen,
         LogPair<float>* __restrict__ lp2, float* __restrict__ logz, int maxT, int maxU, int Up, int A,
         int blank, int tilesU, int tiles, int N, int* gate, int seq) {
-    using ST = uint16_t;
+    using ST = typename Tag::store;
     constexpr int WAVES = S == 1 ? 4 : S;
     __shared__ float xch[S == 1 ? 1 : S * 1024];           // S > 1: the wavefronts' fragments meet here
     __shared__ float refs[SAMPLED ? (S == 1 ? WAVES : 1) : 1][64];   // SAMPLED: the tile's 32 + 32 reference values (x log2 e)
@@ -419,6 +451,12 @@ __global__ __launch_bounds__(S == 1 ? 256 : S * 64) void joint_z16_kernel(
     const int trow = t0 + col < Tb ? t0 + col : Tb - 1, urow = u0 + col < Ub ? u0 + col : Ub - 1;
     const ST* frow = f + (static_cast<size_t>(b) * maxT + trow) * A + 8 * half;
     const ST* grow = g + (static_cast<size_t>(b) * maxU + urow) * A + 8 * half;
+    // eight consecutive columns of a row = one contraction half-step of this lane: PPS 16-byte packets
+    constexpr int EPP = 16 / static_cast<int>(sizeof(ST)), PPS = 8 / EPP;     // elements per packet (8 | 4), packets per 8 columns (1 | 2)
+    auto load8 = [&](const ST* p8, float* v) {
+#pragma unroll
+        for (int q = 0; q < PPS; ++q) unpack<Tag>(load_packet<false>(reinterpret_cast<const u32x4*>(p8 + q * EPP)), v + q * EPP);
+    };
     float mfr, mgr;
     float tf = neg_inf<float>(), tg = neg_inf<float>();   // SAMPLED: the true maxima of what this lane streams
     if constexpr (!SAMPLED) {
@@ -431,10 +469,8 @@ __global__ __launch_bounds__(S == 1 ? 256 : S * 64) void joint_z16_kernel(
         const int rw = S == 1 ? wave : 0;
         if (S == 1 || wave == 0) {
             float a[8], c[8], a2[8], c2[8];
-            unpack<Tag>(load_packet<false>(reinterpret_cast<const u32x4*>(frow)), a);
-            unpack<Tag>(load_packet<false>(reinterpret_cast<const u32x4*>(frow + 16)), a2);
-            unpack<Tag>(load_packet<false>(reinterpret_cast<const u32x4*>(grow)), c);
-            unpack<Tag>(load_packet<false>(reinterpret_cast<const u32x4*>(grow + 16)), c2);
+            load8(frow, a); load8(frow + 16, a2);
+            load8(grow, c); load8(grow + 16, c2);
             float ma = neg_inf<float>(), mc = neg_inf<float>();
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
@@ -467,38 +503,46 @@ __global__ __launch_bounds__(S == 1 ? 256 : S * 64) void joint_z16_kernel(
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-    const int nchunk = (A + 63) >> 6;
+    // a chunk = STEPS contraction steps of 16 columns = four 16-byte packets of each operand per lane (64 columns of
+    // 16-bit storage, 32 of fp32)
+    constexpr int STEPS = 4 / PPS, CH = 16 * STEPS;
+    constexpr int NS = JointSplit<Tag>::NS;
+    const int nchunk = (A + CH - 1) / CH;
     auto load = [&](uint4 (&fv)[4], uint4 (&gv)[4], int cc) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int k = cc * 64 + 16 * j + 8 * half;     // (columns past the end: the row's last packet, cancelled below)
-            const int ko = k < A ? cc * 64 + 16 * j : A - 8 - 8 * half;
-            fv[j] = load_packet<false>(reinterpret_cast<const u32x4*>(frow + ko));
-            gv[j] = load_packet<false>(reinterpret_cast<const u32x4*>(grow + ko));
+        for (int j = 0; j < STEPS; ++j) {
+            const int k = cc * CH + 16 * j + 8 * half;     // (columns past the end: the row's last eight, cancelled below)
+            const int ko = k < A ? cc * CH + 16 * j : A - 8 - 8 * half;
+#pragma unroll
+            for (int q = 0; q < PPS; ++q) {
+                fv[j * PPS + q] = load_packet<false>(reinterpret_cast<const u32x4*>(frow + ko + q * EPP));
+                gv[j * PPS + q] = load_packet<false>(reinterpret_cast<const u32x4*>(grow + ko + q * EPP));
+            }
         }
     };
     auto compute = [&](const uint4 (&fv)[4], const uint4 (&gv)[4], int cc) {
         const float pinf = -neg_inf<float>();
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const bool in = cc * 64 + 16 * j + 8 * half < A;
+        for (int j = 0; j < STEPS; ++j) {
+            const bool in = cc * CH + 16 * j + 8 * half < A;
             const float ra = in ? mfr : pinf, rb = in ? mgr : pinf;
             float x[8], y[8];
-            unpack<Tag>(fv[j], x);
-            unpack<Tag>(gv[j], y);
+#pragma unroll
+            for (int q = 0; q < PPS; ++q) {
+                unpack<Tag>(fv[j * PPS + q], x + q * EPP);
+                unpack<Tag>(gv[j * PPS + q], y + q * EPP);
+            }
             if constexpr (SAMPLED) {
 #pragma unroll
                 for (int i = 0; i < 8; ++i) { tf = fmaxf(tf, x[i]); tg = fmaxf(tg, y[i]); }
             }
-            uint32_t ahw[4], alw[4], bhw[4], blw[4];
+            JointFrag<NS> fa, fb2;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                split_pair(joint_exp(x[2 * q], ra), joint_exp(x[2 * q + 1], ra), ahw[q], alw[q]);
-                split_pair(joint_exp(y[2 * q], rb), joint_exp(y[2 * q + 1], rb), bhw[q], blw[q]);
+                set_pair<NS>(fa, q, joint_exp(x[2 * q], ra), joint_exp(x[2 * q + 1], ra));
+                set_pair<NS>(fb2, q, joint_exp(y[2 * q], rb), joint_exp(y[2 * q + 1], rb));
             }
-            const u32x4 ah = {ahw[0], ahw[1], ahw[2], ahw[3]}, al = {alw[0], alw[1], alw[2], alw[3]};
-            const u32x4 bh = {bhw[0], bhw[1], bhw[2], bhw[3]}, bl = {blw[0], blw[1], blw[2], blw[3]};
-            acc = mma_split(ah, al, bh, bl, acc);
+            acc = mma_split<NS>(fa, fb2, acc);
         }
     };
     {

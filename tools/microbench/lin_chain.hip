@@ -8,6 +8,7 @@
 //   mode 3  mode 1 without the per-step ldexp of the label operand (one exponent per wavefront)
 //   mode 4  the bare fp64 chain on constant operands (latency floor)
 //   mode 5  the bare fp32 chain  a' = fma(shr(a), pl, a * pb)
+//   mode 6  the chain wavefront of a helper-wavefront design: fp64 operands read from LDS, raw fp64 results written to LDS
 // One wavefront per block, one block per CU; reports shader cycles (s_memtime) and wall ns per step.
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -92,6 +93,28 @@ __global__ __launch_bounds__(64) void chain_kernel(const float2* __restrict__ ce
         };
         for (int j = 0; j < nchunks; j += 2) { chunk(j, bx[0], by[0], bx[1], by[1]); chunk(j + 1, bx[1], by[1], bx[0], by[0]); }
         out64[blockIdx.x * 64 + lane] = a + hist[0] + e_lane;
+    } else if constexpr (MODE == 6) {
+        // the chain wavefront of a helper-wavefront design: operands arrive as fp64 pairs in LDS (ds_read_b128), results leave
+        // as raw fp64 into LDS (ds_write_b64); conversions would be done by other wavefronts of the block (not modelled: upper bound)
+        __shared__ double2 opnd[2][C][64];
+        __shared__ double res[2][C][64];
+        for (int k = 0; k < C; ++k) { opnd[0][k][lane] = make_double2(0.4 + 1e-3 * lane, 0.1); opnd[1][k][lane] = make_double2(0.5, 0.12); }
+        __syncthreads();
+        double a = lane == 0 ? 1.0 : 0.0, up = 0.0;
+        for (int j = 0; j < nchunks; ++j) {
+#pragma unroll
+            for (int k = 0; k < C; ++k) {
+                const double2 o = opnd[j & 1][k][lane];
+                const double t = a * o.x;
+                up = wave_shr1(up, a);
+                a = __builtin_fma(up, o.y, t);
+                res[j & 1][k][lane] = a;
+            }
+            const int e = a != 0.0 ? __builtin_amdgcn_frexp_exp(a) : 0;
+            a = __builtin_ldexp(a, -e);
+            __builtin_amdgcn_s_barrier();
+        }
+        out64[blockIdx.x * 64 + lane] = a + res[0][0][lane];
     } else if constexpr (MODE == 4) {
         double a = lane == 0 ? 1.0 : 0.0, up = 0.0;
         const double pb = 0.5 + 1e-3 * lane, pl = 0.5 - 1e-3 * lane;
@@ -155,6 +178,7 @@ int main(int argc, char** argv) {
     run<1, 8>("1 linear fp64, cvt operands, log2 results, lane exps", dlin, o32, o64, cyc, nchunks * 2, blocks);
     run<2, 16>("2 linear fp64, cvt operands, raw fp64 results", dlin, o32, o64, cyc, nchunks, blocks);
     run<3, 16>("3 linear fp64, cvt operands, log2 results, wave exp", dlin, o32, o64, cyc, nchunks, blocks);
+    run<6, 16>("6 chain wavefront of a helper design (LDS in / out)", dlin, o32, o64, cyc, nchunks, blocks);
     run<4, 16>("4 bare fp64 chain (mul | dpp x2 -> fma)", dlin, o32, o64, cyc, nchunks, blocks);
     run<5, 16>("5 bare fp32 chain (mul | dpp -> fma)", dlin, o32, o64, cyc, nchunks, blocks);
     // check that mode 1 and mode 0 agree on a log-likelihood-like number

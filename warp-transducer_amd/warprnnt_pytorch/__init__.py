@@ -107,7 +107,9 @@ class _RNNT(Function):
             warp_rnnt.gpu_rnnt_bwd(acts, grads, scale, ctx.workspace, ctx.blank)
             return grads, None, None, None, None, None, None, None
         # out of place (the reference scales the saved tensor in place, __init__.py:47-50, so a second
-        # backward through a retained graph compounds the factors and gradcheck fails)
+        # backward through a retained graph compounds the factors and gradcheck fails).  Cost: one more
+        # (B,T,U,V) tensor alive during backward on THIS route -- the CPU location and WARPRNNT_SYNC_API=1;
+        # the default GPU route above keeps no gradient tensor at all between forward and backward.
         grad_output = grad_output.view(-1, 1, 1, 1).to(ctx.grads)
         return ctx.grads * grad_output, None, None, None, None, None, None, None
 

@@ -428,3 +428,21 @@ def test_bf16_matrix_core_kernels_on_peaked_rows(oracle):
         f2[:, ::3, 700] += bump                                     # beyond the first 32 columns: not in the sampled reference
         g2[:, 1::2, 900] += bump
         _bf16_case(oracle, f2, g2, labels, tl, ll, blank)
+
+
+def test_bf16_matrix_core_kernels_with_masked_vocabulary(oracle):
+    """-inf logits through the bf16 matrix-core kernels: masked columns that are neither the blank nor a label (probability
+    zero, gradient exactly zero, no NaN), including rows whose first 32 columns -- the sampled reference -- are ALL masked."""
+    shape = (2, 37, 19, 640)
+    f, g, labels, tl, ll, blank = problem(shape, 21)
+    labels = (100 + labels % 50).astype(np.int32)
+    blank = 90
+    f[..., 300:340] = -np.inf
+    g[:, :, 500:560] = -np.inf
+    f[:, 3::7, :32] = -np.inf                                  # no finite sample in these rows: the exact pass takes over
+    g[:, 2::5, :32] = -np.inf
+    df, dg = _bf16_case(oracle, f, g, labels, tl, ll, blank)
+    df, dg = df.float().cpu().numpy(), dg.float().cpu().numpy()
+    assert not np.isnan(df).any() and not np.isnan(dg).any()
+    for sl in (slice(300, 340), slice(500, 560)):
+        assert not df[..., sl].any() and not dg[..., sl].any()

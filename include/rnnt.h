@@ -386,7 +386,10 @@ rnntStatus_t compute_rnnt_loss_add_bwd(const float* const trans_acts,
 /* The two-phase additive-joint entries with the STORAGE type of the activations as an argument:
  * dtype_code 0 = fp32 (identical to compute_rnnt_loss_add_fwd_fastemit / compute_rnnt_loss_add_bwd),
  * 2 = bf16, 3 = fp16 (raw 16-bit storage of trans_acts, pred_acts and both gradients; every kernel
- * computes in fp32; costs and grad_scale stay float).  Same workspace query, same conventions. */
+ * computes in fp32 -- element-wise work and accumulation in fp32; with 16-bit storage, rows of whole 16-byte packets and 512
+ * symbols or more the three contractions run on the bf16 matrix cores with every operand split into a bf16 hi + lo pair,
+ * ~2^-17 relative per product, otherwise on the fp32 ones --; costs and grad_scale stay float).  Same workspace query, same
+ * conventions. */
 rnntStatus_t compute_rnnt_loss_add_fwd_dt(const void* trans_acts,
                                           const void* pred_acts,
                                           const int* const flat_labels,

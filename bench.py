@@ -150,6 +150,48 @@ def cpu_baseline(w, acts, labels, act_lens, label_lens, budget_samples):
                                              % (n2, N, N / n2)))
 
 
+def measure_traffic(argv_tail, kernel="grad_flat_kernel"):
+    """HBM bytes per launch of the dominant kernel, MEASURED for this command on this box: two extra passes of the same
+    workload (3 steps) under `rocprofv3 --pmc FETCH_SIZE --kernel-trace` and `--pmc WRITE_SIZE --kernel-trace` (separate
+    passes, counters in their own runs, as MI355X_MICROARCH.md's HBM section prescribes), FETCH_SIZE doubled (that guide's
+    gfx950 correction for wide coalesced reads), both counters in KiB.  Outside the timed region; None if rocprofv3 is
+    not there or a pass fails (the committed profiles/ figure is reported then, and labelled so)."""
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    prof = shutil.which("rocprofv3")
+    if prof is None:
+        return None
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    try:
+        from make_traffic import per_launch
+    except ImportError:
+        return None
+    got = {}
+    tmp = tempfile.mkdtemp(prefix="rnnt_pmc_", dir="/tmp")
+    try:
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+            out_dir = os.path.join(tmp, ctr)
+            cmd = [prof, "--pmc", ctr, "--kernel-trace", "-d", out_dir, "-o", "pmc", "--", sys.executable,
+                   os.path.abspath(__file__)] + argv_tail + ["--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-verify",
+                                                             "--no-traffic-pass"]
+            r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True, timeout=600)
+            dbs = glob.glob(os.path.join(out_dir, "**", "*.db"), recursive=True)
+            if r.returncode != 0 or not dbs:
+                return None
+            per = per_launch(dbs[0], ctr)
+            hit = [v for k, v in per.items() if kernel in k]
+            if not hit:
+                return None
+            got[ctr] = hit[0]
+    except (OSError, subprocess.SubprocessError, ValueError, KeyError, Exception):       # noqa: BLE001 -- measurement aid only
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    return int((2 * got["FETCH_SIZE"] + got["WRITE_SIZE"]) * 1024)
+
+
 def verify_batch(w, acts, labels, act_lens, label_lens, grads, costs):
     """Parity evidence for THIS run, outside the timed region: the first and the last sample of the timed batch (the
     gradients and costs the last timed step left behind) against the fp64 oracle on the same -- storage-rounded --
@@ -195,6 +237,9 @@ def main():
                     help="sharded step through the two-phase entry with the all-reduce BESIDE the gradient pass (A/B runs)")
     ap.add_argument("--force-sharded", action="store_true",
                     help="dev: run the multi-GPU step (async entry + RCCL all-reduce) even with one rank")
+    ap.add_argument("--no-traffic-pass", action="store_true",
+                    help="do not run the two extra rocprofv3 --pmc passes that measure `roofline.traffic` for this run "
+                         "(one GPU only; the figure of the newest committed profiles/r*_traffic.json is reported instead)")
     ap.add_argument("--no-verify", action="store_true",
                     help="skip the parity check of the timed batch (two samples against the fp64 oracle, outside the "
                          "timed region; its result is the JSON line's `check` object)")
@@ -487,20 +532,33 @@ def main():
         gk = sm[3]
         traffic = None
         traffic_file = None
-        try:   # PMC-measured HBM bytes per launch of this kernel, from the committed rocprofv3 passes (newest round)
-            import glob
-            traffic_file = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))[-1]
-            tj = json.load(open(traffic_file))
-            if not args.override and not args.varlen:
-                traffic = tj[args.workload]["grad_flat_kernel"]["traffic_bytes"]
-        except (OSError, KeyError, ValueError, IndexError):
-            pass
+        traffic_source = None
+        if not sharded and not args.no_traffic_pass and not args.packed and not args.graph:
+            tail = ["--workload", args.workload]
+            if args.override:
+                tail += ["--override", args.override]
+            if args.varlen:
+                tail += ["--varlen"]
+            traffic = measure_traffic(tail)
+            if traffic is not None:
+                traffic_source = ("measured for this run: two extra passes of the same workload under rocprofv3 --pmc FETCH_SIZE / "
+                                  "--pmc WRITE_SIZE with --kernel-trace (3 steps each, outside the timed region), 2 x FETCH + WRITE")
+        if traffic is None:
+            try:   # fallback: the committed rocprofv3 passes of the newest round
+                import glob
+                traffic_file = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))[-1]
+                tj = json.load(open(traffic_file))
+                if not args.override and not args.varlen:
+                    traffic = tj[args.workload]["grad_flat_kernel"]["traffic_bytes"]
+                    traffic_source = "profiles/%s (committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes; not measured in this run)" \
+                                     % os.path.basename(traffic_file)
+            except (OSError, KeyError, ValueError, IndexError):
+                pass
         out["roofline"] = {"bound": "hbm", "kernel": "grad_flat_kernel (second read of the logits + dense gradient write-back)",
                            "achieved": round(ab["grad_kernel"] / (gk * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS,
                            "unit": "GB/s", "frac": round(ab["grad_kernel"] / (gk * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                            "traffic": traffic, "bytes_algo": ab["grad_kernel"], "avg_ms": round(gk, 4),
-                           "traffic_source": "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)"
-                           % os.path.basename(traffic_file) if traffic else None}
+                           "traffic_source": traffic_source}
         out["stage_ms"] = {"row_stats": round(sm[0], 4), "lattice": round(sm[1], 4), "coef": round(sm[2], 4),
                            "grad": round(sm[3], 4), "enqueue_span": round(sm[4], 4)}
         out["stats_roofline"] = {"achieved": round(ab["stats_kernel"] / (sm[0] * 1e-3) / 1e9, 1),

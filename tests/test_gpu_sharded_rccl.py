@@ -137,7 +137,7 @@ def test_bench_sharded_step_on_one_rank():
     box too: same loss sum as the plain one-GPU step on the same inputs, a complete JSON line as the LAST line of stdout."""
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29547")
     base = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--workload", "c5", "--steps", "4", "--warmup", "1",
-            "--no-cpu-baseline"]
+            "--no-cpu-baseline", "--no-traffic-pass"]
     lines = []
     for extra in (["--force-sharded"], ["--force-sharded", "--overlap-collective"], []):
         out = subprocess.run(base + extra, capture_output=True, text=True, timeout=900, env=env)

@@ -11,11 +11,11 @@ OUT=$REPO/gpurun_out
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 for wl in $WLS; do
-  python "$REPO/bench.py" --workload $wl --steps 50 --warmup 5 $( [ "$wl" = c3 ] || echo --no-cpu-baseline ) \
+  python "$REPO/bench.py" --workload $wl --steps 50 --warmup 5 --no-traffic-pass $( [ "$wl" = c3 ] || echo --no-cpu-baseline ) \
       > "$OUT/${TAG}_bench_${wl}.json" 2> "$OUT/${TAG}_bench_${wl}.err"
   rm -rf /tmp/prof_$wl
   rocprofv3 --kernel-trace --stats -d /tmp/prof_$wl -o trace -- python "$REPO/bench.py" --workload $wl --steps 20 \
-      --warmup 3 --no-cpu-baseline > "$OUT/${TAG}_trace_${wl}.log" 2>&1
+      --warmup 3 --no-cpu-baseline --no-traffic-pass > "$OUT/${TAG}_trace_${wl}.log" 2>&1
   db=$(find /tmp/prof_$wl -name "*.db" | head -1)
   [ -n "$db" ] && python "$REPO/tools/rocpd_summary.py" "$db" \
       "$TAG kernel trace: rocprofv3 --kernel-trace --stats -- python bench.py --workload $wl --steps 20 --warmup 3 --no-cpu-baseline" \
@@ -24,7 +24,7 @@ for wl in $WLS; do
     for ctr in FETCH_SIZE WRITE_SIZE; do
       rm -rf /tmp/pmc_${wl}_$ctr
       rocprofv3 --pmc $ctr --kernel-trace -d /tmp/pmc_${wl}_$ctr -o pmc -- python "$REPO/bench.py" --workload $wl \
-          --steps 3 --warmup 1 --no-cpu-baseline > "$OUT/${TAG}_pmc_${wl}_$ctr.log" 2>&1
+          --steps 3 --warmup 1 --no-cpu-baseline --no-traffic-pass > "$OUT/${TAG}_pmc_${wl}_$ctr.log" 2>&1
       db=$(find /tmp/pmc_${wl}_$ctr -name "*.db" | head -1)
       if [ -n "$db" ]; then
         cp "$db" "$OUT/${TAG}_pmc_${wl}_$ctr.db"

@@ -34,7 +34,7 @@ def main():
             m = re.search(r"average 10 time cost: ([0-9.]+) ms variance: ([0-9.]+)", tt.stdout)
             tt_s = "%.3f (%.4f)" % (float(m.group(1)), float(m.group(2))) if m else "failed"
             b = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", wl, "--override", "N=%d" % N,
-                                "--steps", "50", "--warmup", "5", "--no-cpu-baseline"], capture_output=True, text=True)
+                                "--steps", "50", "--warmup", "5", "--no-cpu-baseline", "--no-traffic-pass"], capture_output=True, text=True)
             line = [l for l in b.stdout.splitlines() if l.startswith("{")]
             if line:
                 j = json.loads(line[-1])

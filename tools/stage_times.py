@@ -4,7 +4,7 @@ Usage: python tools/stage_times.py c3 c5 ...   (honours RNNT_TUNE)"""
 import json, os, subprocess, sys
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for w in sys.argv[1:] or ["c3"]:
-    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--workload", w, "--no-cpu-baseline",
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--workload", w, "--no-cpu-baseline", "--no-traffic-pass",
                           "--steps", "20", "--warmup", "5", "--override", os.environ.get("OVERRIDE", "")] + (["--varlen"] if os.environ.get("VARLEN") else []), capture_output=True, text=True)
     line = [l for l in out.stdout.splitlines() if l.startswith("{")]
     if not line:

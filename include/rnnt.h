@@ -177,6 +177,29 @@ rnntStatus_t compute_rnnt_loss_async(const void* activations,
                                      rnntOptions options,
                                      int dtype_code);
 
+/* Batch-sharded step for one rank of a multi-GPU job (samples are independent, every rank runs the path on
+ * its own slab of the batch, gradients stay local, and the data path needs exactly ONE collective): compute_rnnt_loss_async
+ * on this rank's shard, then [summed loss, sample count] of the shard as two fp64 values into `loss_sum_count_device`, then --
+ * when `rccl_comm` is not NULL -- one in-place ncclAllReduce(sum) of those 16 bytes over the communicator (an `ncclComm_t` of
+ * RCCL, passed as void*; shards may be ragged, the mean is sum / count of the reduced pair), all enqueued on options.stream:
+ * no host copy, no synchronisation.  RCCL is looked up at run time (librccl.so.1): the library has no link dependency on it;
+ * EXECUTION_FAILED if a communicator is given and RCCL cannot be found or the collective fails.  rccl_comm == NULL leaves
+ * the local pair (single GPU, or a caller with its own collective).  Not in the reference (no multi-device layer). */
+rnntStatus_t compute_rnnt_loss_sharded(const void* activations,
+                                       void* gradients,
+                                       const int* const flat_labels,
+                                       const int* const label_lengths,
+                                       const int* const input_lengths,
+                                       int alphabet_size,
+                                       int minibatch,
+                                       void* costs_device,
+                                       const void* grad_scale_device,
+                                       double* loss_sum_count_device,
+                                       void* rccl_comm,
+                                       void* workspace,
+                                       rnntOptions options,
+                                       int dtype_code);
+
 /* Two-phase form for autograd frameworks ("fused backward").
  * compute_rnnt_loss_fwd enqueues the row statistics, the lattice and -- with prepare_backward != 0 --
  * the gradient-coefficient table, and writes the costs to `costs_device`; compute_rnnt_loss_bwd,

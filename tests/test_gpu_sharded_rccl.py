@@ -169,3 +169,123 @@ def test_bench_refuses_more_gpus_than_visible():
                          capture_output=True, text=True, timeout=600)
     assert out.returncode == 2
     assert "refusing" in out.stderr and not out.stdout.strip()
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# compute_rnnt_loss_sharded: the sharded step behind the C-ABI, with the collective issued by the library itself
+import ctypes as C
+
+
+class _NcclUniqueId(C.Structure):
+    _fields_ = [("internal", C.c_char * 128)]               # rccl.h: NCCL_UNIQUE_ID_BYTES
+
+
+def _rccl():
+    """The RCCL the library itself resolves (dlopen by soname: the process's loaded copy when there is one)."""
+    for name in ("librccl.so.1", "librccl.so"):
+        try:
+            lib = C.CDLL(name)
+        except OSError:
+            continue
+        lib.ncclGetUniqueId.argtypes = [C.POINTER(_NcclUniqueId)]
+        lib.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, _NcclUniqueId, C.c_int]
+        lib.ncclCommDestroy.argtypes = [C.c_void_p]
+        return lib
+    pytest.skip("no librccl in this environment")
+
+
+def _sharded_call(acts, labels, tl, ll, comm):
+    """One compute_rnnt_loss_sharded call; returns (costs, grads, [sum, count])."""
+    from warprnnt_pytorch import _lib
+    lib = _lib.lib()
+    dev = acts.device
+    N, T, U, A = acts.shape
+    costs = torch.zeros(N, device=dev)
+    grads = torch.full_like(acts, 5.0)
+    pair = torch.full((2,), -1.0, dtype=torch.float64, device=dev)
+    ws = torch.empty(_lib.workspace_bytes(T, U, N, True, 4), dtype=torch.uint8, device=dev)
+    opt = _lib.rnntOptions(loc=1, num_threads=0, stream=torch.cuda.current_stream(dev).cuda_stream, blank_label=0, maxT=T,
+                           maxU=U, batch_first=True)
+    st = lib.compute_rnnt_loss_sharded(acts.data_ptr(), grads.data_ptr(), labels.data_ptr(), ll.data_ptr(), tl.data_ptr(), A, N,
+                                       costs.data_ptr(), None, pair.data_ptr(), comm, ws.data_ptr(), opt, _lib.DT_F32)
+    assert st == 0, _lib.status_string(st)
+    torch.cuda.synchronize(dev)
+    return costs, grads, pair
+
+
+def test_native_sharded_entry_on_one_rank():
+    """compute_rnnt_loss_sharded without a communicator (the local [sum, count] pair) and over a ONE-rank RCCL communicator
+    created here (a 1-GPU box can run that): costs and gradients of compute_rnnt_loss_async, pair = [sum of the costs in
+    fp64, N] either way; argument validation."""
+    from warprnnt_pytorch import _lib, warp_rnnt
+    dev = torch.device("cuda:0")
+    acts, labels, tl, ll = _batch(dev)
+    ref_c = torch.zeros(acts.shape[0], device=dev)
+    ref_g = torch.zeros_like(acts)
+    warp_rnnt.gpu_rnnt_async(acts, labels, tl, ll, ref_c, ref_g, 0)
+    torch.cuda.synchronize()
+    costs, grads, pair = _sharded_call(acts, labels, tl, ll, None)
+    assert torch.equal(costs, ref_c) and torch.equal(grads, ref_g)
+    assert pair[1].item() == acts.shape[0] and abs(pair[0].item() - ref_c.double().sum().item()) < 1e-9
+    rccl = _rccl()
+    uid = _NcclUniqueId()
+    assert rccl.ncclGetUniqueId(C.byref(uid)) == 0
+    comm = C.c_void_p()
+    assert rccl.ncclCommInitRank(C.byref(comm), 1, uid, 0) == 0
+    try:
+        costs2, grads2, pair2 = _sharded_call(acts, labels, tl, ll, comm)
+    finally:
+        rccl.ncclCommDestroy(comm)
+    assert torch.equal(costs2, ref_c) and torch.equal(grads2, ref_g) and torch.equal(pair2, pair)
+    lib = _lib.lib()
+    opt = _lib.rnntOptions(loc=1, num_threads=0, stream=None, blank_label=0, maxT=acts.shape[1], maxU=acts.shape[2], batch_first=True)
+    assert lib.compute_rnnt_loss_sharded(acts.data_ptr(), None, labels.data_ptr(), ll.data_ptr(), tl.data_ptr(), acts.shape[3],
+                                         acts.shape[0], costs.data_ptr(), None, None, None, costs.data_ptr(), opt, 0) == 2
+
+
+def _native_worker(rank, world, uid_bytes, q):
+    for p in (ROOT, os.path.join(ROOT, "warp-transducer_amd")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    torch.cuda.set_device(rank)
+    dev = torch.device("cuda", rank)
+    rccl = _rccl()
+    uid = _NcclUniqueId()
+    C.memmove(C.byref(uid), uid_bytes, 128)
+    comm = C.c_void_p()
+    assert rccl.ncclCommInitRank(C.byref(comm), world, uid, rank) == 0
+    acts, labels, tl, ll = _batch(dev)
+    sl = slice(0, 4) if rank == 0 else slice(4, 6)                  # ragged shards: 4 + 2 samples
+    costs, grads, pair = _sharded_call(acts[sl].contiguous(), labels[sl].contiguous(), tl[sl].contiguous(), ll[sl].contiguous(), comm)
+    q.put((rank, costs.cpu().numpy(), pair.cpu().numpy()))
+    rccl.ncclCommDestroy(comm)
+
+
+def test_native_sharded_entry_over_two_rccl_ranks():
+    """Two processes, one GPU each, ragged shards (4 + 2 samples): every rank's pair is the GLOBAL [sum, count]."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs 2 GPUs (one RCCL rank per device)")
+    import torch.multiprocessing as mp
+    from warprnnt_pytorch import warp_rnnt
+    dev = torch.device("cuda:0")
+    acts, labels, tl, ll = _batch(dev)
+    ref_c = torch.zeros(acts.shape[0], device=dev)
+    warp_rnnt.gpu_rnnt_async(acts, labels, tl, ll, ref_c, torch.zeros_like(acts), 0)
+    torch.cuda.synchronize()
+    rccl = _rccl()
+    uid = _NcclUniqueId()
+    assert rccl.ncclGetUniqueId(C.byref(uid)) == 0
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_native_worker, args=(r, 2, bytes(uid.internal), q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted((q.get(timeout=300) for _ in procs), key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    total = ref_c.double().sum().item()
+    for rank, costs, pair in got:
+        assert pair[1] == 6 and abs(pair[0] - total) <= 1e-9 * abs(total)
+        assert np.array_equal(costs, ref_c[:4].cpu().numpy() if rank == 0 else ref_c[4:].cpu().numpy())

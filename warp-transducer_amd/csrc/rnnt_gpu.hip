@@ -485,6 +485,55 @@ rnntStatus_t compute_rnnt_loss_async(const void* activations, void* gradients, c
                      costs_device, grad_scale_device, workspace, options, dtype_code, 3, -1);
 }
 
+// RCCL is looked up at run time (the library links against no collective library): the process's already loaded librccl
+// when there is one (PyTorch ships its own), else the ROCm one.
+struct Rccl {
+    bool tried = false;
+    int (*all_reduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
+};
+static Rccl& rccl() {
+    static Rccl r;
+    static std::mutex mu;
+    std::lock_guard<std::mutex> g(mu);
+    if (!r.tried) {
+        r.tried = true;
+        for (const char* name : {"librccl.so.1", "librccl.so"}) {
+            void* h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+            if (h == nullptr) continue;
+            r.all_reduce = reinterpret_cast<int (*)(const void*, void*, size_t, int, int, void*, hipStream_t)>(dlsym(h, "ncclAllReduce"));
+            if (r.all_reduce != nullptr) break;
+        }
+    }
+    return r;
+}
+
+rnntStatus_t compute_rnnt_loss_sharded(const void* activations, void* gradients, const int* const flat_labels,
+                                       const int* const label_lengths, const int* const input_lengths,
+                                       int alphabet_size, int minibatch, void* costs_device,
+                                       const void* grad_scale_device, double* loss_sum_count_device, void* rccl_comm,
+                                       void* workspace, rnntOptions options, int dtype_code) {
+    if (bad_args(activations, flat_labels, label_lengths, input_lengths, costs_device, workspace,
+                 alphabet_size, minibatch, options) || options.loc != RNNT_GPU || loss_sum_count_device == nullptr)
+        return RNNT_STATUS_INVALID_VALUE;
+    if (rccl_comm != nullptr && rccl().all_reduce == nullptr) return RNNT_STATUS_EXECUTION_FAILED;   // no RCCL in this process
+    const rnntStatus_t st = run_async(activations, gradients, flat_labels, label_lengths, input_lengths, alphabet_size,
+                                      minibatch, costs_device, grad_scale_device, workspace, options, dtype_code, 3, -1);
+    if (st != RNNT_STATUS_SUCCESS) return st;
+    hipStream_t stream = reinterpret_cast<hipStream_t>(options.stream);
+    (void)hipGetLastError();
+    if (dtype_code == 1)
+        hipLaunchKernelGGL((loss_sum_kernel<double>), dim3(1), dim3(256), 0, stream, static_cast<const double*>(costs_device),
+                           minibatch, loss_sum_count_device);
+    else
+        hipLaunchKernelGGL((loss_sum_kernel<float>), dim3(1), dim3(256), 0, stream, static_cast<const float*>(costs_device),
+                           minibatch, loss_sum_count_device);
+    if (hipGetLastError() != hipSuccess) return RNNT_STATUS_EXECUTION_FAILED;
+    if (rccl_comm != nullptr &&
+        rccl().all_reduce(loss_sum_count_device, loss_sum_count_device, 2, /*ncclFloat64*/ 8, /*ncclSum*/ 0, rccl_comm, stream) != 0)
+        return RNNT_STATUS_EXECUTION_FAILED;
+    return RNNT_STATUS_SUCCESS;
+}
+
 rnntStatus_t compute_rnnt_loss_fwd(const void* activations, const int* const flat_labels,
                                    const int* const label_lengths, const int* const input_lengths,
                                    int alphabet_size, int minibatch, void* costs_device, void* workspace,

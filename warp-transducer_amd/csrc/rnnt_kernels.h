@@ -1344,6 +1344,23 @@ __global__ __launch_bounds__(256) void coef_kernel(
 }
 
 // ------------------------------------------------------------------------------------------
+// [summed loss, sample count] of a shard in fp64 -- the 16-byte payload of the batch-sharded step's one collective
+// (compute_rnnt_loss_sharded).  One block of 256 threads; a marker NaN of an invalid sample propagates into the sum.
+template <typename C>
+__global__ __launch_bounds__(256) void loss_sum_kernel(const C* __restrict__ costs, int N, double* __restrict__ out2) {
+    __shared__ double part[4];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < N; i += 256) s += static_cast<double>(costs[i]);
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        out2[0] = part[0] + part[1] + part[2] + part[3];
+        out2[1] = static_cast<double>(N);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // Packed layout with a per-sample gradient scale: one scale per packed ROW, so that the gradient kernel's lookup
 // needs no search (rowscale lives in the `alpha` array of the workspace, dead once the coefficients exist).
 // grid = (N, 8), block = 256.

@@ -39,6 +39,8 @@ EXPORTS = {
     "compute_rnnt_loss_fp16": (C.c_int, _LOSS_ARGS),
     "compute_rnnt_loss_async": (C.c_int, [_PTR, _PTR, _PTR, _PTR, _PTR, C.c_int, C.c_int, _PTR,
                                           _PTR, _PTR, rnntOptions, C.c_int]),
+    "compute_rnnt_loss_sharded": (C.c_int, [_PTR, _PTR, _PTR, _PTR, _PTR, C.c_int, C.c_int, _PTR, _PTR, _PTR, _PTR, _PTR,
+                                            rnntOptions, C.c_int]),
     "compute_rnnt_loss_fwd": (C.c_int, [_PTR, _PTR, _PTR, _PTR, C.c_int, C.c_int, _PTR, _PTR, rnntOptions,
                                         C.c_int, C.c_int]),
     "compute_rnnt_loss_bwd": (C.c_int, [_PTR, _PTR, _PTR, C.c_int, C.c_int, _PTR, rnntOptions, C.c_int]),

@@ -192,6 +192,46 @@ def measure_traffic(argv_tail, kernel="grad_flat_kernel"):
     return int((2 * got["FETCH_SIZE"] + got["WRITE_SIZE"]) * 1024)
 
 
+class _NcclUniqueId(C.Structure):
+    _fields_ = [("internal", C.c_char * 128)]               # rccl.h: NCCL_UNIQUE_ID_BYTES
+
+
+def native_communicator(world, rank, dev):
+    """An RCCL communicator of this job's ranks for compute_rnnt_loss_sharded (the library issues the collective itself):
+    rank 0 draws the unique id, torch.distributed broadcasts its 128 bytes, every rank joins.  None when RCCL cannot be
+    loaded or the communicator cannot be formed (the step then uses torch.distributed's all-reduce)."""
+    try:
+        rccl = None
+        for name in ("librccl.so.1", "librccl.so"):
+            try:
+                rccl = C.CDLL(name)
+                break
+            except OSError:
+                continue
+        if rccl is None:
+            print("bench.py: librccl not loadable; using torch.distributed's all-reduce", file=sys.stderr)
+            return None, None
+        rccl.ncclGetUniqueId.argtypes = [C.POINTER(_NcclUniqueId)]
+        rccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, _NcclUniqueId, C.c_int]
+        rccl.ncclCommDestroy.argtypes = [C.c_void_p]
+        uid = _NcclUniqueId()
+        if rank == 0 and rccl.ncclGetUniqueId(C.byref(uid)) != 0:
+            return None, None
+        raw = torch.frombuffer(bytearray(C.string_at(C.addressof(uid), 128)), dtype=torch.uint8).to(dev)   # (all 128 bytes: a c_char field reads as a NUL-terminated string)
+        if world > 1:
+            dist.broadcast(raw, src=0)
+        C.memmove(C.byref(uid), bytes(raw.cpu().numpy().tobytes()), 128)
+        comm = C.c_void_p()
+        rc = rccl.ncclCommInitRank(C.byref(comm), world, uid, rank)
+        if rc != 0:
+            print("bench.py: ncclCommInitRank failed (%d); using torch.distributed's all-reduce" % rc, file=sys.stderr)
+            return None, None
+        return rccl, comm
+    except Exception as e:                                         # noqa: BLE001 -- fall back to torch.distributed's collective
+        print("bench.py: no native RCCL communicator (%r); using torch.distributed's all-reduce" % (e,), file=sys.stderr)
+        return None, None
+
+
 def verify_batch(w, acts, labels, act_lens, label_lens, grads, costs):
     """Parity evidence for THIS run, outside the timed region: the first and the last sample of the timed batch (the
     gradients and costs the last timed step left behind) against the fp64 oracle on the same -- storage-rounded --
@@ -235,6 +275,9 @@ def main():
                     help="one GPU: compute_rnnt_loss_async captured into a HIP graph once, step = replay + device sync")
     ap.add_argument("--overlap-collective", action="store_true",
                     help="sharded step through the two-phase entry with the all-reduce BESIDE the gradient pass (A/B runs)")
+    ap.add_argument("--torch-collective", action="store_true",
+                    help="sharded step: torch.sum + torch.distributed.all_reduce instead of compute_rnnt_loss_sharded "
+                         "(the library's own ncclAllReduce of [sum, count]) -- A/B runs")
     ap.add_argument("--force-sharded", action="store_true",
                     help="dev: run the multi-GPU step (async entry + RCCL all-reduce) even with one rank")
     ap.add_argument("--no-traffic-pass", action="store_true",
@@ -318,6 +361,7 @@ def main():
         stream = torch.cuda.current_stream(dev).cuda_stream
         opt = _lib.rnntOptions(loc=_lib.RNNT_GPU, num_threads=0, stream=stream, blank_label=0, maxT=T,
                                maxU=U, batch_first=True)
+        rccl_lib = comm = None
         if args.packed:
             costs = torch.zeros(N, dtype=torch.float32, device=dev)
             code = {"fp32": _lib.DT_F32, "bf16": _lib.DT_BF16}[w["dtype"]]
@@ -383,7 +427,22 @@ def main():
                 torch.sum(costs, dim=0, keepdim=True, dtype=torch.float64, out=packed)
                 return dist.all_reduce(packed, async_op=async_op)
 
-            if args.overlap_collective:
+            rccl_lib, comm = (None, None) if (args.torch_collective or args.overlap_collective) else native_communicator(world, rank, dev)
+            pair = torch.zeros(2, dtype=torch.float64, device=dev)       # [summed loss, sample count] of the whole job
+            sh_argv = (acts.data_ptr(), grads.data_ptr(), labels.data_ptr(), label_lens.data_ptr(), act_lens.data_ptr(), A, N,
+                       costs.data_ptr(), None, pair.data_ptr(), comm, ws.data_ptr(), opt, code)
+            collective = ("compute_rnnt_loss_sharded: one ncclAllReduce of [sum, count] (16 B) issued by the library on the compute "
+                          "stream" if comm is not None else "torch.sum + torch.distributed.all_reduce of the summed loss (8 B)")
+            if comm is not None:
+                def step():
+                    # the whole sharded step behind the C-ABI: loss + gradients of this rank's shard, the shard's [sum, count],
+                    # ONE in-place ncclAllReduce of those 16 bytes over xGMI -- then the one device synchronisation of the step
+                    st = lib.compute_rnnt_loss_sharded(*sh_argv)
+                    assert st == 0, _lib.status_string(st)
+                    torch.cuda.synchronize(dev)
+                    lib.rnnt_profile_collect()
+                    return pair
+            elif args.overlap_collective:
                 def step():
                     # two-phase entry: the costs exist after the forward phase, so the collective (16 bytes, RCCL's own
                     # stream) can run BESIDE the gradient pass.  Measured on one rank (`profiles/r02x_*`): the two
@@ -474,6 +533,7 @@ def main():
                          single_gpu_same_workload_ms=round(max(per_rank_local), 4),
                          per_rank_single_gpu_ms=[round(v, 4) for v in per_rank_local],
                          scaling_efficiency=round(max(per_rank_local) / max(per_rank), 4),
+                         collective=collective,
                          note="single_gpu_same_workload_ms = the same per-GPU batch through compute_rnnt_loss_async + "
                               "device sync with NO collective, all ranks at once (max over ranks); scaling_efficiency = "
                               "that / value (weak scaling: 1.0 = the all-reduce and the barrier are free)")
@@ -493,6 +553,9 @@ def main():
             res["verify"] = verify_batch(w, acts, labels, act_lens, label_lens, grads, costs)
         if with_cpu and rank == 0 and not args.packed:
             res["cpu"] = cpu_baseline(w, acts, labels, act_lens, label_lens, args.cpu_samples)
+        if comm is not None:
+            torch.cuda.synchronize(dev)
+            rccl_lib.ncclCommDestroy(comm)
         del acts, grads, ws
         torch.cuda.empty_cache()
         return res

@@ -139,11 +139,14 @@ def test_bench_sharded_step_on_one_rank():
     base = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--workload", "c5", "--steps", "4", "--warmup", "1",
             "--no-cpu-baseline", "--no-traffic-pass"]
     lines = []
-    for extra in (["--force-sharded"], ["--force-sharded", "--overlap-collective"], []):
+    for extra in (["--force-sharded"], ["--force-sharded", "--overlap-collective"], [], ["--force-sharded", "--torch-collective"]):
         out = subprocess.run(base + extra, capture_output=True, text=True, timeout=900, env=env)
         assert out.returncode == 0, out.stderr[-2000:]
         lines.append(json.loads(out.stdout.strip().splitlines()[-1]))
-    sh, ov, plain = lines
+    sh, ov, plain, tc = lines
+    # the default sharded step is the library's own (compute_rnnt_loss_sharded); --torch-collective is the round-2 form
+    assert "compute_rnnt_loss_sharded" in sh["multi_gpu"]["collective"] and "torch.distributed" in tc["multi_gpu"]["collective"]
+    assert abs(tc["check"]["loss_sum"] - plain["check"]["loss_sum"]) <= 1e-6 * abs(plain["check"]["loss_sum"])
     assert abs(ov["check"]["loss_sum"] - plain["check"]["loss_sum"]) <= 1e-6 * abs(plain["check"]["loss_sum"])
     assert ov["stage_ms"]["grad"] > 0 and ov["stage_ms"]["row_stats"] > 0      # two calls, one profiled step
     assert sh["n_gpus"] == 1 and sh["scaling"] == "weak" and sh["dtype"] == "bf16" and sh["value"] > 0
@@ -151,7 +154,7 @@ def test_bench_sharded_step_on_one_rank():
     assert abs(sh["check"]["loss_sum"] - plain["check"]["loss_sum"]) <= 1e-6 * abs(plain["check"]["loss_sum"])
     assert sh["stage_ms"]["grad"] > 0 and sh["stage_ms"]["row_stats"] > 0
     # the multi-GPU line is self-sufficient: ranks RCCL saw, per-rank times, the same workload without the collective
-    for line in (sh, ov):
+    for line in (sh, ov, tc):
         m = line["multi_gpu"]
         assert m["ranks_seen"] == 1 and m["backend"] == "nccl" and len(m["per_rank_ms"]) == 1
         assert m["single_gpu_same_workload_ms"] > 0 and 0.3 < m["scaling_efficiency"] <= 1.5
@@ -278,7 +281,8 @@ def test_native_sharded_entry_over_two_rccl_ranks():
     assert rccl.ncclGetUniqueId(C.byref(uid)) == 0
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_native_worker, args=(r, 2, bytes(uid.internal), q)) for r in range(2)]
+    uid_bytes = C.string_at(C.addressof(uid), 128)                 # all 128 bytes (a c_char field reads as a NUL-terminated string)
+    procs = [ctx.Process(target=_native_worker, args=(r, 2, uid_bytes, q)) for r in range(2)]
     for p in procs:
         p.start()
     got = sorted((q.get(timeout=300) for _ in procs), key=lambda t: t[0])

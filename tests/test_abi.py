@@ -125,3 +125,29 @@ def test_header_is_plain_c_and_cxx(tmp_path, lang, std, cc):
                        capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
 
+
+
+def test_round3_extension_entries_without_a_gpu():
+    """What the round-3 extension entries do before they touch a device: the extension revision, the staging switch (off
+    unless asked for; nothing allocated by toggling it), and INVALID_VALUE for missing arguments / the CPU location."""
+    lib = _lib.lib()
+    assert lib.get_warprnnt_extension_version() == 3
+    assert lib.rnnt_host_staging(-1) == 0 and lib.rnnt_host_staging_bytes() == 0        # default: the library allocates nothing
+    assert lib.rnnt_host_staging(1) == 0 and lib.rnnt_host_staging(-1) == 1
+    assert lib.rnnt_host_staging(0) == 1 and lib.rnnt_host_staging(-1) == 0
+    assert lib.rnnt_host_staging_bytes() == 0 and lib.rnnt_host_staging_release() == 0
+    x = np.zeros(64, dtype=np.float64)
+    i = np.ones(8, dtype=np.int32)
+    gpu = _lib.rnntOptions(loc=1, num_threads=0, stream=None, blank_label=0, maxT=1, maxU=2, batch_first=True)
+    cpu = _lib.rnntOptions(loc=0, num_threads=1, stream=None, blank_label=0, maxT=1, maxU=2, batch_first=True)
+    p = x.ctypes.data
+    # likelihood read-back: NULL outputs, bad dtype code, CPU location
+    assert lib.compute_rnnt_loss_likelihoods(p, 1, gpu, 0, None, p) == 2
+    assert lib.compute_rnnt_loss_likelihoods(p, 1, gpu, 7, p, p) == 2
+    assert lib.compute_rnnt_loss_likelihoods(p, 1, cpu, 0, p, p) == 2
+    assert lib.compute_rnnt_loss_likelihoods(None, 1, gpu, 0, p, p) == 2
+    # sharded step: NULL pair, CPU location, NULL activations
+    args = (p, None, i.ctypes.data, i.ctypes.data, i.ctypes.data, 3, 1, p, None)
+    assert lib.compute_rnnt_loss_sharded(*args, None, None, p, gpu, 0) == 2
+    assert lib.compute_rnnt_loss_sharded(*args, p, None, p, cpu, 0) == 2
+    assert lib.compute_rnnt_loss_sharded(None, None, i.ctypes.data, i.ctypes.data, i.ctypes.data, 3, 1, p, None, p, None, p, gpu, 0) == 2

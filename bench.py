@@ -169,14 +169,15 @@ def measure_traffic(argv_tail, kernel="grad_flat_kernel"):
     except ImportError:
         return None
     got = {}
-    tmp = tempfile.mkdtemp(prefix="rnnt_pmc_", dir="/tmp")
+    tmp = None
     try:
+        tmp = tempfile.mkdtemp(prefix="rnnt_pmc_", dir="/tmp" if os.path.isdir("/tmp") else None)
         for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
             out_dir = os.path.join(tmp, ctr)
             cmd = [prof, "--pmc", ctr, "--kernel-trace", "-d", out_dir, "-o", "pmc", "--", sys.executable,
                    os.path.abspath(__file__)] + argv_tail + ["--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-verify",
                                                              "--no-traffic-pass"]
-            r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True, timeout=600)
+            r = subprocess.run(cmd, cwd=tmp, env=dict(os.environ, TMPDIR=tmp), capture_output=True, text=True, timeout=600)
             dbs = glob.glob(os.path.join(out_dir, "**", "*.db"), recursive=True)
             if r.returncode != 0 or not dbs:
                 return None
@@ -188,7 +189,8 @@ def measure_traffic(argv_tail, kernel="grad_flat_kernel"):
     except (OSError, subprocess.SubprocessError, ValueError, KeyError, Exception):       # noqa: BLE001 -- measurement aid only
         return None
     finally:
-        shutil.rmtree(tmp, ignore_errors=True)
+        if tmp is not None:
+            shutil.rmtree(tmp, ignore_errors=True)
     return int((2 * got["FETCH_SIZE"] + got["WRITE_SIZE"]) * 1024)
 
 

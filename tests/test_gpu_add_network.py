@@ -446,3 +446,42 @@ def test_bf16_matrix_core_kernels_with_masked_vocabulary(oracle):
     assert not np.isnan(df).any() and not np.isnan(dg).any()
     for sl in (slice(300, 340), slice(500, 560)):
         assert not df[..., sl].any() and not dg[..., sl].any()
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_full_size_c3_shape(oracle, dtype):
+    """The additive joint at the benchmark's size (N=128, T=150, U=21, A=5000; tools/add_network_bench.py): the first two
+    samples against the fp64 oracle on the materialised joint of the (rounded) inputs, ragged lengths on top, and over the
+    whole batch the size-independent properties -- every row of df and of dg sums to zero (each row of the joint's gradient
+    does), padded rows are exactly zero, costs finite."""
+    from warprnnt_pytorch.add_network import RNNTLossAdd
+    N, T, U, A = 128, 150, 21, 5000
+    dev = torch.device("cuda:0")
+    g0 = torch.Generator(device=dev).manual_seed(3)
+    f = torch.rand((N, T, A), generator=g0, device=dev).to(dtype).requires_grad_(True)
+    g = torch.rand((N, U, A), generator=g0, device=dev).to(dtype).requires_grad_(True)
+    labels = torch.randint(1, A, (N, U - 1), generator=g0, device=dev, dtype=torch.int32)
+    tl = torch.randint(T // 2, T + 1, (N,), generator=g0, device=dev, dtype=torch.int32)
+    ll = torch.randint((U - 1) // 2, U, (N,), generator=g0, device=dev, dtype=torch.int32)
+    tl[0], ll[0] = T, U - 1
+    tl[1], ll[1] = T - 37, 9
+    loss = RNNTLossAdd(blank=0, reduction="none")(f, g, labels, tl, ll)
+    loss.sum().backward()
+    assert bool(torch.isfinite(loss).all())
+    df, dg = f.grad.float(), g.grad.float()
+    bound = 2e-3 if dtype == torch.float32 else 0.5           # bf16: A roundings of 2^-9 relative each
+    assert df.sum(-1).abs().max().item() < bound and dg.sum(-1).abs().max().item() < bound
+    t_idx = torch.arange(T, device=dev).view(1, T)
+    u_idx = torch.arange(U, device=dev).view(1, U)
+    assert df[(t_idx >= tl.view(N, 1))].abs().max().item() == 0.0
+    assert dg[(u_idx > ll.view(N, 1))].abs().max().item() == 0.0
+    K = 2
+    fr, gr = f.detach()[:K].double().cpu().numpy(), g.detach()[:K].double().cpu().numpy()
+    z = fr[:, :, None, :] + gr[:, None, :, :]
+    oracle.lib().oracle_set_num_threads(K)
+    ref_c, ref_gz = oracle.rnnt_logits(z, labels[:K].cpu().numpy(), tl[:K].cpu().numpy(), ll[:K].cpu().numpy(), 0)
+    assert np.abs(loss[:K].detach().double().cpu().numpy() - ref_c).max() <= 1e-4 * np.abs(ref_c).max()
+    ulp = 0.0 if dtype == torch.float32 else 2.0 ** -8
+    rdf, rdg = ref_gz.sum(axis=2), ref_gz.sum(axis=1)
+    assert (np.abs(df[:K].double().cpu().numpy() - rdf) <= 2e-4 + 5e-5 * np.abs(rdf) + ulp * np.abs(rdf)).all()
+    assert (np.abs(dg[:K].double().cpu().numpy() - rdg) <= 2e-4 * (T / 32) + 5e-5 * np.abs(rdg) + ulp * np.abs(rdg)).all()

@@ -7,6 +7,7 @@
 // them (first call of a process: tools/first_call.py).  Everything here is static / template code, compiled into both.
 #pragma once
 
+#include <atomic>
 #include <hip/hip_runtime.h>
 
 #include <dlfcn.h>
@@ -172,10 +173,12 @@ static void ranges_mark(int i, bool do_fwd, bool do_bwd, const char* const names
 // additive-joint DF kernel (-1: vocabularies <= 256), lat2 = two lattice columns per lane (-1: maxU > 256),
 // jsamp = additive joint: sampled row references + guard instead of the row-maximum pass (rnnt_joint_kernels.h) on/off,
 // j16 = bf16 storage on the bf16 matrix cores (rnnt_joint16_kernels.h), bit 0 DG, bit 1 DF, bit 2 Z; j16pf = operand ping-pong there, j16nt = columns per lane of its DF / DG (8 | 4),
+// latlin = linear-domain lattice kernel (chain + helper wavefronts) for one-wavefront fp32 lattices: 0 off, 1 up to one block per CU,
+//          2 at any size and every block takes the log-domain fallback (tests), 3 at any size,
 // tile2d = 2-D cell-tile statistics kernel for short rows under wide lattices on/off.
 struct Tune { int sw = 4, nta = 1, gmax = 4194304, rows = 0, tile = 1, tilekb = 52, ppt = 2;
               int jfnk = 0, jfpf = 1, jgnk = 0, jgpf = 1, blk = 1, jzs = 0, xcd = 1, ctile = 1, pskip = 1, joh = -1;
-              int lat2 = -1, xst = 0, jsamp = 1, tilemax = kTileMaxRowBytes, j16 = 7, j16pf = 1, j16nt = 4, tile2d = 1; };
+              int lat2 = -1, xst = 0, jsamp = 1, tilemax = kTileMaxRowBytes, j16 = 7, j16pf = 1, j16nt = 4, tile2d = 1, latlin = 1; };
 #ifdef RNNT_DEV
 static Tune read_tune() {
     Tune t;
@@ -186,7 +189,7 @@ static Tune read_tune() {
         {"tilekb", &t.tilekb}, {"ppt", &t.ppt}, {"jfnk", &t.jfnk}, {"jfpf", &t.jfpf}, {"jgnk", &t.jgnk},
         {"jgpf", &t.jgpf}, {"blk", &t.blk}, {"jzs", &t.jzs}, {"xcd", &t.xcd}, {"ctile", &t.ctile},
         {"pskip", &t.pskip}, {"joh", &t.joh}, {"lat2", &t.lat2}, {"xst", &t.xst}, {"jsamp", &t.jsamp}, {"tilemax", &t.tilemax},
-        {"j16", &t.j16}, {"j16pf", &t.j16pf}, {"j16nt", &t.j16nt}, {"tile2d", &t.tile2d}};
+        {"j16", &t.j16}, {"j16pf", &t.j16pf}, {"j16nt", &t.j16nt}, {"tile2d", &t.tile2d}, {"latlin", &t.latlin}};
     // tokens are separated by ',', a token is key=value with the WHOLE key compared
     for (const char* p = e; *p;) {
         const char* end = strchr(p, ',');
@@ -273,6 +276,19 @@ static bool make_plan(Plan<C>& p, int A, int N, const rnntOptions& opt, void* wo
     return true;
 }
 
+// Compute units of the current device (256 on an MI355X in SPX mode, fewer in the partitioned modes), asked once per device.
+static inline int device_cus() {
+    static std::atomic<int> cache[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    int n = cache[dev].load(std::memory_order_relaxed);
+    if (n == 0) {
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        cache[dev].store(n, std::memory_order_relaxed);
+    }
+    return n;
+}
+
 // Stage 2: alpha (and, for gradients, beta) recursion; writes the costs.
 template <typename C> static void launch_lattice(Plan<C>& p, bool with_beta) {
     const int dirs = with_beta ? 2 : 1;
@@ -280,7 +296,17 @@ template <typename C> static void launch_lattice(Plan<C>& p, bool with_beta) {
     hipLaunchKernelGGL((lattice_kernel<C, MW, CC>), dim3(p.N * dirs), dim3(p.lat_w * 64), 0, p.stream, p.lp2,          \
                        p.alpha, p.beta, p.offa, p.offb, p.llf, p.llb, p.costs_dev, p.input_lengths, p.label_lengths,  \
                        p.maxT, p.maxU, p.Up, dirs)
-    if (p.Up <= 64) RNNT_LATTICE(1, 1);                            // one wavefront, no synchronisation
+    // One-wavefront fp32 lattices with at most one block per compute unit: the linear-domain chain with helper wavefronts
+    // (range guard + log-domain fallback inside).  Its eight wavefronts per (sample, direction) buy latency with idle
+    // SIMDs; past one block per CU there are none and the one-wavefront kernel is the faster again (N=128 T=200 U=41:
+    // 13.6 us against 17.2; N=192: 18.9 against 17.4; N=1024: 57 against 37).
+    if (p.Up <= 64 && sizeof(C) == 4 && tune().latlin && (tune().latlin >= 2 || p.N * dirs <= device_cus())) {
+        if constexpr (sizeof(C) == 4)
+            hipLaunchKernelGGL((lattice_lin_kernel<0>), dim3(p.N * dirs), dim3(kLinThreads), 0, p.stream, p.lp2, p.alpha, p.beta, p.offa, p.offb,
+                               p.llf, p.llb, p.costs_dev, p.input_lengths, p.label_lengths, p.maxT, p.maxU, p.Up, dirs,
+                               tune().latlin == 2 ? 1 : 0);
+    }
+    else if (p.Up <= 64) RNNT_LATTICE(1, 1);                       // one wavefront, no synchronisation
     else if (p.lat_cols == 1) RNNT_LATTICE(8, 1);                  // maxU <= 512, one column per lane
     else if (p.lat_w <= 4) RNNT_LATTICE(4, 2);                     // two columns per lane, one wavefront per SIMD
     else RNNT_LATTICE(8, 2);                                       // maxU <= 1024 in at most 8 wavefronts

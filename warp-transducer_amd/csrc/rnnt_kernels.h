@@ -851,24 +851,22 @@ __device__ __forceinline__ void lds_barrier() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
 
+// The sweep of ONE (sample, direction) by the W wavefronts whose threads call this with tid = 0 .. 64 W - 1 (the kernel
+// below: the whole block; the linear-domain kernel's fallback: its first wavefront, W = 1).
 template <typename L, int MAXW, int COLS>
-__global__ __launch_bounds__(MAXW * 64) void lattice_kernel(
+__device__ __forceinline__ void lattice_body(
         const LogPair<L>* __restrict__ lp2, L* __restrict__ alpha, L* __restrict__ beta,
         double* __restrict__ offa, double* __restrict__ offb, double* __restrict__ ll_fwd,
         double* __restrict__ ll_bwd, L* __restrict__ costs_dev, const int* __restrict__ xlen,
-        const int* __restrict__ ylen, int maxT, int maxU, int Up, int dirs) {
+        const int* __restrict__ ylen, int maxT, int maxU, int Up, const int b, const int dir, const int tid, const int W) {
     constexpr int C = LatChunk<L, MAXW, COLS>::C;
     constexpr bool MULTI = MAXW > 1;
     using IO = LatIO<L, COLS>;
     __shared__ L ring[MAXW][2][C];
     __shared__ double ringoff[MAXW][2];
-    const int b = blockIdx.x / dirs;
-    const int dir = blockIdx.x - b * dirs;
-    const int tid = threadIdx.x;
     const int u0 = tid * COLS;                       // first of this lane's COLS adjacent columns
     const int lane = tid & 63;
     const int wave = uniform(tid >> 6);
-    const int W = blockDim.x >> 6;
     // Lengths live on the device, so the host cannot validate them (the CPU location does: rnnt_cpu.cpp).  A
     // sample whose lengths do not fit the tensor is run on clamped lengths (memory-safe) and its cost becomes
     // the marker NaN of cost_invalid(), which the synchronous entry points turn into RNNT_STATUS_INVALID_VALUE.
@@ -1100,6 +1098,296 @@ __global__ __launch_bounds__(MAXW * 64) void lattice_kernel(
             ll_bwd[b] = (static_cast<double>(b0) + (nsteps == 0 ? 0.0 : Cused)) * kLn2;
         }
     }
+}
+
+template <typename L, int MAXW, int COLS>
+__global__ __launch_bounds__(MAXW * 64) void lattice_kernel(
+        const LogPair<L>* __restrict__ lp2, L* __restrict__ alpha, L* __restrict__ beta,
+        double* __restrict__ offa, double* __restrict__ offb, double* __restrict__ ll_fwd,
+        double* __restrict__ ll_bwd, L* __restrict__ costs_dev, const int* __restrict__ xlen,
+        const int* __restrict__ ylen, int maxT, int maxU, int Up, int dirs) {
+    const int b = blockIdx.x / dirs;
+    lattice_body<L, MAXW, COLS>(lp2, alpha, beta, offa, offb, ll_fwd, ll_bwd, costs_dev, xlen, ylen, maxT, maxU, Up, b,
+                                static_cast<int>(blockIdx.x) - b * dirs, static_cast<int>(threadIdx.x), static_cast<int>(blockDim.x >> 6));
+}
+
+// ------------------------------------------------------------------------------------------
+// Lattice recursion in the LINEAR domain, for lattices of one wavefront (maxU <= 64) with an fp32 lattice: a CHAIN
+// wavefront and six helper wavefronts per (sample, direction).
+//
+// The log-domain step above is a dependent chain of nine instructions with two transcendentals (108 cycles per
+// anti-diagonal for a lone wavefront); on probabilities the same step is  a' = fma(shr(a), pl, a * pb)  in fp64 -- 22
+// cycles -- but a lone wavefront then drowns in the conversions around it (exp2 of the stored log-probs, and a log2 of
+// every result, because the stored lattice has to stay in the range-free log form the coefficient kernel reads):
+// 96 cycles, tools/microbench/lin_chain.hip.  A single-wavefront lattice block leaves three of the CU's four SIMDs idle,
+// so the conversions move there (wavefront w runs on SIMD w & 3):
+//   wavefront 0 (chain)        chunk j: the chunk's C operand pairs from LDS into registers, per diagonal the fp64 step and
+//                              one ds_write_b64; per chunk one re-normalisation by a power of two (exact) on the
+//                              wavefront's in-lattice maximum, the exponent accumulated in fp64 -- the same
+//                              per-(wavefront, diagonal) offsets as above.  Alone on SIMD 0 (wavefront 4 only waits);
+//   wavefronts 1-3 (operands)  chunk j+1, a third of its diagonals each: the rows of log-probs (requested 8 chunks ahead),
+//                              cells outside the T_b x U_b lattice masked to probability 0 (so the chain needs no
+//                              validity logic: unstarted and finished columns are exact zeros), exp2, the label operand
+//                              shifted one lane (alpha), fp64 pairs into LDS;
+//   wavefronts 5-7 (results)   chunk j-1, a third each: log2 of the results (exponent field + v_log_f32 of the top
+//                              mantissa bits), stored in the skewed arrays exactly as lattice_kernel stores them, and
+//                              the offsets.
+// One block barrier per chunk of C = 12 diagonals.  Measured (tools/microbench/lattice_bench, MI355X): 35.7 ns per diagonal
+// on long lattices against 56.2 for lattice_kernel; 10.6 us against 13.2 on N=16 T=150 U=41, 10.9 / 12.7 on N=128 T=150
+// U=21, 13.6 / 17.2 on N=128 T=200 U=41.  Each role alone runs at 26-32 ns per diagonal, the chain being the slowest.
+// RANGE GUARD: fp64 spans 2^-1022 below the wavefront's maximum and fp32 exp2 covers log-probs down to -126; a lattice
+// cell that underflows (or is exactly zero: -inf logits), comes out negative / inf / NaN, a log-prob in (-1e29, -126), or
+// a non-positive final value raises the block's flag, and the block's first wavefront then runs the log-domain sweep
+// (lattice_body) for that (sample, direction) -- every input is handled exactly as before, ordinary inputs never take
+// the fallback.  grid = N * dirs, block = 512.
+constexpr int kLinC = 12;                           // diagonals per chunk: 4 per operand / result wavefront
+constexpr int kLinThreads = 512;
+
+__device__ __forceinline__ int wave_max_i32_dpp(int v) {
+    auto mx = [](int a, int b) { return a > b ? a : b; };
+    v = mx(v, __builtin_amdgcn_update_dpp(v, v, 0xB1, 0xf, 0xf, false));    // quad_perm [1,0,3,2]
+    v = mx(v, __builtin_amdgcn_update_dpp(v, v, 0x4E, 0xf, 0xf, false));    // quad_perm [2,3,0,1]
+    v = mx(v, __builtin_amdgcn_update_dpp(v, v, 0x141, 0xf, 0xf, false));   // row_half_mirror
+    v = mx(v, __builtin_amdgcn_update_dpp(v, v, 0x140, 0xf, 0xf, false));   // row_mirror
+    v = mx(v, __builtin_amdgcn_update_dpp(v, v, 0x142, 0xa, 0xf, false));   // row_bcast:15 -> rows 1,3
+    v = mx(v, __builtin_amdgcn_update_dpp(v, v, 0x143, 0xc, 0xf, false));   // row_bcast:31 -> rows 2,3
+    return __builtin_amdgcn_readlane(v, 63);
+}
+
+// LDS of one block of the linear-domain kernel (declared once in the kernel, shared by its two direction instantiations)
+struct LinShared {
+    double2 ops[2][kLinC][64];                       // {p_blank, p_label (alpha: of the lane's left neighbour)} per diagonal and lane
+    double res[2][kLinC][64];                        // the chain's results, relative to chunk_off
+    double chunk_off[2];
+    int bad;
+};
+
+template <int DIR>                                   // 0 alpha, 1 beta: compile-time, so that no step carries a direction branch
+__device__ __forceinline__ void lattice_lin_body(
+        LinShared& sh, const LogPair<float>* __restrict__ lp2, float* __restrict__ alpha, float* __restrict__ beta,
+        double* __restrict__ offa, double* __restrict__ offb, double* __restrict__ ll_fwd,
+        double* __restrict__ ll_bwd, float* __restrict__ costs_dev, const int* __restrict__ xlen,
+        const int* __restrict__ ylen, int maxT, int maxU, int Up, const int b) {
+    constexpr int C = kLinC;
+    constexpr int KW = C / 3;                        // diagonals of a chunk per operand wavefront and per result wavefront
+    constexpr int PFD = 8;                           // chunks of log-probs in flight per operand wavefront (96 rows ahead)
+    using L = float;
+    const int lane = threadIdx.x & 63, wave = uniform(threadIdx.x >> 6);
+    const int Tb_raw = xlen[b], Ub_raw = ylen[b] + 1;
+    const bool bad_len = Tb_raw < 1 || Ub_raw < 1 || Tb_raw > maxT || Ub_raw > maxU;
+    const int Tb = Tb_raw < 1 ? 1 : (Tb_raw > maxT ? maxT : Tb_raw);
+    const int Ub = Ub_raw < 1 ? 1 : (Ub_raw > maxU ? maxU : Ub_raw);
+    const int Db = Tb + Ub - 1;
+    const size_t Dp = lat_rows(maxT, maxU);
+    const size_t sample0 = static_cast<size_t>(b) * Dp * Up;
+    const int cell_row = Up * static_cast<int>(sizeof(LogPair<L>));
+    const int val_row = Up * static_cast<int>(sizeof(L));
+    const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<LogPair<L>*>(lp2) + sample0, 0, static_cast<int>(Dp * cell_row), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(
+        (DIR == 0 ? alpha : beta) + sample0, 0, static_cast<int>(Dp * val_row), 0x00020000);
+    const int u = lane;
+    const bool in_row = u < Up;                      // lanes past the row: parked (load zeros, store nothing)
+    const int vc = in_row ? u * static_cast<int>(sizeof(LogPair<L>)) : kLatOob;
+    const int vv = in_row ? u * static_cast<int>(sizeof(L)) : kLatOob;
+    const bool ucol = u < Ub;
+    // cell (n - u, u) of diagonal n lies in the lattice  <=>  unsigned(n - ueff) < T_b  (columns past U_b: never)
+    const int ueff = ucol ? u : u - (1 << 30);
+    double* off = (DIR == 0 ? offa : offb) + static_cast<size_t>(b) * Dp + kLatPad;     // (one wavefront per block in the offsets' layout)
+    const int nsteps = Db - 1;
+    const int nchunks = (nsteps + C - 1) / C;
+    const int ulast = Ub - 1;
+    const unsigned Tbu = static_cast<unsigned>(Tb);
+    const float NEG = log_zero<float>();
+    // step i (0-based over the whole sweep): alpha computes diagonal i + 1 from row i; beta computes diagonal Db - 2 - i
+    // (i may run past nsteps - 1 in the last chunk: those rows lie in the padding of the skewed arrays)
+    auto row_of = [&](int i) { return DIR == 0 ? i : Db - 2 - i; };          // the row whose log-probs step i reads
+    auto diag_of = [&](int i) { return DIR == 0 ? i + 1 : Db - 2 - i; };     // the diagonal step i produces
+    if (threadIdx.x == 0) sh.bad = 0;
+    float x_last = 0.0f;                             // beta: log2 p(blank) of the terminal cell
+    if (wave == 0) {
+        if (DIR == 0) {
+            if (lane == 0) { lat_store1(rv, 0, kLatPad * val_row, 0.0f); off[0] = 0.0; }
+        } else {
+            x_last = lat_clamp(lat_load1(rc, ulast * static_cast<int>(sizeof(LogPair<L>)), (Db - 1 + kLatPad) * cell_row, 0.0f));
+            if (lane == ulast) lat_store1(rv, ulast * static_cast<int>(sizeof(L)), (Db - 1 + kLatPad) * val_row, x_last);
+            if (lane == 0) off[Db - 1] = 0.0;
+        }
+    }
+    __syncthreads();
+
+    // Roles by wavefront (w -> SIMD w & 3): 0 the chain, alone on its SIMD (4 waits at the barriers and nothing else);
+    // 1..3 operands and 5..7 results, one of each per remaining SIMD.  Every role runs the same nchunks + 2 block barriers
+    // (slot s: operands of chunk s, chain on chunk s - 1, results of chunk s - 2).  The barrier orders LDS traffic only
+    // (lds_barrier): the operand wavefronts' prefetch and the result wavefronts' stores stay in flight across it.
+    // Everything inside the per-diagonal loops is straight-line and lean: a wave64 VALU instruction is 4 issue cycles, the
+    // chain needs ~44 cycles per diagonal, so each helper role may spend ~130 cycles per diagonal of ITS share -- the first
+    // form (masks as bool logic, && / ||, a run-time direction) spent 250 per diagonal in the operand role alone.
+    const int nslots = nchunks + 2;
+    if (wave >= 1 && wave <= 3) {
+        // ---- operands: diagonals [cw*KW, cw*KW + KW) of every chunk; a ring of PFD chunks of rows in registers
+        const int cw = wave - 1;
+        // A ring of PFD chunks of rows in registers, refilled slot by slot.  The requests and the waits are written out
+        // (inline asm): the memory is ~1 us away, a chunk lasts ~0.4 us, and with compiler-tracked loads the vmcnt
+        // bookkeeping across the loop's back edge collapsed to "wait for everything in flight" in every form tried
+        // (measured: this role alone 25-29 ns per diagonal instead of ~8).  Nothing else in this wavefront uses vmcnt.
+        typedef int lin_i32x4 __attribute__((ext_vector_type(4)));
+        const unsigned long long cbase = reinterpret_cast<unsigned long long>(lp2 + sample0);
+        const lin_i32x4 rd = {static_cast<int>(cbase), static_cast<int>((cbase >> 32) & 0xffffu),
+                              static_cast<int>(Dp * cell_row), 0x00020000};
+        lat_u32x2 ring[PFD][KW];
+        auto request = [&](int j, lat_u32x2 (&dst)[KW]) {
+            const int jj = j < nchunks ? j : (nchunks > 0 ? nchunks - 1 : 0);      // (past the end: a valid chunk again, unused)
+#pragma unroll
+            for (int k = 0; k < KW; ++k)
+                asm volatile("buffer_load_dwordx2 %0, %1, %2, %3 offen"
+                             : "=v"(dst[k]) : "v"(vc), "s"(rd), "s"((row_of(jj * C + cw * KW + k) + kLatPad) * cell_row) : "memory");
+        };
+        // RANGE GUARD, operand side: a log-prob strictly inside (-1e29, -126) has no normal fp32 exp2.  As bit patterns
+        // (negative floats order as unsigned integers) that is one unsigned window; the minimum over the wavefront's
+        // values of (bits - window start) falls below the window's width iff some value lies in it.  Values at or below
+        // the sentinel (-1e30: masked cells, -inf logits) give exact zeros; NaN and +inf pass through to the chain and
+        // are caught on the result side.
+        constexpr unsigned kWin0 = 0xC2FC0001u;                        // one past bits(-126.0f)
+        constexpr unsigned kWinW = 0xEFA18F08u - kWin0;                // up to bits(-1e29f), exclusive (log_zero is beyond it)
+        unsigned win = 0xffffffffu;
+#pragma unroll
+        for (int r = 0; r < PFD; ++r) request(r, ring[r]);
+        for (int s0 = 0; s0 < nslots; s0 += PFD) {
+#pragma unroll
+            for (int r = 0; r < PFD; ++r) {
+                const int j = s0 + r;
+                if (j < nslots) {
+                    // chunk j's rows have landed once at most the (PFD - 1) * KW younger requests are outstanding
+                    static_assert(KW == 4, "the wait below names the chunk's four registers");
+                    asm volatile("s_waitcnt vmcnt(%4)" : "+v"(ring[r][0]), "+v"(ring[r][1]), "+v"(ring[r][2]), "+v"(ring[r][3])
+                                 : "n"((PFD - 1) * KW) : "memory");
+                    if (j < nchunks) {                                             // (the two slots past the last chunk write nothing)
+#pragma unroll
+                        for (int k = 0; k < KW; ++k) {
+                            const int kk = cw * KW + k;
+                            const bool inl = static_cast<unsigned>(row_of(j * C + kk) - ueff) < Tbu;
+                            const float x = inl ? __uint_as_float(ring[r][k].x) : NEG, y = inl ? __uint_as_float(ring[r][k].y) : NEG;
+                            win = min(win, min(__float_as_uint(x) - kWin0, __float_as_uint(y) - kWin0));
+                            const float pb = __builtin_amdgcn_exp2f(x);
+                            float pl = __builtin_amdgcn_exp2f(y);
+                            if (DIR == 0) pl = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(pl), 0x138, 0xf, 0xf, true));   // wave_shr:1, lane 0 <- 0
+                            sh.ops[j & 1][kk][lane] = make_double2(static_cast<double>(pb), static_cast<double>(pl));
+                        }
+                    }
+                    request(j + PFD, ring[r]);
+                    lds_barrier();
+                }
+            }
+        }
+        // The ring's last requests are still in flight and nobody reads them: without a use after the wait the compiler
+        // hands their registers to other values (it did: the guard word below) and a late arrival overwrites those.
+#pragma unroll
+        for (int r = 0; r < PFD; ++r)
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(ring[r][0]), "+v"(ring[r][1]), "+v"(ring[r][2]), "+v"(ring[r][3]) : : "memory");
+        if (__ballot(win < kWinW) != 0 && lane == 0) sh.bad = 1;
+    } else if (wave == 0) {
+        // ---- the chain: chunk s - 1 in slot s; the chunk's operands are all requested before the first step
+        double a, up = 0.0, Ecum = 0.0;
+        if (DIR == 0) a = (u == 0) ? 1.0 : 0.0;
+        else a = (u == ulast) ? exp2(static_cast<double>(x_last)) : 0.0;
+        for (int s = 0; s < nslots; ++s) {
+            if (s >= 1 && s <= nchunks) {
+                const int j = s - 1;
+                double2 o[C];
+#pragma unroll
+                for (int k = 0; k < C; ++k) o[k] = sh.ops[j & 1][k][lane];
+                if (lane == 0) sh.chunk_off[j & 1] = Ecum;
+#pragma unroll
+                for (int k = 0; k < C; ++k) {
+                    const double t = a * o[k].x;
+                    up = DIR == 0 ? wave_shr1(up, a) : wave_shl1(up, a);       // the edge lane keeps its zero
+                    a = __builtin_fma(up, o[k].y, t);
+                    sh.res[j & 1][k][lane] = a;
+                }
+                if (j + 1 < nchunks) {
+                    // re-normalise on the in-lattice maximum of the diagonal just computed: an exact power of two
+                    const int n = diag_of(j * C + C - 1);
+                    const bool inl = (static_cast<unsigned>(n - ueff) < Tbu) & (a > 0.0);
+                    const int e = inl ? __builtin_amdgcn_frexp_exp(a) : -100000;
+                    const int E = wave_max_i32_dpp(e);
+                    if (E > -50000) {
+                        a = __builtin_ldexp(a, -E);
+                        Ecum += static_cast<double>(E);
+                    }
+                }
+            }
+            lds_barrier();
+        }
+    } else if (wave >= 5) {
+        // ---- results of chunk s - 2 in slot s: base-2 logs into the skewed array, and the offsets.
+        // RANGE GUARD, result side: the biased exponent field (with the sign bit above it) of an in-lattice result must be
+        // 1..2046 -- zero, a denormal (underflow), a negative number, inf or NaN raise the flag.  The same field, minus
+        // the bias, is the integer part of the logarithm; the fraction is v_log_f32 of the top 23 mantissa bits.
+        const int fw = wave - 5;
+        unsigned worst = 0;
+        for (int s = 0; s < nslots; ++s) {
+            if (s >= 2) {
+                const int j = s - 2;
+                const double Eo = sh.chunk_off[j & 1];
+#pragma unroll
+                for (int k = 0; k < KW; ++k) {
+                    const int kk = fw * KW + k;
+                    const int n = diag_of(j * C + kk);
+                    const double v = sh.res[j & 1][kk][lane];
+                    const unsigned hi = static_cast<unsigned>(__double2hiint(v)), lo = static_cast<unsigned>(__double2loint(v));
+                    const unsigned field = (hi >> 20) - 1u;                                  // 0..2045 for a positive normal number
+                    const bool inl = static_cast<unsigned>(n - ueff) < Tbu;
+                    worst = max(worst, inl ? field : 0u);
+                    const float mant = __uint_as_float((__builtin_amdgcn_alignbit(hi, lo, 29) & 0x007fffffu) | 0x3f800000u);
+                    const float val = fmaxf((static_cast<float>(static_cast<int>(field)) - 1022.0f) + __builtin_amdgcn_logf(mant), NEG);
+                    lat_store1(rv, vv, (n + kLatPad) * val_row, inl ? val : NEG);
+                }
+                if (lane < KW) off[diag_of(j * C + fw * KW + lane)] = Eo;                    // this wavefront's diagonals: one store
+            }
+            lds_barrier();
+        }
+        if (__ballot(worst >= 2046u) != 0 && lane == 0) sh.bad = 1;
+    } else {
+        for (int s = 0; s < nslots; ++s) lds_barrier();                                      // wavefront 4: leaves the chain's SIMD to the chain
+    }
+    __syncthreads();
+
+    // ---- the likelihood, from the last diagonal the chain computed
+    if (wave == 0) {
+        const int il = nsteps - 1, jl = il >= 0 ? il / C : 0, kl = il >= 0 ? il % C : 0;
+        const int who = DIR == 0 ? ulast : 0;
+        double fin = 1.0, Eo = 0.0;
+        if (nsteps > 0) { fin = sh.res[jl & 1][kl][who]; Eo = sh.chunk_off[jl & 1]; }
+        if (lane == who) {
+            if (!(fin > 0.0)) sh.bad = 1;
+            if (DIR == 0) {
+                const float xb = lat_clamp(lat_load1(rc, ulast * static_cast<int>(sizeof(LogPair<L>)), (Db - 1 + kLatPad) * cell_row, 0.0f));
+                const double ll2 = log2(fin) + Eo + static_cast<double>(xb);
+                ll_fwd[b] = ll2;
+                costs_dev[b] = bad_len ? cost_invalid<float>() : static_cast<float>(-ll2 * kLn2);
+            } else {
+                ll_bwd[b] = (nsteps > 0 ? log2(fin) + Eo : static_cast<double>(x_last)) * kLn2;
+            }
+        }
+    }
+    __syncthreads();
+}
+
+template <int UNUSED = 0>                            // (a template so that the two translation units share one definition)
+__global__ __launch_bounds__(kLinThreads) void lattice_lin_kernel(
+        const LogPair<float>* __restrict__ lp2, float* __restrict__ alpha, float* __restrict__ beta,
+        double* __restrict__ offa, double* __restrict__ offb, double* __restrict__ ll_fwd,
+        double* __restrict__ ll_bwd, float* __restrict__ costs_dev, const int* __restrict__ xlen,
+        const int* __restrict__ ylen, int maxT, int maxU, int Up, int dirs, int force_fallback) {
+    __shared__ LinShared sh;
+    const int b = blockIdx.x / dirs;
+    const int dir = static_cast<int>(blockIdx.x) - b * dirs;
+    if (dir == 0) lattice_lin_body<0>(sh, lp2, alpha, beta, offa, offb, ll_fwd, ll_bwd, costs_dev, xlen, ylen, maxT, maxU, Up, b);
+    else lattice_lin_body<1>(sh, lp2, alpha, beta, offa, offb, ll_fwd, ll_bwd, costs_dev, xlen, ylen, maxT, maxU, Up, b);
+    if ((sh.bad | force_fallback) != 0 && threadIdx.x < 64)   // the range guard tripped (or RNNT_TUNE=latlin=2, the tests): the log-domain sweep
+        lattice_body<float, 1, 1>(lp2, alpha, beta, offa, offb, ll_fwd, ll_bwd, costs_dev, xlen, ylen, maxT, maxU, Up, b, dir,
+                                  static_cast<int>(threadIdx.x), 1);
 }
 
 // ------------------------------------------------------------------------------------------

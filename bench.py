@@ -198,10 +198,15 @@ class _NcclUniqueId(C.Structure):
     _fields_ = [("internal", C.c_char * 128)]               # rccl.h: NCCL_UNIQUE_ID_BYTES
 
 
-def native_communicator(world, rank, dev):
+def native_communicator(world, rank, dev, timeout_s=120.0):
     """An RCCL communicator of this job's ranks for compute_rnnt_loss_sharded (the library issues the collective itself):
-    rank 0 draws the unique id, torch.distributed broadcasts its 128 bytes, every rank joins.  None when RCCL cannot be
-    loaded or the communicator cannot be formed (the step then uses torch.distributed's all-reduce)."""
+    rank 0 draws the unique id, torch.distributed broadcasts its 128 bytes, every rank joins.  (None, None) when RCCL
+    cannot be loaded or the communicator cannot be formed ON ANY RANK -- the ranks agree on the outcome through one
+    torch.distributed all-reduce, so that no rank issues the native collective while another waits in torch's -- and the
+    step then uses torch.distributed's all-reduce everywhere.  The join runs in a helper thread with a time limit: a
+    bootstrap that never returns costs the native path, not the run."""
+    import threading
+    state = {"rccl": None, "comm": None, "why": None}
     try:
         rccl = None
         for name in ("librccl.so.1", "librccl.so"):
@@ -211,27 +216,51 @@ def native_communicator(world, rank, dev):
             except OSError:
                 continue
         if rccl is None:
-            print("bench.py: librccl not loadable; using torch.distributed's all-reduce", file=sys.stderr)
-            return None, None
-        rccl.ncclGetUniqueId.argtypes = [C.POINTER(_NcclUniqueId)]
-        rccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, _NcclUniqueId, C.c_int]
-        rccl.ncclCommDestroy.argtypes = [C.c_void_p]
+            state["why"] = "librccl not loadable"
+        else:
+            rccl.ncclGetUniqueId.argtypes = [C.POINTER(_NcclUniqueId)]
+            rccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, _NcclUniqueId, C.c_int]
+            rccl.ncclCommDestroy.argtypes = [C.c_void_p]
         uid = _NcclUniqueId()
-        if rank == 0 and rccl.ncclGetUniqueId(C.byref(uid)) != 0:
-            return None, None
+        if rccl is not None and rank == 0 and rccl.ncclGetUniqueId(C.byref(uid)) != 0:
+            state["why"] = "ncclGetUniqueId failed"
+        # (every rank takes part in the broadcast, whatever happened above: the collectives of the ranks must pair up)
         raw = torch.frombuffer(bytearray(C.string_at(C.addressof(uid), 128)), dtype=torch.uint8).to(dev)   # (all 128 bytes: a c_char field reads as a NUL-terminated string)
         if world > 1:
             dist.broadcast(raw, src=0)
         C.memmove(C.byref(uid), bytes(raw.cpu().numpy().tobytes()), 128)
-        comm = C.c_void_p()
-        rc = rccl.ncclCommInitRank(C.byref(comm), world, uid, rank)
-        if rc != 0:
-            print("bench.py: ncclCommInitRank failed (%d); using torch.distributed's all-reduce" % rc, file=sys.stderr)
-            return None, None
-        return rccl, comm
+        if rccl is not None and state["why"] is None:
+            def join():
+                try:
+                    torch.cuda.set_device(dev)
+                    comm = C.c_void_p()
+                    rc = rccl.ncclCommInitRank(C.byref(comm), world, uid, rank)
+                    if rc == 0:
+                        state["comm"] = comm
+                    else:
+                        state["why"] = "ncclCommInitRank failed (%d)" % rc
+                except Exception as e:                             # noqa: BLE001
+                    state["why"] = repr(e)
+            th = threading.Thread(target=join, daemon=True)
+            th.start()
+            th.join(timeout_s)
+            if th.is_alive():
+                state["why"] = "ncclCommInitRank did not return within %.0f s" % timeout_s
+                state["comm"] = None
+            state["rccl"] = rccl
     except Exception as e:                                         # noqa: BLE001 -- fall back to torch.distributed's collective
-        print("bench.py: no native RCCL communicator (%r); using torch.distributed's all-reduce" % (e,), file=sys.stderr)
+        state["why"] = repr(e)
+        state["comm"] = None
+    ok = torch.tensor([1 if state["comm"] is not None else 0], dtype=torch.int32, device=dev)
+    if world > 1:
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    if int(ok.item()) == 0:
+        if state["comm"] is not None:                              # another rank could not join: nobody uses the native path
+            state["rccl"].ncclCommDestroy(state["comm"])
+        print("bench.py: no native RCCL communicator on rank %d (%s); every rank uses torch.distributed's all-reduce"
+              % (rank, state["why"] or "another rank could not join"), file=sys.stderr)
         return None, None
+    return state["rccl"], state["comm"]
 
 
 def verify_batch(w, acts, labels, act_lens, label_lens, grads, costs):
@@ -255,6 +284,11 @@ def verify_batch(w, acts, labels, act_lens, label_lens, grads, costs):
 
 
 def main():
+    # stdout carries the ONE JSON line and nothing else: whatever libraries print on the way (RCCL's version banner at
+    # communicator creation goes to C stdout) is sent to stderr until the line is ready
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -314,7 +348,7 @@ def main():
                "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
         # the host driver only supports dmabuf IPC: without this RCCL's peer setup fails (hipIpcGetMemHandle)
         env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
-        raise SystemExit(subprocess.call(cmd, env=env))
+        raise SystemExit(subprocess.call(cmd, env=env, stdout=real_stdout))      # (rank 0 of the job writes the JSON line)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -646,12 +680,14 @@ def main():
         out["other_workloads"] = extra
     if sharded:
         dist.destroy_process_group()
-    # RCCL prints its version banner through C stdio, which would otherwise be flushed at exit, BEHIND the JSON line:
-    # flush it first so that the JSON line is the last line of stdout
+    # RCCL prints its version banner through C stdio: flush it (to stderr, see the top of main) before stdout comes back
     try:
         C.CDLL(None).fflush(None)
     except OSError:
         pass
+    sys.stdout.flush()
+    os.dup2(real_stdout, 1)
+    os.close(real_stdout)
     if rank == 0:
         print(json.dumps(out), flush=True)
 

@@ -134,7 +134,7 @@ def test_bench_self_launches_two_ranks():
 def test_bench_sharded_step_on_one_rank():
     """The step `bench.py --gpus N` times for N > 1 (loss + gradients -> RCCL all-reduce of [loss sum, count]; and its
     two-phase variant with the collective beside the gradient pass), on a one-rank RCCL group so that it runs on a one-GPU
-    box too: same loss sum as the plain one-GPU step on the same inputs, a complete JSON line as the LAST line of stdout."""
+    box too: same loss sum as the plain one-GPU step on the same inputs, the JSON line as the ONLY line of stdout."""
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29547")
     base = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--workload", "c5", "--steps", "4", "--warmup", "1",
             "--no-cpu-baseline", "--no-traffic-pass"]
@@ -142,6 +142,7 @@ def test_bench_sharded_step_on_one_rank():
     for extra in (["--force-sharded"], ["--force-sharded", "--overlap-collective"], [], ["--force-sharded", "--torch-collective"]):
         out = subprocess.run(base + extra, capture_output=True, text=True, timeout=900, env=env)
         assert out.returncode == 0, out.stderr[-2000:]
+        assert len(out.stdout.strip().splitlines()) == 1, out.stdout[:400]     # ONE line: RCCL's banner goes to stderr
         lines.append(json.loads(out.stdout.strip().splitlines()[-1]))
     sh, ov, plain, tc = lines
     # the default sharded step is the library's own (compute_rnnt_loss_sharded); --torch-collective is the round-2 form

@@ -784,3 +784,61 @@ def test_stage_ranges_for_external_profilers(tmp_path):
         pytest.skip("rocprofv3 failed here (rc %d): %s" % (out.returncode, out.stderr[-300:]))
     for name in ("warprnnt:row_stats", "warprnnt:lattice", "warprnnt:coefficients", "warprnnt:gradient"):
         assert name in text, (name, text[:500])
+
+
+@pytest.mark.parametrize("dtype,A", [(torch.bfloat16, 1024), (torch.float32, 1000), (torch.float16, 2048)])
+def test_padding_flag_follows_the_batch(oracle, dtype, A):
+    """Rows of 2-8 KB: the gradient kernel leaves the logits of padded rows unread only when the coefficient kernel has seen
+    padding in THIS batch (one flag word in the workspace, zeroed by the lattice kernel of every call).  Ragged, full-length
+    and ragged again on one workspace, with NaNs planted in the padded rows of the ragged batches (never read, never
+    propagated), each against the oracle; then the per-sample scale form and the two-phase entries on the same workspace."""
+    from warprnnt_pytorch import warp_rnnt, _lib
+    dev = torch.device("cuda:0")
+    N, T, U = 5, 14, 9
+    rng = np.random.default_rng(A)
+    base = rng.standard_normal((N, T, U, A)).astype(np.float32)
+    labels = rng.integers(1, A, size=(N, U - 1)).astype(np.int32)
+    ragged = (np.array([T, T - 3, T // 2, T - 1, 5], dtype=np.int32), np.array([U - 1, 3, U - 1, 0, U - 2], dtype=np.int32))
+    full = (np.full(N, T, dtype=np.int32), np.full(N, U - 1, dtype=np.int32))
+    esz = 4 if dtype == torch.float32 else 2
+    ws = torch.empty(_lib.workspace_bytes(T, U, N, True, esz), dtype=torch.uint8, device=dev)
+    lab = torch.tensor(labels, device=dev)
+    tol_g = 1e-4 if dtype == torch.float32 else (4e-3 if dtype == torch.bfloat16 else 6e-4)
+
+    def inputs(lens, poison):
+        x = torch.tensor(base, device=dev).to(dtype)
+        if poison:
+            for b in range(N):
+                x[b, lens[0][b]:] = float("nan")
+                x[b, :, lens[1][b] + 1:] = float("nan")
+        clean = torch.tensor(base, device=dev).to(dtype).float().cpu().numpy().astype(np.float64)
+        return x, clean
+
+    for lens, poison in ((ragged, True), (full, False), (ragged, True)):
+        x, clean = inputs(lens, poison)
+        ref_c, ref_g = oracle.rnnt_logits(clean, labels, lens[0], lens[1], 0)
+        costs, grads = torch.zeros(N), torch.full_like(x, 7.0)
+        tl, ll = torch.tensor(lens[0], device=dev), torch.tensor(lens[1], device=dev)
+        assert warp_rnnt.gpu_rnnt(x, lab, tl, ll, costs, grads, 0, 0, workspace=ws) == 0
+        g = grads.float().cpu().numpy().astype(np.float64)
+        assert np.abs(costs.numpy() - ref_c).max() <= 1e-4 * np.abs(ref_c).max()
+        assert not np.isnan(g).any() and np.abs(g - ref_g).max() <= tol_g
+        for b in range(N):
+            assert not g[b, lens[0][b]:].any() and not g[b, :, lens[1][b] + 1:].any()
+    # per-sample scale folded in (the form autograd callers get), ragged with poisoned padding, same workspace
+    x, clean = inputs(ragged, True)
+    ref_c, ref_g = oracle.rnnt_logits(clean, labels, ragged[0], ragged[1], 0)
+    tl, ll = torch.tensor(ragged[0], device=dev), torch.tensor(ragged[1], device=dev)
+    scale = torch.tensor([0.5, 2.0, 1.0, 0.25, 3.0], device=dev)
+    dcosts, grads = torch.zeros(N, device=dev), torch.full_like(x, 7.0)
+    warp_rnnt.gpu_rnnt_async(x, lab, tl, ll, dcosts, grads, 0, grad_scale=scale, workspace=ws)
+    torch.cuda.synchronize()
+    g = grads.float().cpu().numpy().astype(np.float64)
+    want = ref_g * scale.cpu().numpy().reshape(N, 1, 1, 1)
+    assert not np.isnan(g).any() and np.abs(g - want).max() <= 3 * tol_g
+    # two-phase entries: the flag written in the forward phase is what the backward phase reads
+    dcosts2, grads2 = torch.zeros(N, device=dev), torch.full_like(x, 7.0)
+    ws2 = warp_rnnt.gpu_rnnt_fwd(x, lab, tl, ll, dcosts2, 0, True)
+    warp_rnnt.gpu_rnnt_bwd(x, grads2, scale, ws2, 0)
+    torch.cuda.synchronize()
+    assert torch.equal(dcosts, dcosts2) and torch.equal(grads, grads2)

@@ -22,6 +22,7 @@ int main(int argc, char** argv) {
     CK(hipMalloc(&offa, N * W * Dp * 8)); CK(hipMalloc(&offb, (N * W * Dp + Dp) * 8));
     CK(hipMalloc(&llf, N * 8)); CK(hipMalloc(&llb, N * 8)); CK(hipMalloc(&costs, N * 4));
     CK(hipMalloc(&xlen, N * 4)); CK(hipMalloc(&ylen, N * 4));
+    int* padflag; CK(hipMalloc(&padflag, 4));
     std::vector<LogPair<float>> h(N * Dp * Up);
     for (auto& c : h) { c.x = -1.0f - (rand() % 100) * 0.01f; c.y = -2.0f - (rand() % 100) * 0.01f; }
     CK(hipMemcpy(cells, h.data(), h.size() * 8, hipMemcpyHostToDevice));
@@ -33,11 +34,11 @@ int main(int argc, char** argv) {
     hipStream_t ls; CK(hipStreamCreateWithFlags(&ls, hipStreamNonBlocking));
     auto launch = [&] {
         const int cols = argc > 4 ? atoi(argv[4]) : 2;          // columns per lane for U > 64
-        if (W == 1 && argc > 6 && atoi(argv[6]) != 0) hipLaunchKernelGGL((lattice_lin_kernel<0>), dim3(N * 2), dim3(kLinThreads), 0, ls, cells, alpha, beta, offa, offb, llf, llb, costs, xlen, ylen, T, U, Up, 2, 0);   // argv[6] = 1: the linear-domain kernel
-        else if (W == 1) hipLaunchKernelGGL((lattice_kernel<float, 1, 1>), dim3(N * 2), dim3(64), 0, ls, cells, alpha, beta, offa, offb, llf, llb, costs, xlen, ylen, T, U, Up, 2);
-        else if (cols == 1) hipLaunchKernelGGL((lattice_kernel<float, 8, 1>), dim3(N * 2), dim3(W * 64), 0, ls, cells, alpha, beta, offa, offb, llf, llb, costs, xlen, ylen, T, U, Up, 2);
-        else if (lat_waves(Up, 2) <= 4) hipLaunchKernelGGL((lattice_kernel<float, 4, 2>), dim3(N * 2), dim3(lat_waves(Up, 2) * 64), 0, ls, cells, alpha, beta, offa, offb, llf, llb, costs, xlen, ylen, T, U, Up, 2);
-        else hipLaunchKernelGGL((lattice_kernel<float, 8, 2>), dim3(N * 2), dim3(lat_waves(Up, 2) * 64), 0, ls, cells, alpha, beta, offa, offb, llf, llb, costs, xlen, ylen, T, U, Up, 2);
+        if (W == 1 && argc > 6 && atoi(argv[6]) != 0) hipLaunchKernelGGL((lattice_lin_kernel<0>), dim3(N * 2), dim3(kLinThreads), 0, ls, cells, alpha, beta, offa, offb, llf, llb, costs, xlen, ylen, T, U, Up, 2, 0, padflag);   // argv[6] = 1: the linear-domain kernel
+        else if (W == 1) hipLaunchKernelGGL((lattice_kernel<float, 1, 1>), dim3(N * 2), dim3(64), 0, ls, cells, alpha, beta, offa, offb, llf, llb, costs, xlen, ylen, T, U, Up, 2, padflag);
+        else if (cols == 1) hipLaunchKernelGGL((lattice_kernel<float, 8, 1>), dim3(N * 2), dim3(W * 64), 0, ls, cells, alpha, beta, offa, offb, llf, llb, costs, xlen, ylen, T, U, Up, 2, padflag);
+        else if (lat_waves(Up, 2) <= 4) hipLaunchKernelGGL((lattice_kernel<float, 4, 2>), dim3(N * 2), dim3(lat_waves(Up, 2) * 64), 0, ls, cells, alpha, beta, offa, offb, llf, llb, costs, xlen, ylen, T, U, Up, 2, padflag);
+        else hipLaunchKernelGGL((lattice_kernel<float, 8, 2>), dim3(N * 2), dim3(lat_waves(Up, 2) * 64), 0, ls, cells, alpha, beta, offa, offb, llf, llb, costs, xlen, ylen, T, U, Up, 2, padflag);
     };
     for (int i = 0; i < 3; ++i) launch();
     CK(hipDeviceSynchronize());

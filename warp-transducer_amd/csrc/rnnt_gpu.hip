@@ -159,16 +159,20 @@ static void launch_grad(Plan<typename Tag::comp>& p, const typename Tag::store* 
         }
 #define RNNT_FLAT(SC, PP, PS)                                                                                       \
     hipLaunchKernelGGL((grad_flat_kernel<Tag, SC, PP, PS>), dim3(grid), dim3(256), 0, p.stream, acts, grads,        \
-                       p.rowtab, grad_scale, E, R, p.A, p.blank, p.cells_per_sample, invA, dq, drem, rowscale)
-        const bool padskip = tn.pskip && row_bytes >= 8192;     // skip reading padded rows only where rows are long
-        if (grad_scale && rowscale) { if (padskip) RNNT_FLAT(2, 2, true); else RNNT_FLAT(2, 2, false); }
-        else if (grad_scale) { if (padskip) RNNT_FLAT(1, 2, true); else RNNT_FLAT(1, 2, false); }
+                       p.rowtab, grad_scale, E, R, p.A, p.blank, p.cells_per_sample, invA, dq, drem, rowscale, p.padflag)
+        // padded rows are not read: always for long rows (the record is asked for first), for shorter ones when the
+        // coefficient kernel has seen padding in this batch (packed layout: there are no padded rows)
+        const int padskip = (!tn.pskip || packed) ? 0 : row_bytes >= static_cast<size_t>(tn.pskipb) ? 1
+                                                       : row_bytes >= static_cast<size_t>(tn.pskipmin) ? 2 : 0;
+        if (grad_scale && rowscale) RNNT_FLAT(2, 2, 0);
+        else if (grad_scale) { if (padskip == 1) RNNT_FLAT(1, 2, 1); else if (padskip == 2) RNNT_FLAT(1, 2, 2); else RNNT_FLAT(1, 2, 0); }
 #ifdef RNNT_DEV
-        else if (ppt == 1) RNNT_FLAT(0, 1, false);
-        else if (ppt == 4) RNNT_FLAT(0, 4, false);
+        else if (ppt == 1) RNNT_FLAT(0, 1, 0);
+        else if (ppt == 4) RNNT_FLAT(0, 4, 0);
 #endif
-        else if (padskip) RNNT_FLAT(0, 2, true);
-        else RNNT_FLAT(0, 2, false);
+        else if (padskip == 1) RNNT_FLAT(0, 2, 1);
+        else if (padskip == 2) RNNT_FLAT(0, 2, 2);
+        else RNNT_FLAT(0, 2, 0);
 #undef RNNT_FLAT
     } else {
         for (int b0 = 0; b0 < p.N; b0 += kGridSamples) {

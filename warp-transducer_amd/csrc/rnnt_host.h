@@ -27,7 +27,7 @@ constexpr size_t kAlign = 256;
 static inline size_t align_up(size_t x) { return (x + kAlign - 1) / kAlign * kAlign; }
 
 struct Layout {
-    size_t lp2, logz, alpha, rowtab, beta, offa, offb, llf, llb, costs, rowmax, side, side_bytes, wmat, total;
+    size_t lp2, logz, alpha, rowtab, beta, offa, offb, llf, llb, costs, padflag, rowmax, side, side_bytes, wmat, total;
 };
 
 // lat = bytes of one lattice value (4: fp32 lattice for 16/32-bit activations, 8: fp64).
@@ -50,6 +50,7 @@ static Layout make_layout(int maxT, int maxU, int N, size_t lat, bool joint) {
     l.llf = o;   o = align_up(o + N * sizeof(double));
     l.llb = o;   o = align_up(o + N * sizeof(double));
     l.costs = o; o = align_up(o + N * sizeof(double));
+    l.padflag = o; o = align_up(o + sizeof(int));   // "some record of this batch is padding": zeroed by the lattice kernel, set by the coefficient kernel, read by the gradient kernel
     // additive joint only: row maxima of f and g, dense matrices W, CB, CL (row stride = maxU rounded up to 8)
     l.rowmax = o; l.wmat = o; l.side = o; l.side_bytes = 0;
     if (joint) {
@@ -169,7 +170,8 @@ static void ranges_mark(int i, bool do_fwd, bool do_bwd, const char* const names
 // per lane of the DF / DG kernels (0: widest the alignment allows), jfpf / jgpf = operand ping-pong;
 // blk = block-per-row statistics kernel for rows >= 12 KB on/off, jzs = vocabulary split of the Z kernel (1|4|8),
 // xcd = XCD-aware tile order of the short-row statistics kernel on/off, ctile = tiled coefficient kernel on/off,
-// pskip = the gradient kernel's skip-padded-rows form for rows >= 8 KB on/off, joh = one-hot df corrections in the
+// pskip = the gradient kernel's skip-padded-rows forms on/off (pskipb: rows from this size on always test the record first,
+//         pskipmin .. pskipb: only when the batch has padding -- the flag of the coefficient kernel), joh = one-hot df corrections in the
 // additive-joint DF kernel (-1: vocabularies <= 256), lat2 = two lattice columns per lane (-1: maxU > 256),
 // jsamp = additive joint: sampled row references + guard instead of the row-maximum pass (rnnt_joint_kernels.h) on/off,
 // j16 = bf16 storage on the bf16 matrix cores (rnnt_joint16_kernels.h), bit 0 DG, bit 1 DF, bit 2 Z; j16pf = operand ping-pong there, j16nt = columns per lane of its DF / DG (8 | 4),
@@ -178,7 +180,7 @@ static void ranges_mark(int i, bool do_fwd, bool do_bwd, const char* const names
 // tile2d = 2-D cell-tile statistics kernel for short rows under wide lattices on/off.
 struct Tune { int sw = 4, nta = 1, gmax = 4194304, rows = 0, tile = 1, tilekb = 52, ppt = 2;
               int jfnk = 0, jfpf = 1, jgnk = 0, jgpf = 1, blk = 1, jzs = 0, xcd = 1, ctile = 1, pskip = 1, joh = -1;
-              int lat2 = -1, xst = 0, jsamp = 1, tilemax = kTileMaxRowBytes, j16 = 7, j16pf = 1, j16nt = 4, tile2d = 1, latlin = 1; };
+              int lat2 = -1, xst = 0, jsamp = 1, tilemax = kTileMaxRowBytes, j16 = 7, j16pf = 1, j16nt = 4, tile2d = 1, latlin = 1, pskipb = 8192, pskipmin = 2048; };
 #ifdef RNNT_DEV
 static Tune read_tune() {
     Tune t;
@@ -189,7 +191,7 @@ static Tune read_tune() {
         {"tilekb", &t.tilekb}, {"ppt", &t.ppt}, {"jfnk", &t.jfnk}, {"jfpf", &t.jfpf}, {"jgnk", &t.jgnk},
         {"jgpf", &t.jgpf}, {"blk", &t.blk}, {"jzs", &t.jzs}, {"xcd", &t.xcd}, {"ctile", &t.ctile},
         {"pskip", &t.pskip}, {"joh", &t.joh}, {"lat2", &t.lat2}, {"xst", &t.xst}, {"jsamp", &t.jsamp}, {"tilemax", &t.tilemax},
-        {"j16", &t.j16}, {"j16pf", &t.j16pf}, {"j16nt", &t.j16nt}, {"tile2d", &t.tile2d}, {"latlin", &t.latlin}};
+        {"j16", &t.j16}, {"j16pf", &t.j16pf}, {"j16nt", &t.j16nt}, {"tile2d", &t.tile2d}, {"latlin", &t.latlin}, {"pskipb", &t.pskipb}, {"pskipmin", &t.pskipmin}};
     // tokens are separated by ',', a token is key=value with the WHOLE key compared
     for (const char* p = e; *p;) {
         const char* end = strchr(p, ',');
@@ -222,6 +224,7 @@ template <typename C> struct Plan {
     const int *labels, *input_lengths, *label_lengths;
     LogPair<C>* lp2; C *logz, *alpha, *beta; Cell<C>* rowtab;
     double *offa, *offb, *llf, *llb;
+    int* padflag;
     float *rowmax, *wmat, *side;
     size_t side_bytes = 0;
     int lat_cols = 1;              // lattice columns per lane (1 | 2), its wavefronts per block ...
@@ -268,6 +271,7 @@ static bool make_plan(Plan<C>& p, int A, int N, const rnntOptions& opt, void* wo
     p.offb = reinterpret_cast<double*>(ws + lay.offb);
     p.llf = reinterpret_cast<double*>(ws + lay.llf);
     p.llb = reinterpret_cast<double*>(ws + lay.llb);
+    p.padflag = reinterpret_cast<int*>(ws + lay.padflag);
     p.rowmax = reinterpret_cast<float*>(ws + lay.rowmax);
     p.wmat = reinterpret_cast<float*>(ws + lay.wmat);
     p.side = reinterpret_cast<float*>(ws + lay.side);
@@ -295,7 +299,7 @@ template <typename C> static void launch_lattice(Plan<C>& p, bool with_beta) {
 #define RNNT_LATTICE(MW, CC)                                                                                     \
     hipLaunchKernelGGL((lattice_kernel<C, MW, CC>), dim3(p.N * dirs), dim3(p.lat_w * 64), 0, p.stream, p.lp2,          \
                        p.alpha, p.beta, p.offa, p.offb, p.llf, p.llb, p.costs_dev, p.input_lengths, p.label_lengths,  \
-                       p.maxT, p.maxU, p.Up, dirs)
+                       p.maxT, p.maxU, p.Up, dirs, p.padflag)
     // One-wavefront fp32 lattices with at most one block per compute unit: the linear-domain chain with helper wavefronts
     // (range guard + log-domain fallback inside).  Its eight wavefronts per (sample, direction) buy latency with idle
     // SIMDs; past one block per CU there are none and the one-wavefront kernel is the faster again (N=128 T=200 U=41:
@@ -304,7 +308,7 @@ template <typename C> static void launch_lattice(Plan<C>& p, bool with_beta) {
         if constexpr (sizeof(C) == 4)
             hipLaunchKernelGGL((lattice_lin_kernel<0>), dim3(p.N * dirs), dim3(kLinThreads), 0, p.stream, p.lp2, p.alpha, p.beta, p.offa, p.offb,
                                p.llf, p.llb, p.costs_dev, p.input_lengths, p.label_lengths, p.maxT, p.maxU, p.Up, dirs,
-                               tune().latlin == 2 ? 1 : 0);
+                               tune().latlin == 2 ? 1 : 0, p.padflag);
     }
     else if (p.Up <= 64) RNNT_LATTICE(1, 1);                       // one wavefront, no synchronisation
     else if (p.lat_cols == 1) RNNT_LATTICE(8, 1);                  // maxU <= 512, one column per lane
@@ -329,7 +333,7 @@ template <typename C> static void launch_coef(Plan<C>& p, bool joint = false, bo
                              p.N - b0 < kGridSamples ? p.N - b0 : kGridSamples);
             hipLaunchKernelGGL((coef_cell_kernel<C>), cgrid, dim3(256), 0, p.stream, p.lp2, p.logz, p.alpha, p.beta, p.offa,
                                p.offb, p.llf, p.labels, p.input_lengths, p.label_lengths, p.rowtab, p.maxT, p.maxU, p.Up,
-                               wmat, Upad, p.fastemit, planes, p.offsets, p.lat_w, p.lat_sh, b0, p.N);
+                               wmat, Upad, p.fastemit, planes, p.offsets, p.lat_w, p.lat_sh, b0, p.N, p.padflag);
         }
     } else {
         const int DN = sizeof(C) == 4 ? 32 : 16;           // diagonals per tile (coef_kernel)
@@ -338,7 +342,7 @@ template <typename C> static void launch_coef(Plan<C>& p, bool joint = false, bo
             const dim3 cgrid(static_cast<unsigned>(tilesU * tilesN), p.N - b0 < kGridSamples ? p.N - b0 : kGridSamples);
             hipLaunchKernelGGL((coef_kernel<C>), cgrid, dim3(256), 0, p.stream, p.lp2, p.logz, p.alpha, p.beta, p.offa,
                                p.offb, p.llf, p.labels, p.input_lengths, p.label_lengths, p.rowtab, p.maxT, p.maxU, p.Up,
-                               wmat, Upad, tilesU, p.fastemit, planes, p.offsets, p.lat_w, p.lat_sh, b0, p.N);
+                               wmat, Upad, tilesU, p.fastemit, planes, p.offsets, p.lat_w, p.lat_sh, b0, p.N, p.padflag);
         }
     }
     p.check();

@@ -1105,8 +1105,9 @@ __global__ __launch_bounds__(MAXW * 64) void lattice_kernel(
         const LogPair<L>* __restrict__ lp2, L* __restrict__ alpha, L* __restrict__ beta,
         double* __restrict__ offa, double* __restrict__ offb, double* __restrict__ ll_fwd,
         double* __restrict__ ll_bwd, L* __restrict__ costs_dev, const int* __restrict__ xlen,
-        const int* __restrict__ ylen, int maxT, int maxU, int Up, int dirs) {
+        const int* __restrict__ ylen, int maxT, int maxU, int Up, int dirs, int* __restrict__ padflag) {
     const int b = blockIdx.x / dirs;
+    if (blockIdx.x == 0 && threadIdx.x == 0) *padflag = 0;     // (set again by the coefficient kernel if the batch has padding)
     lattice_body<L, MAXW, COLS>(lp2, alpha, beta, offa, offb, ll_fwd, ll_bwd, costs_dev, xlen, ylen, maxT, maxU, Up, b,
                                 static_cast<int>(blockIdx.x) - b * dirs, static_cast<int>(threadIdx.x), static_cast<int>(blockDim.x >> 6));
 }
@@ -1379,9 +1380,10 @@ __global__ __launch_bounds__(kLinThreads) void lattice_lin_kernel(
         const LogPair<float>* __restrict__ lp2, float* __restrict__ alpha, float* __restrict__ beta,
         double* __restrict__ offa, double* __restrict__ offb, double* __restrict__ ll_fwd,
         double* __restrict__ ll_bwd, float* __restrict__ costs_dev, const int* __restrict__ xlen,
-        const int* __restrict__ ylen, int maxT, int maxU, int Up, int dirs, int force_fallback) {
+        const int* __restrict__ ylen, int maxT, int maxU, int Up, int dirs, int force_fallback, int* __restrict__ padflag) {
     __shared__ LinShared sh;
     const int b = blockIdx.x / dirs;
+    if (blockIdx.x == 0 && threadIdx.x == 0) *padflag = 0;     // (set again by the coefficient kernel if the batch has padding)
     const int dir = static_cast<int>(blockIdx.x) - b * dirs;
     if (dir == 0) lattice_lin_body<0>(sh, lp2, alpha, beta, offa, offb, ll_fwd, ll_bwd, costs_dev, xlen, ylen, maxT, maxU, Up, b);
     else lattice_lin_body<1>(sh, lp2, alpha, beta, offa, offb, ll_fwd, ll_bwd, costs_dev, xlen, ylen, maxT, maxU, Up, b);
@@ -1493,7 +1495,7 @@ __global__ __launch_bounds__(256) void coef_cell_kernel(
         const double* __restrict__ offb, const double* __restrict__ ll_fwd,
         const int* __restrict__ labels, const int* __restrict__ xlen, const int* __restrict__ ylen,
         Cell<L>* __restrict__ rowtab, int maxT, int maxU, int Up, float* __restrict__ wmat, int Upad, float fastemit,
-        int planes, const long long* __restrict__ offsets, int lw, int lsh, int b0, int N) {   // offsets: packed row order (see row_stats_kernel); b0 = first sample of this launch, N = samples of the batch   // planes: 1 = W only; 2 = W and CL (third plane); 3 = W, CB, CL (one-hot df corrections); 4 = W, CB, CL and a plane of c
+        int planes, const long long* __restrict__ offsets, int lw, int lsh, int b0, int N, int* __restrict__ padflag) {   // offsets: packed row order (see row_stats_kernel); b0 = first sample of this launch, N = samples of the batch   // planes: 1 = W only; 2 = W and CL (third plane); 3 = W, CB, CL (one-hot df corrections); 4 = W, CB, CL and a plane of c
                         // that is written INTO the record table's memory (stride Upad <= 4 maxU floats) instead of
                         // the records -- with the one-hot DF nothing reads cb / cl / label per record any more,
                         // and 16 instead of 28 bytes leave per cell
@@ -1521,6 +1523,7 @@ __global__ __launch_bounds__(256) void coef_cell_kernel(
         if (t < Tb && u < Ub && at < static_cast<size_t>(N) * maxT * maxU) rowtab[at] = o;   // (inside the table whatever the offsets say)
     } else if (planes != 4) {
         rowtab[(static_cast<size_t>(b) * maxT + t) * maxU + u] = o;
+        if (t >= Tb || u >= Ub) *padflag = 1;                 // the batch has padded rows: the gradient kernel may skip their logits
     }
     if (wmat != nullptr) {                                    // additive joint only: W = exp(c), cb, cl; row stride Upad
         const float c = static_cast<float>(o.x);
@@ -1559,7 +1562,8 @@ __global__ __launch_bounds__(256) void coef_kernel(
         const double* __restrict__ offb, const double* __restrict__ ll_fwd,
         const int* __restrict__ labels, const int* __restrict__ xlen, const int* __restrict__ ylen,
         Cell<L>* __restrict__ rowtab, int maxT, int maxU, int Up, float* __restrict__ wmat, int Upad, int tilesU,
-        float fastemit, int planes, const long long* __restrict__ offsets, int lw, int lsh, int b0, int N) {
+        float fastemit, int planes, const long long* __restrict__ offsets, int lw, int lsh, int b0, int N,
+        int* __restrict__ padflag) {
     constexpr int DN = sizeof(L) == 4 ? 32 : 16;           // diagonals per tile (LDS: DN * 64 records)
     __shared__ Cell<L> recs[DN][64];
     const int b = b0 + blockIdx.y;
@@ -1615,6 +1619,7 @@ __global__ __launch_bounds__(256) void coef_kernel(
             if (t < Tb && u < Ub && at < static_cast<size_t>(N) * maxT * maxU) rowtab[at] = o;
         } else if (planes != 4) {
             rowtab[(static_cast<size_t>(b) * maxT + t) * maxU + u] = o;
+            if (t >= Tb || u >= Ub) *padflag = 1;          // the batch has padded rows: the gradient kernel may skip their logits
         }
         if (wmat != nullptr) {                             // additive joint only: W = exp(c), cb, cl; row stride Upad
             const float cc = static_cast<float>(o.x);
@@ -1675,14 +1680,20 @@ __global__ __launch_bounds__(256) void fill_row_scale_kernel(
 // here, so no memset of the gradient tensor exists (the reference does one: gpu_rnnt.h:107-110).
 // Measured on MI355X (tools/microbench/stream_variants.hip): this structure sustains
 // 6.4-6.5 TB/s read+write with the exp included, the wavefront-per-row form 5.1 TB/s.
-template <typename Tag, int SCALE, int PPT, bool PADSKIP>   // SCALE: 0 none, 1 per sample (padded layout), 2 per row (packed); PPT = packets per thread and iteration
+template <typename Tag, int SCALE, int PPT, int PADSKIP>   // SCALE: 0 none, 1 per sample (padded layout), 2 per row (packed); PPT = packets per thread and iteration;
+                                                            // PADSKIP: the logits of padded rows are not read -- 0 never, 1 always, 2 when the batch has padding (padflag)
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(typename Tag::comp) == 8 ? 1 : 8))) void grad_flat_kernel(
         const typename Tag::store* __restrict__ acts, typename Tag::store* __restrict__ grads,
         const Cell<typename Tag::comp>* __restrict__ rowtab, const typename Tag::comp* __restrict__ grad_scale,
         unsigned long long E, unsigned long long R, int A, int blank, int TU, float invA,
-        unsigned long long dq, int drem, const typename Tag::comp* __restrict__ rowscale) {
+        unsigned long long dq, int drem, const typename Tag::comp* __restrict__ rowscale, const int* __restrict__ padflag) {
     using C = typename Tag::comp;
     constexpr bool SCALED = SCALE != 0;
+    // Short rows (PADSKIP == 2): testing the record before the load is a dependent memory latency per block and costs a
+    // batch WITHOUT padding 7 % (2 KB rows); whether there is any padding is one word the coefficient kernel has left
+    // behind -- a scalar load that is back before the index arithmetic below is through.
+    bool ps = PADSKIP == 1;
+    if constexpr (PADSKIP == 2) ps = padflag[0] != 0;
     constexpr int V = Vec<Tag>::N;
     constexpr int kChunkPackets = PPT * 256;
     constexpr int CH = kChunkPackets * V;                 // elements per chunk
@@ -1783,19 +1794,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(type
             row[k] = r + q;
             if (live[k]) {
                 rec[k] = rowtab[row[k]];
-                if constexpr (!PADSKIP) raw[k] = load_packet<true>(in + pk0 + p);
+                if (PADSKIP == 0 || !ps) raw[k] = load_packet<true>(in + pk0 + p);
                 // a packet that crosses into the next row (A % V != 0) needs that row's record too: asked
                 // for here, with the other loads -- fetched inside the compute phase it was a dependent
                 // global latency that nearly every wavefront paid on c4 (A = 50: 5.9 -> 6.4 TB/s)
                 if (rr + V > A) rec2[k] = rowtab[row[k] + 1 < R ? row[k] + 1 : R - 1];
             }
         }
-        if constexpr (PADSKIP) {
-            // Long rows only (host: row >= 8 KB): the record comes first, and a packet that lies
-            // wholly inside a PADDED row is only zero-filled, its logits are never read (with T_b,
-            // U_b spread over [max/2, max] that is ~40 % of the rows: c3 gradient pass 2.58 ->
-            // 2.11 ms).  For short rows the extra dependent latency costs more than it saves
-            // (measured +7 % on 2 KB rows), so they keep the unconditional load above.
+        if (PADSKIP != 0 && ps) {
+            // The record comes first, and a packet that lies wholly inside a PADDED row is only zero-filled, its logits
+            // are never read (with T_b, U_b spread over [max/2, max] that is ~40 % of the rows: c3 gradient pass 2.58 ->
+            // 2.11 ms, c5 0.67 -> 0.60).  Rows from 8 KB on always go this way; shorter ones when the batch has padding.
 #pragma unroll
             for (int k = 0; k < PPT; ++k) {
                 const int p = k * 256 + threadIdx.x;

@@ -1,7 +1,7 @@
 #!/bin/bash
 # One GPU-box session (run through gpurun from the repo root): the -m gpu suite, the smoke test, the default bench line and
 # the profile set of tools/gpu_profile.sh.  Everything lands in gpurun_out/ (scratch); copy what should be judged to profiles/.
-#   /usr/local/graft/bin/gpurun --timeout 2400 -- 'bash tools/gpu_call.sh r03r'
+#   /usr/local/graft/bin/gpurun --timeout 2400 -- 'bash tools/gpu_call.sh r03s'
 set -x
 TAG=${1:-rXX}
 cd "${GRAFT_REPO_ROOT:-.}"

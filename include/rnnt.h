@@ -86,7 +86,13 @@ typedef struct rnntOptions rnntOptions;
  * Replaces reference include/rnnt.h:104-113 / src/rnnt_entrypoint.cpp:38-93.
  * Returns RNNT_STATUS_INVALID_VALUE for NULL activations / flat_labels /
  * label_lengths / input_lengths / costs / workspace, for alphabet_size,
- * minibatch, options.maxT or options.maxU <= 0, and for an unknown options.loc. */
+ * minibatch, options.maxT or options.maxU <= 0, and for an unknown options.loc.
+ * NON-FINITE LOGITS (RNNT_GPU; every entry point, also the packed and the additive-joint ones): a NaN or +inf logit -- or a
+ * row of -inf only -- in a row INSIDE a sample's T_b x U_b lattice makes that sample's cost NaN and the gradient of each of
+ * its in-lattice rows NaN, as the reference's arithmetic does (include/detail/reduce.h:85,103 -> gpu_rnnt_kernel.h:5-9 ->
+ * rnnt_helper.h:16-24); its padded rows stay zero, the other samples of the batch are not affected, and the status is
+ * RNNT_STATUS_SUCCESS (a NaN loss is a result, as in the reference).  Values in PADDED rows are never read.  Single -inf
+ * logits are ordinary (probability zero). */
 rnntStatus_t compute_rnnt_loss(const float* const activations,
                                float* gradients,
                                const int* const flat_labels,
@@ -182,9 +188,19 @@ rnntStatus_t compute_rnnt_loss_async(const void* activations,
  * on this rank's shard, then [summed loss, sample count] of the shard as two fp64 values into `loss_sum_count_device`, then --
  * when `rccl_comm` is not NULL -- one in-place ncclAllReduce(sum) of those 16 bytes over the communicator (an `ncclComm_t` of
  * RCCL, passed as void*; shards may be ragged, the mean is sum / count of the reduced pair), all enqueued on options.stream:
- * no host copy, no synchronisation.  RCCL is looked up at run time (librccl.so.1): the library has no link dependency on it;
- * EXECUTION_FAILED if a communicator is given and RCCL cannot be found or the collective fails.  rccl_comm == NULL leaves
- * the local pair (single GPU, or a caller with its own collective).  Not in the reference (no multi-device layer). */
+ * no host copy, no synchronisation.  rccl_comm == NULL leaves the local pair (single GPU, or a caller with its own
+ * collective).  Not in the reference (no multi-device layer).
+ * WHICH RCCL: the library has no link dependency on RCCL and calls ncclAllReduce through a pointer -- which must belong to
+ * the SAME RCCL copy that created `rccl_comm` (a process can hold two: PyTorch ships torch/lib/librccl.so next to
+ * /opt/rocm/lib/librccl.so; a communicator handed to the other copy is undefined behaviour).  The pointer is, in order:
+ * the one registered with rnnt_set_rccl_all_reduce(); else the ncclAllReduce of the ONE librccl already mapped into the
+ * process (opened with RTLD_NOLOAD: nothing new is loaded); else -- none mapped -- librccl.so.1 / librccl.so by name.
+ * Two different copies mapped and none registered: EXECUTION_FAILED and a line on stderr naming them, never a guess.
+ * EXECUTION_FAILED also if RCCL cannot be found or the collective fails.
+ * ALL RANKS OR NONE: once the arguments every rank shares are accepted (loss_sum_count_device, loc, RCCL available), a
+ * rank whose LOCAL part fails (INVALID_VALUE for its shard's shape, a launch error) still joins the collective, with a
+ * NaN pair, and then returns its own status: its peers are not left blocked in ncclAllReduce, and every rank's reduced
+ * loss is NaN. */
 rnntStatus_t compute_rnnt_loss_sharded(const void* activations,
                                        void* gradients,
                                        const int* const flat_labels,
@@ -199,6 +215,13 @@ rnntStatus_t compute_rnnt_loss_sharded(const void* activations,
                                        void* workspace,
                                        rnntOptions options,
                                        int dtype_code);
+
+/* The ncclAllReduce compute_rnnt_loss_sharded calls (see there): the address of `ncclAllReduce` in the RCCL copy the caller's
+ * communicators come from, e.g. dlsym(handle_of_that_librccl, "ncclAllReduce").  NULL un-registers and makes the next
+ * sharded call look again.  rnnt_rccl_source() says where the pointer in use came from ("registered by the caller", the
+ * path of the mapped library, the name it was opened by, or "" when there is none) -- for logs and tests. */
+void rnnt_set_rccl_all_reduce(void* nccl_all_reduce_fn);
+const char* rnnt_rccl_source(void);
 
 /* Two-phase form for autograd frameworks ("fused backward").
  * compute_rnnt_loss_fwd enqueues the row statistics, the lattice and -- with prepare_backward != 0 --

@@ -12,8 +12,12 @@
 #include "rnnt_cpu.h"
 #include "rnnt_host.h"
 
+#include <link.h>
+#include <limits.h>
+
 #include <atomic>
 #include <mutex>
+#include <string>
 #include <vector>
 
 
@@ -45,7 +49,7 @@ static void launch_row_stats(Plan<typename Tag::comp>& p, const typename Tag::st
 #define RNNT_TILE2D(T1, U1)                                                                                       \
     hipLaunchKernelGGL((row_stats_tile2d_kernel<Tag, T1, U1>), dim3(xgrid), dim3(256), lds2, p.stream, acts, p.labels, \
                        p.input_lengths, p.label_lengths, p.lp2, p.logz, p.maxT, p.maxU, p.Up, p.A, p.blank, p.N, tilesT, \
-                       tilesU, piece)
+                       tilesU, piece, p.poison)
             if (sq) RNNT_TILE2D(16, 16); else RNNT_TILE2D(8, 32);
 #undef RNNT_TILE2D
             p.check();
@@ -67,7 +71,7 @@ static void launch_row_stats(Plan<typename Tag::comp>& p, const typename Tag::st
 #define RNNT_TILE(GG)                                                                                       \
     hipLaunchKernelGGL((row_stats_tile_kernel<Tag, GG>), dim3(xgrid), dim3(256), lds, p.stream, acts, p.labels, \
                        p.input_lengths, p.label_lengths, p.lp2, p.logz, Rall, p.maxT, p.maxU, p.Up,           \
-                       p.A, p.blank, tn.xcd | (tn.xst << 4), p.offsets, p.N)
+                       p.A, p.blank, tn.xcd | (tn.xst << 4), p.offsets, p.N, p.poison)
             switch (G) {
                 case 1: RNNT_TILE(1); break;
                 case 2: RNNT_TILE(2); break;
@@ -92,12 +96,12 @@ static void launch_row_stats(Plan<typename Tag::comp>& p, const typename Tag::st
             if (!tn.nta)
                 hipLaunchKernelGGL((row_stats_block_kernel<Tag, false, 4>), bgrid, dim3(256), 0, p.stream, acts, p.labels,
                                    p.input_lengths, p.label_lengths, p.lp2, p.logz, p.maxT, p.maxU, p.Up, p.A, p.blank, vec_ok,
-                                   p.offsets, p.packed_rows, b0);
+                                   p.offsets, p.packed_rows, b0, p.poison);
             else
 #endif
                 hipLaunchKernelGGL((row_stats_block_kernel<Tag, true, 4>), bgrid, dim3(256), 0, p.stream, acts, p.labels,
                                    p.input_lengths, p.label_lengths, p.lp2, p.logz, p.maxT, p.maxU, p.Up, p.A, p.blank, vec_ok,
-                                   p.offsets, p.packed_rows, b0);
+                                   p.offsets, p.packed_rows, b0, p.poison);
         }
         p.check();
         return;
@@ -108,7 +112,7 @@ static void launch_row_stats(Plan<typename Tag::comp>& p, const typename Tag::st
         hipLaunchKernelGGL((row_stats_kernel<Tag, WV, NT>),                                                      \
                            dim3((p.cells_per_sample + WV - 1) / WV, p.N - b0 < kGridSamples ? p.N - b0 : kGridSamples), \
                            dim3(WV * 64), 0, p.stream, acts, p.labels, p.input_lengths, p.label_lengths, p.lp2,  \
-                           p.logz, p.maxT, p.maxU, p.Up, p.A, p.blank, vec_ok, p.offsets, p.packed_rows, b0)
+                           p.logz, p.maxT, p.maxU, p.Up, p.A, p.blank, vec_ok, p.offsets, p.packed_rows, b0, p.poison)
     // (the forms a release build never selects exist in the development build only: less device code to load)
 #ifdef RNNT_DEV
     if (tn.nta) { if (tn.sw == 8) RNNT_STATS(8, true); else if (tn.sw == 2) RNNT_STATS(2, true); else RNNT_STATS(4, true); }
@@ -489,26 +493,76 @@ rnntStatus_t compute_rnnt_loss_async(const void* activations, void* gradients, c
                      costs_device, grad_scale_device, workspace, options, dtype_code, 3, -1);
 }
 
-// RCCL is looked up at run time (the library links against no collective library): the process's already loaded librccl
-// when there is one (PyTorch ships its own), else the ROCm one.
+// RCCL is looked up at run time: the library links against no collective library.  Which copy matters: an ncclComm_t is
+// only meaningful to the RCCL that created it, and a process can hold more than one (PyTorch ships its own librccl.so
+// under torch/lib next to the ROCm one).  Order: (1) the function the caller registered with rnnt_set_rccl_all_reduce();
+// (2) the ONE librccl that is already mapped into the process (dl_iterate_phdr; opened with RTLD_NOLOAD, so nothing new is
+// loaded) -- two different mapped copies and no registered function is an error, reported on stderr, never a guess;
+// (3) nothing mapped: librccl.so.1 / librccl.so by name (a caller that creates its communicator later, from the same name).
 struct Rccl {
+    using AllReduce = int (*)(const void*, void*, size_t, int, int, void*, hipStream_t);
+    std::mutex mu;
+    AllReduce registered = nullptr;                 // rnnt_set_rccl_all_reduce
     bool tried = false;
-    int (*all_reduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
+    AllReduce found = nullptr;
+    char from[512] = {0};                           // where `found` came from (rnnt_rccl_source)
 };
-static Rccl& rccl() {
-    static Rccl r;
-    static std::mutex mu;
-    std::lock_guard<std::mutex> g(mu);
-    if (!r.tried) {
-        r.tried = true;
-        for (const char* name : {"librccl.so.1", "librccl.so"}) {
-            void* h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
-            if (h == nullptr) continue;
-            r.all_reduce = reinterpret_cast<int (*)(const void*, void*, size_t, int, int, void*, hipStream_t)>(dlsym(h, "ncclAllReduce"));
-            if (r.all_reduce != nullptr) break;
-        }
+static Rccl& rccl_state() { static Rccl r; return r; }
+
+static int rccl_visit(struct dl_phdr_info* info, size_t, void* data) {
+    auto* paths = static_cast<std::vector<std::string>*>(data);
+    if (info->dlpi_name == nullptr) return 0;
+    const char* base = strrchr(info->dlpi_name, '/');
+    base = base ? base + 1 : info->dlpi_name;
+    if (strncmp(base, "librccl.so", 10) != 0) return 0;
+    char real[PATH_MAX];
+    std::string path = realpath(info->dlpi_name, real) != nullptr ? real : info->dlpi_name;   // (symlinks of one file count once)
+    for (const auto& q : *paths)
+        if (q == path) return 0;
+    paths->push_back(path);
+    return 0;
+}
+
+static Rccl::AllReduce rccl_all_reduce() {
+    Rccl& r = rccl_state();
+    std::lock_guard<std::mutex> g(r.mu);
+    if (r.registered != nullptr) return r.registered;
+    if (r.tried) return r.found;
+    r.tried = true;
+    std::vector<std::string> mapped;
+    dl_iterate_phdr(rccl_visit, &mapped);
+    if (mapped.size() > 1) {
+        fprintf(stderr, "warprnnt: %zu different RCCL libraries are mapped into this process (", mapped.size());
+        for (size_t i = 0; i < mapped.size(); ++i) fprintf(stderr, "%s%s", i ? ", " : "", mapped[i].c_str());
+        fprintf(stderr, "): compute_rnnt_loss_sharded cannot tell which one made the communicator -- pass its ncclAllReduce "
+                        "to rnnt_set_rccl_all_reduce()\n");
+        return nullptr;
     }
-    return r;
+    auto take = [&](const char* name, int flags) {
+        void* h = dlopen(name, flags);
+        if (h == nullptr) return false;
+        r.found = reinterpret_cast<Rccl::AllReduce>(dlsym(h, "ncclAllReduce"));
+        if (r.found != nullptr) snprintf(r.from, sizeof(r.from), "%s", name);
+        return r.found != nullptr;
+    };
+    if (mapped.size() == 1) { (void)take(mapped[0].c_str(), RTLD_NOW | RTLD_NOLOAD); return r.found; }
+    for (const char* name : {"librccl.so.1", "librccl.so"})
+        if (take(name, RTLD_NOW | RTLD_GLOBAL)) break;
+    return r.found;
+}
+
+void rnnt_set_rccl_all_reduce(void* nccl_all_reduce_fn) {
+    Rccl& r = rccl_state();
+    std::lock_guard<std::mutex> g(r.mu);
+    r.registered = reinterpret_cast<Rccl::AllReduce>(nccl_all_reduce_fn);
+    if (nccl_all_reduce_fn == nullptr) { r.tried = false; r.found = nullptr; r.from[0] = 0; }   // NULL: forget, look again at the next call
+}
+
+const char* rnnt_rccl_source(void) {
+    if (rccl_all_reduce() == nullptr) return "";
+    Rccl& r = rccl_state();
+    std::lock_guard<std::mutex> g(r.mu);
+    return r.registered != nullptr ? "registered by the caller" : r.from;
 }
 
 rnntStatus_t compute_rnnt_loss_sharded(const void* activations, void* gradients, const int* const flat_labels,
@@ -516,26 +570,38 @@ rnntStatus_t compute_rnnt_loss_sharded(const void* activations, void* gradients,
                                        int alphabet_size, int minibatch, void* costs_device,
                                        const void* grad_scale_device, double* loss_sum_count_device, void* rccl_comm,
                                        void* workspace, rnntOptions options, int dtype_code) {
-    if (bad_args(activations, flat_labels, label_lengths, input_lengths, costs_device, workspace,
-                 alphabet_size, minibatch, options) || options.loc != RNNT_GPU || loss_sum_count_device == nullptr)
-        return RNNT_STATUS_INVALID_VALUE;
-    if (rccl_comm != nullptr && rccl().all_reduce == nullptr) return RNNT_STATUS_EXECUTION_FAILED;   // no RCCL in this process
-    const rnntStatus_t st = run_async(activations, gradients, flat_labels, label_lengths, input_lengths, alphabet_size,
-                                      minibatch, costs_device, grad_scale_device, workspace, options, dtype_code, 3, -1);
-    if (st != RNNT_STATUS_SUCCESS) return st;
+    // (argument errors every rank of a job makes alike return before anything is enqueued)
+    if (loss_sum_count_device == nullptr || options.loc != RNNT_GPU) return RNNT_STATUS_INVALID_VALUE;
+    Rccl::AllReduce all_reduce = nullptr;
+    if (rccl_comm != nullptr && (all_reduce = rccl_all_reduce()) == nullptr) return RNNT_STATUS_EXECUTION_FAILED;   // no (unambiguous) RCCL in this process
     hipStream_t stream = reinterpret_cast<hipStream_t>(options.stream);
+    rnntStatus_t st = bad_args(activations, flat_labels, label_lengths, input_lengths, costs_device, workspace,
+                               alphabet_size, minibatch, options)
+                          ? RNNT_STATUS_INVALID_VALUE
+                          : run_async(activations, gradients, flat_labels, label_lengths, input_lengths, alphabet_size,
+                                      minibatch, costs_device, grad_scale_device, workspace, options, dtype_code, 3, -1);
     (void)hipGetLastError();
-    if (dtype_code == 1)
-        hipLaunchKernelGGL((loss_sum_kernel<double>), dim3(1), dim3(256), 0, stream, static_cast<const double*>(costs_device),
-                           minibatch, loss_sum_count_device);
-    else
-        hipLaunchKernelGGL((loss_sum_kernel<float>), dim3(1), dim3(256), 0, stream, static_cast<const float*>(costs_device),
-                           minibatch, loss_sum_count_device);
-    if (hipGetLastError() != hipSuccess) return RNNT_STATUS_EXECUTION_FAILED;
+    if (st == RNNT_STATUS_SUCCESS) {
+        if (dtype_code == 1)
+            hipLaunchKernelGGL((loss_sum_kernel<double>), dim3(1), dim3(256), 0, stream, static_cast<const double*>(costs_device),
+                               minibatch, loss_sum_count_device);
+        else
+            hipLaunchKernelGGL((loss_sum_kernel<float>), dim3(1), dim3(256), 0, stream, static_cast<const float*>(costs_device),
+                               minibatch, loss_sum_count_device);
+        if (hipGetLastError() != hipSuccess) st = RNNT_STATUS_EXECUTION_FAILED;
+    }
+    // ALL RANKS OR NONE: a rank whose local part failed (a shard shape only this rank has, a launch error) still joins
+    // the collective -- with a NaN pair, so every rank's reduced loss is NaN and every rank can see the step failed --
+    // instead of leaving its peers blocked in ncclAllReduce for ever; it then returns its own status.
+    if (st != RNNT_STATUS_SUCCESS && rccl_comm != nullptr &&
+        hipMemsetAsync(loss_sum_count_device, 0xff, 2 * sizeof(double), stream) != hipSuccess) {
+        (void)hipGetLastError();
+        return st;                                       // (cannot even mark the pair: nothing sane is left to send)
+    }
     if (rccl_comm != nullptr &&
-        rccl().all_reduce(loss_sum_count_device, loss_sum_count_device, 2, /*ncclFloat64*/ 8, /*ncclSum*/ 0, rccl_comm, stream) != 0)
-        return RNNT_STATUS_EXECUTION_FAILED;
-    return RNNT_STATUS_SUCCESS;
+        all_reduce(loss_sum_count_device, loss_sum_count_device, 2, /*ncclFloat64*/ 8, /*ncclSum*/ 0, rccl_comm, stream) != 0)
+        return st != RNNT_STATUS_SUCCESS ? st : RNNT_STATUS_EXECUTION_FAILED;
+    return st;
 }
 
 rnntStatus_t compute_rnnt_loss_fwd(const void* activations, const int* const flat_labels,

@@ -27,7 +27,7 @@ constexpr size_t kAlign = 256;
 static inline size_t align_up(size_t x) { return (x + kAlign - 1) / kAlign * kAlign; }
 
 struct Layout {
-    size_t lp2, logz, alpha, rowtab, beta, offa, offb, llf, llb, costs, padflag, rowmax, side, side_bytes, wmat, total;
+    size_t lp2, logz, alpha, rowtab, beta, offa, offb, llf, llb, costs, padflag, poison, rowmax, side, side_bytes, wmat, total;
 };
 
 // lat = bytes of one lattice value (4: fp32 lattice for 16/32-bit activations, 8: fp64).
@@ -51,6 +51,7 @@ static Layout make_layout(int maxT, int maxU, int N, size_t lat, bool joint) {
     l.llb = o;   o = align_up(o + N * sizeof(double));
     l.costs = o; o = align_up(o + N * sizeof(double));
     l.padflag = o; o = align_up(o + sizeof(int));   // "some record of this batch is padding": zeroed by the lattice kernel, set by the coefficient kernel, read by the gradient kernel
+    l.poison = o; o = align_up(o + N * sizeof(int));   // per sample: the statistics kernels' hint of a row with a non-finite log Z (rnnt_kernels.h: note_non_finite)
     // additive joint only: row maxima of f and g, dense matrices W, CB, CL (row stride = maxU rounded up to 8)
     l.rowmax = o; l.wmat = o; l.side = o; l.side_bytes = 0;
     if (joint) {
@@ -225,6 +226,7 @@ template <typename C> struct Plan {
     LogPair<C>* lp2; C *logz, *alpha, *beta; Cell<C>* rowtab;
     double *offa, *offb, *llf, *llb;
     int* padflag;
+    int* poison;
     float *rowmax, *wmat, *side;
     size_t side_bytes = 0;
     int lat_cols = 1;              // lattice columns per lane (1 | 2), its wavefronts per block ...
@@ -272,6 +274,7 @@ static bool make_plan(Plan<C>& p, int A, int N, const rnntOptions& opt, void* wo
     p.llf = reinterpret_cast<double*>(ws + lay.llf);
     p.llb = reinterpret_cast<double*>(ws + lay.llb);
     p.padflag = reinterpret_cast<int*>(ws + lay.padflag);
+    p.poison = reinterpret_cast<int*>(ws + lay.poison);
     p.rowmax = reinterpret_cast<float*>(ws + lay.rowmax);
     p.wmat = reinterpret_cast<float*>(ws + lay.wmat);
     p.side = reinterpret_cast<float*>(ws + lay.side);
@@ -299,7 +302,7 @@ template <typename C> static void launch_lattice(Plan<C>& p, bool with_beta) {
 #define RNNT_LATTICE(MW, CC)                                                                                     \
     hipLaunchKernelGGL((lattice_kernel<C, MW, CC>), dim3(p.N * dirs), dim3(p.lat_w * 64), 0, p.stream, p.lp2,          \
                        p.alpha, p.beta, p.offa, p.offb, p.llf, p.llb, p.costs_dev, p.input_lengths, p.label_lengths,  \
-                       p.maxT, p.maxU, p.Up, dirs, p.padflag)
+                       p.maxT, p.maxU, p.Up, dirs, p.padflag, p.logz, p.poison)
     // One-wavefront fp32 lattices with at most one block per compute unit: the linear-domain chain with helper wavefronts
     // (range guard + log-domain fallback inside).  Its eight wavefronts per (sample, direction) buy latency with idle
     // SIMDs; past one block per CU there are none and the one-wavefront kernel is the faster again (N=128 T=200 U=41:
@@ -308,7 +311,7 @@ template <typename C> static void launch_lattice(Plan<C>& p, bool with_beta) {
         if constexpr (sizeof(C) == 4)
             hipLaunchKernelGGL((lattice_lin_kernel<0>), dim3(p.N * dirs), dim3(kLinThreads), 0, p.stream, p.lp2, p.alpha, p.beta, p.offa, p.offb,
                                p.llf, p.llb, p.costs_dev, p.input_lengths, p.label_lengths, p.maxT, p.maxU, p.Up, dirs,
-                               tune().latlin == 2 ? 1 : 0, p.padflag);
+                               tune().latlin == 2 ? 1 : 0, p.padflag, p.logz, p.poison);
     }
     else if (p.Up <= 64) RNNT_LATTICE(1, 1);                       // one wavefront, no synchronisation
     else if (p.lat_cols == 1) RNNT_LATTICE(8, 1);                  // maxU <= 512, one column per lane

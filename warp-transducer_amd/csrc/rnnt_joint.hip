@@ -92,11 +92,11 @@ static rnntStatus_t run_gpu_joint(const typename Tag::store* f, const typename T
 #define RNNT_JZ(SS, VV, SAMP, GATE)                                                                              \
     hipLaunchKernelGGL((joint_z_kernel<Tag, SS, VV, SAMP>), dim3(SS == 1 ? ((tiles + 3) / 4 + 7) / 8 * 8 : tiles, N),               \
                        dim3(SS == 1 ? 256 : SS * 64), 0, p.stream, f, g, p.rowmax, labels, input_lengths,        \
-                       label_lengths, p.lp2, p.logz, maxT, maxU, p.Up, A, p.blank, tilesU, tiles, N, GATE, seq)
+                       label_lengths, p.lp2, p.logz, maxT, maxU, p.Up, A, p.blank, tilesU, tiles, N, GATE, seq, p.poison)
 #define RNNT_JZ16(SS, SAMP, GATE)                                                                                \
     hipLaunchKernelGGL((joint_z16_kernel<Tag, SS, SAMP>), dim3(SS == 1 ? ((tiles + 3) / 4 + 7) / 8 * 8 : tiles, N),    \
                        dim3(SS == 1 ? 256 : SS * 64), 0, p.stream, f, g, p.rowmax, labels, input_lengths,        \
-                       label_lengths, p.lp2, p.logz, maxT, maxU, p.Up, A, p.blank, tilesU, tiles, N, GATE, seq)
+                       label_lengths, p.lp2, p.logz, maxT, maxU, p.Up, A, p.blank, tilesU, tiles, N, GATE, seq, p.poison)
 #define RNNT_JZ_ALL(SAMP, GATE)                                                                                  \
         do {                                                                                                    \
             if constexpr (k16) {                                                      \
@@ -125,7 +125,7 @@ static rnntStatus_t run_gpu_joint(const typename Tag::store* f, const typename T
                 hipLaunchKernelGGL((joint_z_small_kernel<Tag>), dim3(((tiles + 3) / 4 + 7) / 8 * 8, N), dim3(256),
                                    4 * kJointZSmallSlice * sizeof(float), p.stream, f, g, p.rowmax, labels,
                                    input_lengths, label_lengths, p.lp2, p.logz, maxT, maxU, p.Up, A, p.blank, tilesU,
-                                   tiles, N);
+                                   tiles, N, p.poison);
             else
                 RNNT_JZ_ALL(false, no_gate);
         }

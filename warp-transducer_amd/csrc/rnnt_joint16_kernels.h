@@ -427,7 +427,7 @@ __global__ __launch_bounds__(S == 1 ? 256 : S * 64) void joint_z16_kernel(
         const typename Tag::store* __restrict__ f, const typename Tag::store* __restrict__ g, float* rowmax,
         const int* __restrict__ labels, const int* __restrict__ xlen, const int* __restrict__ ylen,
         LogPair<float>* __restrict__ lp2, float* __restrict__ logz, int maxT, int maxU, int Up, int A,
-        int blank, int tilesU, int tiles, int N, int* gate, int seq) {
+        int blank, int tilesU, int tiles, int N, int* gate, int seq, int* __restrict__ poison) {   // poison: note_non_finite (rnnt_kernels.h)
     using ST = typename Tag::store;
     constexpr int WAVES = S == 1 ? 4 : S;
     __shared__ float xch[S == 1 ? 1 : S * 1024];           // S > 1: the wavefronts' fragments meet here
@@ -632,6 +632,7 @@ __global__ __launch_bounds__(S == 1 ? 256 : S * 64) void joint_z16_kernel(
         const size_t idx = lat_index(b, t + u, u, maxT, maxU, Up);
         lp2[idx] = rec;
         logz[idx] = lz;
+        note_non_finite(poison, b, t + u, u, Up, lz);
     };
 
     if constexpr (S == 1) {

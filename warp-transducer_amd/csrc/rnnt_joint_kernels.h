@@ -226,7 +226,7 @@ __global__ __launch_bounds__(S == 1 ? 256 : S * 64) void joint_z_kernel(
         const typename Tag::store* __restrict__ f, const typename Tag::store* __restrict__ g, float* rowmax,
         const int* __restrict__ labels, const int* __restrict__ xlen, const int* __restrict__ ylen,
         LogPair<float>* __restrict__ lp2, float* __restrict__ logz, int maxT, int maxU, int Up, int A,
-        int blank, int tilesU, int tiles, int N, int* gate, int seq) {
+        int blank, int tilesU, int tiles, int N, int* gate, int seq, int* __restrict__ poison) {   // poison: note_non_finite (rnnt_kernels.h)
     constexpr int WAVES = S == 1 ? 4 : S;
     __shared__ float4 stage4[WAVES * kJointZSlice / 4];
     __shared__ float refs[SAMPLED ? (S == 1 ? WAVES : 1) : 1][64];   // SAMPLED: the tile's 32 + 32 reference values (x log2 e)
@@ -470,6 +470,7 @@ __global__ __launch_bounds__(S == 1 ? 256 : S * 64) void joint_z_kernel(
         const size_t idx = lat_index(b, t + u, u, maxT, maxU, Up);
         lp2[idx] = rec;
         logz[idx] = lz;
+        note_non_finite(poison, b, t + u, u, Up, lz);
     };
 
     if constexpr (S == 1) {
@@ -519,7 +520,7 @@ __global__ __launch_bounds__(256) void joint_z_small_kernel(
         const typename Tag::store* __restrict__ f, const typename Tag::store* __restrict__ g, const float* __restrict__ rowmax,
         const int* __restrict__ labels, const int* __restrict__ xlen, const int* __restrict__ ylen,
         LogPair<float>* __restrict__ lp2, float* __restrict__ logz, int maxT, int maxU, int Up, int A,
-        int blank, int tilesU, int tiles, int N) {
+        int blank, int tilesU, int tiles, int N, int* __restrict__ poison) {
     extern __shared__ float4 zsmall4[];
     constexpr int IT = kJointZSmallIt;
     const int AS = A | 1;                                  // LDS row stride
@@ -688,7 +689,9 @@ __global__ __launch_bounds__(256) void joint_z_small_kernel(
             rec.x = px[tl * kJointZOutPad + col];
             rec.y = py[tl * kJointZOutPad + col];
             lp2[idx] = rec;
-            logz[idx] = pz[tl * kJointZOutPad + col];
+            const float lz = pz[tl * kJointZOutPad + col];
+            logz[idx] = lz;
+            note_non_finite(poison, b, t0 + u0 + d, col + u0, Up, lz);
         }
     }
 }

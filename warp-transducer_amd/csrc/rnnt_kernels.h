@@ -101,6 +101,34 @@ __host__ __device__ inline size_t lat_index(int b, int n, int u, int maxT, int m
     return (static_cast<size_t>(b) * lat_rows(maxT, maxU) + kLatPad + n) * Up + u;
 }
 
+// NON-FINITE ROW STATISTICS.  A NaN or +inf logit (or a row of -inf only) makes log Z of its row non-finite, and the
+// reference then returns a NaN cost for that sample and NaN gradients on all its rows: its max / exp-sum reductions
+// and log_sum_exp propagate (include/detail/reduce.h:85,103 -> gpu_rnnt_kernel.h:5-9 -> rnnt_helper.h:16-24).  Here the
+// lattice works on log-probs clamped to [log zero, 0] (lat_clamp), which would turn such a row into "probability
+// zero" and route the mass around it -- a finite, wrong cost.  So the statistics kernels leave a HINT: the lane that
+// stores a non-finite log Z also stores (cell index inside the sample's skewed array) + 1 into poison[b]; the alpha
+// block of the sample reads poison[b] when it starts and, if it is non-zero, LOOKS AT THE CELL: the sample is poisoned
+// iff the hinted cell lies inside T_b x U_b and its log Z (written in THIS call: every in-lattice row is) is
+// non-finite.  The workspace is undefined on entry, so a stale or random word is possible -- it costs that one
+// look-up and is then zeroed; it can never poison a clean sample, and a poisoned sample always carries a valid hint
+// (several bad rows race with plain stores; any of them will do).  The streaming kernels pay one compare per row.
+// A poisoned sample: cost = NaN (a plain quiet NaN, not the marker of cost_invalid), llForward = NaN, hence every
+// record of the coefficient kernels and every gradient of its in-lattice rows is NaN; padded rows stay zero; the
+// other samples of the batch are untouched.
+template <typename C> __device__ __forceinline__ bool non_finite(C v) { return !(v - v == C(0)); }
+template <typename C>
+__device__ __forceinline__ void note_non_finite(int* __restrict__ poison, int b, int n, int u, int Up, C logZ) {
+    if (non_finite(logZ)) poison[b] = (kLatPad + n) * Up + u + 1;
+}
+// the alpha block's check of a non-zero hint (see above); Tb, Ub: the sample's clamped lengths
+template <typename L>
+__device__ __forceinline__ bool hint_is_poison(int hint, const L* __restrict__ logz, size_t sample0, int Up, int Tb, int Ub) {
+    if (hint <= 0) return false;
+    const int cell = hint - 1, row = cell / Up, u = cell - row * Up, t = row - kLatPad - u;
+    if (u >= Ub || t < 0 || t >= Tb) return false;
+    return non_finite(logz[sample0 + cell]);
+}
+
 
 // ------------------------------------------------------------------------------------------
 // Online (max, sum-exp) accumulation of N values into a lane's running pair.
@@ -137,7 +165,7 @@ __global__ __launch_bounds__(WAVES * 64) void row_stats_kernel(
         const int* __restrict__ xlen, const int* __restrict__ ylen,
         LogPair<typename Tag::comp>* __restrict__ lp2, typename Tag::comp* __restrict__ logz,
         int maxT, int maxU, int Up, int A, int blank, int vec_ok, const long long* __restrict__ offsets,
-        unsigned long long total_rows, int b0) {             // packed layout: rows of the tensor (offsets are device data: never read past it); b0 = first sample of this launch
+        unsigned long long total_rows, int b0, int* __restrict__ poison) {   // packed layout: rows of the tensor (offsets are device data: never read past it); b0 = first sample of this launch; poison: note_non_finite
     using S = typename Tag::store;
     using C = typename Tag::comp;
     constexpr int V = Vec<Tag>::N;
@@ -252,6 +280,7 @@ __global__ __launch_bounds__(WAVES * 64) void row_stats_kernel(
         const size_t idx = lat_index(b, t + u, u, maxT, maxU, Up);
         lp2[idx] = rec;
         logz[idx] = logZ;
+        note_non_finite(poison, b, t + u, u, Up, logZ);
     }
 }
 
@@ -267,7 +296,7 @@ __global__ __launch_bounds__(256) void row_stats_block_kernel(
         const int* __restrict__ xlen, const int* __restrict__ ylen,
         LogPair<typename Tag::comp>* __restrict__ lp2, typename Tag::comp* __restrict__ logz,
         int maxT, int maxU, int Up, int A, int blank, int vec_ok, const long long* __restrict__ offsets,
-        unsigned long long total_rows, int b0) {             // packed layout: rows of the tensor (offsets are device data: never read past it); b0 = first sample of this launch
+        unsigned long long total_rows, int b0, int* __restrict__ poison) {   // packed layout: rows of the tensor (offsets are device data: never read past it); b0 = first sample of this launch; poison: note_non_finite
     using S = typename Tag::store;
     using C = typename Tag::comp;
     constexpr int V = Vec<Tag>::N;
@@ -342,6 +371,7 @@ __global__ __launch_bounds__(256) void row_stats_block_kernel(
         const size_t idx = lat_index(b, t + u, u, maxT, maxU, Up);
         lp2[idx] = rec;
         logz[idx] = logZ;
+        note_non_finite(poison, b, t + u, u, Up, logZ);
     }
 }
 
@@ -421,7 +451,7 @@ __global__ __launch_bounds__(256) void row_stats_tile_kernel(
         const int* __restrict__ xlen, const int* __restrict__ ylen,
         LogPair<typename Tag::comp>* __restrict__ lp2, typename Tag::comp* __restrict__ logz,
         unsigned long long R, int maxT, int maxU, int Up, int A, int blank, int xcd_remap,
-        const long long* __restrict__ offsets, int N) {    // offsets != nullptr: packed layout, R = offsets[N] rows
+        const long long* __restrict__ offsets, int N, int* __restrict__ poison) {    // offsets != nullptr: packed layout, R = offsets[N] rows; poison: note_non_finite
     using S = typename Tag::store;
     using C = typename Tag::comp;
     constexpr int V = Vec<Tag>::N;
@@ -600,6 +630,7 @@ __global__ __launch_bounds__(256) void row_stats_tile_kernel(
 #endif
         lp2[idx] = rec;
         logz[idx] = logZ;
+        note_non_finite(poison, b, t + u, u, Up, logZ);
     }
 }
 
@@ -619,7 +650,7 @@ __global__ __launch_bounds__(256) void row_stats_tile2d_kernel(
         const typename Tag::store* __restrict__ acts, const int* __restrict__ labels,
         const int* __restrict__ xlen, const int* __restrict__ ylen,
         LogPair<typename Tag::comp>* __restrict__ lp2, typename Tag::comp* __restrict__ logz,
-        int maxT, int maxU, int Up, int A, int blank, int N, int tilesT, int tilesU, int piece_bytes) {
+        int maxT, int maxU, int Up, int A, int blank, int N, int tilesT, int tilesU, int piece_bytes, int* __restrict__ poison) {
     using S = typename Tag::store;
     using C = typename Tag::comp;
     static_assert(TT * TU == 256, "one lane per row");
@@ -711,7 +742,9 @@ __global__ __launch_bounds__(256) void row_stats_tile2d_kernel(
         if (slot < NSLOT && j >= 0 && j < nu && i < nt) {
             const size_t idx = lat_index(b, t0 + u0 + d, u0 + j, maxT, maxU, Up);
             lp2[idx] = out_lp[i][j];
-            logz[idx] = out_lz[i][j];
+            const C lz = out_lz[i][j];
+            logz[idx] = lz;
+            note_non_finite(poison, b, t0 + u0 + d, u0 + j, Up, lz);
         }
     }
     (void)t;
@@ -858,7 +891,8 @@ __device__ __forceinline__ void lattice_body(
         const LogPair<L>* __restrict__ lp2, L* __restrict__ alpha, L* __restrict__ beta,
         double* __restrict__ offa, double* __restrict__ offb, double* __restrict__ ll_fwd,
         double* __restrict__ ll_bwd, L* __restrict__ costs_dev, const int* __restrict__ xlen,
-        const int* __restrict__ ylen, int maxT, int maxU, int Up, const int b, const int dir, const int tid, const int W) {
+        const int* __restrict__ ylen, int maxT, int maxU, int Up, const int b, const int dir, const int tid, const int W,
+        const L* __restrict__ logz, int* __restrict__ poison) {     // the statistics kernels' hint of a non-finite row: note_non_finite
     constexpr int C = LatChunk<L, MAXW, COLS>::C;
     constexpr bool MULTI = MAXW > 1;
     using IO = LatIO<L, COLS>;
@@ -906,6 +940,8 @@ __device__ __forceinline__ void lattice_body(
 
     if (dir == 0) {
         // ------------------------------- alpha -------------------------------
+        int hint = 0;                                // asked for now, looked at after the sweep
+        if (own_last) hint = poison[b];
         L a[COLS];
 #pragma unroll
         for (int c = 0; c < COLS; ++c) a[c] = (u0 + c == 0) ? L(0) : NEG;
@@ -998,7 +1034,11 @@ __device__ __forceinline__ void lattice_body(
             const L a_last = (nsteps == 0) ? L(0) : lat_load1(rb, vb1, (Db - 1 + kLatPad) * beta_row, L(0));
             const double o_last = (nsteps == 0) ? 0.0 : Cused;   // the last chunk is never re-centred
             const L xb_ = lat_clamp(lat_load1(rc, vc1, (Db - 1 + kLatPad) * cell_row, L(0)));
-            const double ll2 = static_cast<double>(a_last) + o_last + static_cast<double>(xb_);
+            double ll2 = static_cast<double>(a_last) + o_last + static_cast<double>(xb_);
+            if (hint != 0) {                                  // (never taken on a workspace this library has used before, unless a row IS non-finite)
+                poison[b] = 0;
+                if (hint_is_poison(hint, logz, sample0, Up, Tb, Ub)) ll2 = __builtin_nan("");
+            }
             ll_fwd[b] = ll2;                                  // base 2, for the coefficient kernel
             costs_dev[b] = bad_len ? cost_invalid<L>() : static_cast<L>(-ll2 * kLn2);
         }
@@ -1105,11 +1145,13 @@ __global__ __launch_bounds__(MAXW * 64) void lattice_kernel(
         const LogPair<L>* __restrict__ lp2, L* __restrict__ alpha, L* __restrict__ beta,
         double* __restrict__ offa, double* __restrict__ offb, double* __restrict__ ll_fwd,
         double* __restrict__ ll_bwd, L* __restrict__ costs_dev, const int* __restrict__ xlen,
-        const int* __restrict__ ylen, int maxT, int maxU, int Up, int dirs, int* __restrict__ padflag) {
+        const int* __restrict__ ylen, int maxT, int maxU, int Up, int dirs, int* __restrict__ padflag,
+        const L* __restrict__ logz, int* __restrict__ poison) {
     const int b = blockIdx.x / dirs;
     if (blockIdx.x == 0 && threadIdx.x == 0) *padflag = 0;     // (set again by the coefficient kernel if the batch has padding)
     lattice_body<L, MAXW, COLS>(lp2, alpha, beta, offa, offb, ll_fwd, ll_bwd, costs_dev, xlen, ylen, maxT, maxU, Up, b,
-                                static_cast<int>(blockIdx.x) - b * dirs, static_cast<int>(threadIdx.x), static_cast<int>(blockDim.x >> 6));
+                                static_cast<int>(blockIdx.x) - b * dirs, static_cast<int>(threadIdx.x), static_cast<int>(blockDim.x >> 6),
+                                logz, poison);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1168,7 +1210,8 @@ __device__ __forceinline__ void lattice_lin_body(
         LinShared& sh, const LogPair<float>* __restrict__ lp2, float* __restrict__ alpha, float* __restrict__ beta,
         double* __restrict__ offa, double* __restrict__ offb, double* __restrict__ ll_fwd,
         double* __restrict__ ll_bwd, float* __restrict__ costs_dev, const int* __restrict__ xlen,
-        const int* __restrict__ ylen, int maxT, int maxU, int Up, const int b) {
+        const int* __restrict__ ylen, int maxT, int maxU, int Up, const int b, const int force_fallback,
+        const float* __restrict__ logz, int* __restrict__ poison) {
     constexpr int C = kLinC;
     constexpr int KW = C / 3;                        // diagonals of a chunk per operand wavefront and per result wavefront
     constexpr int PFD = 8;                           // chunks of log-probs in flight per operand wavefront (96 rows ahead)
@@ -1206,8 +1249,10 @@ __device__ __forceinline__ void lattice_lin_body(
     auto diag_of = [&](int i) { return DIR == 0 ? i + 1 : Db - 2 - i; };     // the diagonal step i produces
     if (threadIdx.x == 0) sh.bad = 0;
     float x_last = 0.0f;                             // beta: log2 p(blank) of the terminal cell
+    int hint = 0;                                    // alpha: the statistics kernels' hint of a non-finite row (note_non_finite)
     if (wave == 0) {
         if (DIR == 0) {
+            hint = poison[b];
             if (lane == 0) { lat_store1(rv, 0, kLatPad * val_row, 0.0f); off[0] = 0.0; }
         } else {
             x_last = lat_clamp(lat_load1(rc, ulast * static_cast<int>(sizeof(LogPair<L>)), (Db - 1 + kLatPad) * cell_row, 0.0f));
@@ -1364,7 +1409,12 @@ __device__ __forceinline__ void lattice_lin_body(
             if (!(fin > 0.0)) sh.bad = 1;
             if (DIR == 0) {
                 const float xb = lat_clamp(lat_load1(rc, ulast * static_cast<int>(sizeof(LogPair<L>)), (Db - 1 + kLatPad) * cell_row, 0.0f));
-                const double ll2 = log2(fin) + Eo + static_cast<double>(xb);
+                double ll2 = log2(fin) + Eo + static_cast<double>(xb);
+                // (when the log-domain sweep is going to redo this (sample, direction) it reads the hint itself)
+                if (hint != 0 && (sh.bad | force_fallback) == 0) {
+                    poison[b] = 0;
+                    if (hint_is_poison(hint, logz, sample0, Up, Tb, Ub)) ll2 = __builtin_nan("");
+                }
                 ll_fwd[b] = ll2;
                 costs_dev[b] = bad_len ? cost_invalid<float>() : static_cast<float>(-ll2 * kLn2);
             } else {
@@ -1380,16 +1430,17 @@ __global__ __launch_bounds__(kLinThreads) void lattice_lin_kernel(
         const LogPair<float>* __restrict__ lp2, float* __restrict__ alpha, float* __restrict__ beta,
         double* __restrict__ offa, double* __restrict__ offb, double* __restrict__ ll_fwd,
         double* __restrict__ ll_bwd, float* __restrict__ costs_dev, const int* __restrict__ xlen,
-        const int* __restrict__ ylen, int maxT, int maxU, int Up, int dirs, int force_fallback, int* __restrict__ padflag) {
+        const int* __restrict__ ylen, int maxT, int maxU, int Up, int dirs, int force_fallback, int* __restrict__ padflag,
+        const float* __restrict__ logz, int* __restrict__ poison) {
     __shared__ LinShared sh;
     const int b = blockIdx.x / dirs;
     if (blockIdx.x == 0 && threadIdx.x == 0) *padflag = 0;     // (set again by the coefficient kernel if the batch has padding)
     const int dir = static_cast<int>(blockIdx.x) - b * dirs;
-    if (dir == 0) lattice_lin_body<0>(sh, lp2, alpha, beta, offa, offb, ll_fwd, ll_bwd, costs_dev, xlen, ylen, maxT, maxU, Up, b);
-    else lattice_lin_body<1>(sh, lp2, alpha, beta, offa, offb, ll_fwd, ll_bwd, costs_dev, xlen, ylen, maxT, maxU, Up, b);
+    if (dir == 0) lattice_lin_body<0>(sh, lp2, alpha, beta, offa, offb, ll_fwd, ll_bwd, costs_dev, xlen, ylen, maxT, maxU, Up, b, force_fallback, logz, poison);
+    else lattice_lin_body<1>(sh, lp2, alpha, beta, offa, offb, ll_fwd, ll_bwd, costs_dev, xlen, ylen, maxT, maxU, Up, b, force_fallback, logz, poison);
     if ((sh.bad | force_fallback) != 0 && threadIdx.x < 64)   // the range guard tripped (or RNNT_TUNE=latlin=2, the tests): the log-domain sweep
         lattice_body<float, 1, 1>(lp2, alpha, beta, offa, offb, ll_fwd, ll_bwd, costs_dev, xlen, ylen, maxT, maxU, Up, b, dir,
-                                  static_cast<int>(threadIdx.x), 1);
+                                  static_cast<int>(threadIdx.x), 1, logz, poison);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -72,6 +72,8 @@ EXPORTS = {
     "rnnt_host_staging": (C.c_int, [C.c_int]),
     "rnnt_host_staging_bytes": (C.c_longlong, []),
     "rnnt_host_staging_release": (C.c_longlong, []),
+    "rnnt_set_rccl_all_reduce": (None, [_PTR]),
+    "rnnt_rccl_source": (C.c_char_p, []),
     "rnnt_profile_enable": (None, [C.c_int]),
     "rnnt_profile_reset": (None, []),
     "rnnt_profile_collect": (None, []),

@@ -6,20 +6,25 @@ N>1: one rank per GPU over RCCL.  Either the driver launches the ranks itself
 (python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N: WORLD_SIZE is set and must
 equal N), or a plain `python bench.py --gpus N` re-launches itself under torch.distributed.run on
 127.0.0.1.  Fewer than N visible devices is an error (exit code 2) -- never a silent 1-GPU run.
-N=1 defaults to c3 (the headline configuration), N>1 to c5 (BASELINE config 5: bf16, 128 samples per GPU).
+N=1 defaults to c3 (the headline configuration).  N>1 defaults to BASELINE config 5 AT EVERY N: the fixed global batch
+of 1024 samples (T=200, U=41, A=1024, bf16) split N ways (512 / 256 / 128 per GPU; "scaling": "strong"); rank 0 also times
+the whole 1024-sample batch on its own GPU once, so the line carries its own speed-up.  --per-gpu-batch B keeps the weak
+form (B samples per GPU, global batch B*N).  --oversubscribe-gloo (development / single-GPU boxes) lets the ranks share the
+visible device(s) over the gloo backend so that the launcher, the per-rank gather and the rank-0-only JSON line can run
+where RCCL -- one rank per device -- cannot.
 
 A "step" = one pass of the hot path over one synthetic batch already resident in HBM:
 `compute_rnnt_loss` of include/rnnt.h with gradients (row statistics -> lattice -> coefficients
 -> gradient write-back), i.e. exactly what the reference's tests/test_time.cu times
 (compute_rnnt_loss incl. the costs D2H copy and stream sync).  With N>1 the batch is sharded
-(weak scaling: every rank gets the full per-GPU batch) and each step adds the single RCCL
-all-reduce of the summed loss; the line then carries `multi_gpu` (ranks RCCL saw, per-rank ms, the same
-per-GPU workload timed without the collective, scaling efficiency).  Every line carries `check`: two
+(contiguous slabs of samples, one per rank) and each step adds the single RCCL
+all-reduce of the summed loss; the line then carries `multi_gpu` (ranks the backend saw, per-rank ms, the same
+per-GPU shard timed without the collective, the whole global batch on one GPU, speed-up and efficiency).  Every line carries `check`: two
 samples of the timed batch against the fp64 oracle (outside the timed region; --no-verify skips it).
 
 Workloads (BASELINE.json configs; lattice U = L+1 as tests/test_time.cu:56):
   c2: N=16  T=150  L=40  A=28   fp32      c3: N=128 T=150 L=20 A=5000 fp32  (default, headline)
-  c4: N=64  T=1500 L=300 A=50   fp32      c5: N=128/GPU T=200 L=40 A=1024 bf16
+  c4: N=64  T=1500 L=300 A=50   fp32      c5: T=200 L=40 A=1024 bf16, global batch 1024 over N GPUs (one GPU: 128)
 """
 import argparse
 import ctypes as C
@@ -43,6 +48,7 @@ WORKLOADS = {
     "c4": dict(N=64, T=1500, L=300, A=50, dtype="fp32", published_ms=None),
     "c5": dict(N=128, T=200, L=40, A=1024, dtype="bf16", published_ms=None),
 }
+SHARDED_GLOBAL_BATCH = {"c5": 1024}   # BASELINE config 5: N=1024 sharded over the GPUs of one node (other workloads: their own N)
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec (MI355X_MICROARCH.md)
 TORCH_DT = {"fp32": torch.float32, "bf16": torch.bfloat16, "fp64": torch.float64, "fp16": torch.float16}
 ESIZE = {"fp32": 4, "bf16": 2, "fp64": 8, "fp16": 2}
@@ -56,7 +62,9 @@ def make_inputs(w, dev, seed):
     g.manual_seed(seed)
     N, T, L, A = w["N"], w["T"], w["L"], w["A"]
     U = L + 1
-    acts = torch.rand((N, T, U, A), generator=g, device=dev, dtype=torch.float32).to(TORCH_DT[w["dtype"]])
+    acts = torch.empty((N, T, U, A), device=dev, dtype=TORCH_DT[w["dtype"]])
+    for b0 in range(0, N, 128):        # in slabs: the fp32 draw of the whole config-5 batch would be 34 GB of temporary
+        acts[b0:b0 + 128] = torch.rand((min(128, N - b0), T, U, A), generator=g, device=dev, dtype=torch.float32).to(acts.dtype)
     lab = torch.randint(1, A, (L,), generator=g, device=dev, dtype=torch.int32)
     if L >= 3:
         lab[L // 2] = lab[L // 2 + 1]
@@ -314,8 +322,18 @@ def main():
     ap.add_argument("--torch-collective", action="store_true",
                     help="sharded step: torch.sum + torch.distributed.all_reduce instead of compute_rnnt_loss_sharded "
                          "(the library's own ncclAllReduce of [sum, count]) -- A/B runs")
+    ap.add_argument("--global-batch", type=int, default=None,
+                    help="--gpus N > 1: samples of the whole job, split N ways (default: 1024 for c5 = BASELINE config 5, "
+                         "else the workload's own N); must be a multiple of N")
+    ap.add_argument("--per-gpu-batch", type=int, default=None,
+                    help="--gpus N > 1: the WEAK-scaling form instead -- this many samples on every GPU (global batch = B*N)")
+    ap.add_argument("--oversubscribe-gloo", action="store_true",
+                    help="dev: the N ranks share the visible device(s) (rank r -> device r %% visible) and talk over gloo; "
+                         "exercises the launcher / gather / JSON plumbing on a one-GPU box.  NOT a scaling measurement")
     ap.add_argument("--force-sharded", action="store_true",
                     help="dev: run the multi-GPU step (async entry + RCCL all-reduce) even with one rank")
+    ap.add_argument("--no-full-batch", action="store_true",
+                    help="--gpus N > 1: skip rank 0's run of the whole global batch on one GPU (multi_gpu.one_gpu_full_batch_ms)")
     ap.add_argument("--no-traffic-pass", action="store_true",
                     help="do not run the two extra rocprofv3 --pmc passes that measure `roofline.traffic` for this run "
                          "(one GPU only; the figure of the newest committed profiles/r*_traffic.json is reported instead)")
@@ -332,7 +350,7 @@ def main():
         print("bench.py needs an MI355X: the HIP path has no CPU fallback", file=sys.stderr)
         raise SystemExit(2)
     ndev = torch.cuda.device_count()
-    if ndev < args.gpus:
+    if ndev < args.gpus and not args.oversubscribe_gloo:
         print("bench.py: --gpus %d asked for, %d device(s) visible -- refusing to run on fewer GPUs than requested"
               % (args.gpus, ndev), file=sys.stderr)
         raise SystemExit(2)
@@ -355,19 +373,35 @@ def main():
     if world != args.gpus:
         print("bench.py: --gpus %d but the launcher started %d rank(s)" % (args.gpus, world), file=sys.stderr)
         raise SystemExit(2)
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    gloo = args.oversubscribe_gloo and world > 1
+    dev_index = local_rank % ndev if gloo else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     sharded = world > 1 or args.force_sharded
     if sharded:
         if world == 1:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29533")
             dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+        elif gloo:
+            dist.init_process_group("gloo")                   # ranks may share a device: RCCL would refuse
         else:
             dist.init_process_group("nccl", device_id=dev)   # "nccl" is RCCL on ROCm
+    # gloo moves CUDA tensors for all_reduce / broadcast only: the bookkeeping collectives go through the host there
+    meta_dev = torch.device("cpu") if gloo else dev
+
+    def barrier():
+        torch.cuda.synchronize(dev)
+        dist.barrier()
 
     from warprnnt_pytorch import _lib, warp_rnnt
     lib = _lib.lib()
+
+    def gather_ints(v):
+        mine = torch.tensor([int(v)], dtype=torch.int64, device=meta_dev)
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        return [int(t[0]) for t in every]
 
     def run_workload(name, steps, warmup, with_cpu):
         w = dict(WORKLOADS[name])
@@ -375,6 +409,44 @@ def main():
             k, v = kv.split("=")
             w[k] = v if k == "dtype" else int(v)
             w["published_ms"] = None
+        # sharded runs: the GLOBAL batch is the workload (config 5: 1024 samples at every N), a rank holds 1/world of it;
+        # --per-gpu-batch: the weak form; one forced rank (--force-sharded): the workload's own N
+        scaling, global_batch = "weak", w["N"] * world
+        if world > 1 and args.per_gpu_batch:
+            w["N"] = args.per_gpu_batch
+            global_batch = w["N"] * world
+        elif world > 1:
+            global_batch = args.global_batch or SHARDED_GLOBAL_BATCH.get(name, w["N"])
+            if global_batch % world:
+                raise SystemExit("bench.py: global batch %d is not a multiple of %d ranks" % (global_batch, world))
+            w["N"] = global_batch // world
+            scaling = "strong"
+        # the whole global batch on ONE GPU (rank 0, before anything else is resident; the other ranks wait): what the
+        # sharded step's time is read against
+        full_ms = None
+        if world > 1 and scaling == "strong" and not args.no_full_batch:
+            if rank == 0:
+                wf = dict(w, N=global_batch)
+                fa, fl, ftl, fll = make_inputs(wf, dev, 999)
+                fg = torch.empty_like(fa)
+                fws = torch.empty(_lib.workspace_bytes(wf["T"], wf["L"] + 1, global_batch, True, ESIZE[w["dtype"]]), dtype=torch.uint8, device=dev)
+                fc = torch.zeros(global_batch, dtype=torch.float32, device=dev)
+                fopt = _lib.rnntOptions(loc=_lib.RNNT_GPU, num_threads=0, stream=torch.cuda.current_stream(dev).cuda_stream,
+                                        blank_label=0, maxT=wf["T"], maxU=wf["L"] + 1, batch_first=True)
+                fargv = (fa.data_ptr(), fg.data_ptr(), fl.data_ptr(), fll.data_ptr(), ftl.data_ptr(), wf["A"], global_batch,
+                         fc.data_ptr(), None, fws.data_ptr(), fopt, {"fp32": _lib.DT_F32, "bf16": _lib.DT_BF16}[w["dtype"]])
+                for _ in range(2):
+                    assert lib.compute_rnnt_loss_async(*fargv) == 0
+                    torch.cuda.synchronize(dev)
+                f0 = time.perf_counter()
+                nfull = max(3, min(steps, 10))
+                for _ in range(nfull):
+                    assert lib.compute_rnnt_loss_async(*fargv) == 0
+                    torch.cuda.synchronize(dev)
+                full_ms = (time.perf_counter() - f0) * 1e3 / nfull
+                del fa, fg, fws, fc, fl, ftl, fll
+                torch.cuda.empty_cache()
+            barrier()
         acts, labels, act_lens, label_lens = make_inputs(w, dev, 1234 + rank)
         N, T, U, A = acts.shape
         if args.varlen:
@@ -463,7 +535,10 @@ def main():
                 torch.sum(costs, dim=0, keepdim=True, dtype=torch.float64, out=packed)
                 return dist.all_reduce(packed, async_op=async_op)
 
-            rccl_lib, comm = (None, None) if (args.torch_collective or args.overlap_collective) else native_communicator(world, rank, dev)
+            rccl_lib, comm = (None, None) if (args.torch_collective or args.overlap_collective or gloo) else native_communicator(world, rank, dev)
+            if comm is not None:
+                # the library must call the ncclAllReduce of the RCCL copy that made `comm`: say which, do not let it guess
+                lib.rnnt_set_rccl_all_reduce(C.cast(rccl_lib.ncclAllReduce, C.c_void_p))
             pair = torch.zeros(2, dtype=torch.float64, device=dev)       # [summed loss, sample count] of the whole job
             sh_argv = (acts.data_ptr(), grads.data_ptr(), labels.data_ptr(), label_lens.data_ptr(), act_lens.data_ptr(), A, N,
                        costs.data_ptr(), None, pair.data_ptr(), comm, ws.data_ptr(), opt, code)
@@ -510,8 +585,7 @@ def main():
             for _ in range(max(warmup, 2)):
                 assert lib.compute_rnnt_loss_async(*argv) == 0
                 torch.cuda.synchronize(dev)
-            dist.barrier()
-            torch.cuda.synchronize(dev)
+            barrier()
             l0 = time.perf_counter()
             for _ in range(steps):
                 assert lib.compute_rnnt_loss_async(*argv) == 0
@@ -522,7 +596,7 @@ def main():
         lib.rnnt_profile_reset()
         lib.rnnt_profile_enable(1)
         if sharded:
-            dist.barrier()
+            barrier()
         torch.cuda.synchronize(dev)
         t0 = time.perf_counter()
         marks = []
@@ -554,32 +628,47 @@ def main():
                          note="the same steps with the per-stage HIP events switched off")
         multi = None
         if sharded:
-            mine = torch.tensor([elapsed * 1e3 / steps, local_ms], dtype=torch.float64, device=dev)
+            mine = torch.tensor([elapsed * 1e3 / steps, local_ms, float(out[0])], dtype=torch.float64, device=meta_dev)
             every = [torch.zeros_like(mine) for _ in range(world)]
             dist.all_gather(every, mine)
             per_rank = [float(t[0]) for t in every]
             per_rank_local = [float(t[1]) for t in every]
+            reduced = [float(t[2]) for t in every]                     # every rank's copy of the all-reduced loss
             elapsed = max(per_rank) * steps / 1e3                      # MAX over ranks, as the contract asks
             try:
                 rccl = ".".join(str(v) for v in torch.cuda.nccl.version())
             except Exception:                                          # noqa: BLE001 -- version query only
                 rccl = None
             multi = dict(ranks_seen=dist.get_world_size(), backend=dist.get_backend(), rccl_version=rccl,
+                         devices=sorted({int(x) for x in gather_ints(dev_index)}),
                          per_rank_ms=[round(v, 4) for v in per_rank],
                          single_gpu_same_workload_ms=round(max(per_rank_local), 4),
                          per_rank_single_gpu_ms=[round(v, 4) for v in per_rank_local],
                          scaling_efficiency=round(max(per_rank_local) / max(per_rank), 4),
+                         reduced_loss_agrees=bool(max(reduced) - min(reduced) <= 1e-9 * max(1.0, abs(reduced[0]))),
                          collective=collective,
-                         note="single_gpu_same_workload_ms = the same per-GPU batch through compute_rnnt_loss_async + "
+                         note="single_gpu_same_workload_ms = the same per-GPU shard through compute_rnnt_loss_async + "
                               "device sync with NO collective, all ranks at once (max over ranks); scaling_efficiency = "
-                              "that / value (weak scaling: 1.0 = the all-reduce and the barrier are free)")
+                              "that / value (1.0 = the all-reduce and the barrier are free)")
+            if full_ms is not None or (world > 1 and scaling == "strong" and not args.no_full_batch):
+                fm = torch.tensor([full_ms if full_ms is not None else 0.0], dtype=torch.float64, device=meta_dev)
+                dist.broadcast(fm, src=0)
+                full = float(fm[0])
+                multi.update(one_gpu_full_batch_ms=round(full, 4), speedup=round(full / max(per_rank), 4),
+                             strong_scaling_efficiency=round(full / max(per_rank) / world, 4),
+                             strong_note="one_gpu_full_batch_ms = the WHOLE global batch (%d samples) through compute_rnnt_loss_async "
+                                         "+ device sync on rank 0's GPU alone; speedup = that / value; "
+                                         "strong_scaling_efficiency = speedup / n_gpus" % global_batch)
+            if gloo:
+                multi["oversubscribed"] = ("%d ranks on %d device(s) over gloo: launcher / gather / JSON plumbing only, "
+                                           "the times are NOT a scaling measurement" % (world, ndev))
         ms_step = elapsed * 1e3 / steps
         stage = (C.c_double * 5)()
         calls = lib.rnnt_profile_read(stage, 5)
         stage_ms = [stage[i] / calls for i in range(5)] if calls else None
         valid_rows = int((act_lens.long() * (label_lens.long() + 1)).sum().item()) if args.varlen else None
         ab = algorithmic_bytes(w, valid_rows, args.packed)
-        res = dict(workload=name, ms_per_step=ms_step, stage_ms=stage_ms, bytes=ab, w=w,
+        res = dict(workload=name, ms_per_step=ms_step, stage_ms=stage_ms, bytes=ab, w=w, scaling=scaling, global_batch=global_batch,
                    step_ms=dict(median=round(float(np.median(per_step)), 4), p10=round(float(np.percentile(per_step, 10)), 4),
                                 p90=round(float(np.percentile(per_step, 90)), 4), n=int(per_step.size),
                                 note="per-step wall clock on rank 0 (each step ends in a device sync)"),
@@ -604,7 +693,7 @@ def main():
         "metric": "ms/batch RNN-T loss+grad (N,T,U,A); achieved HBM GB/s vs peak",
         "value": round(ms, 4), "unit": "ms/batch", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(ms, 4), "higher_is_better": False,
-        "scaling": "weak", "vs_baseline": (round(ms / w["published_ms"], 5) if w["published_ms"] else None),
+        "scaling": r["scaling"], "vs_baseline": (round(ms / w["published_ms"], 5) if w["published_ms"] else None),
         "dtype": {"fp32": "f32", "bf16": "bf16"}[w["dtype"]], "data": "synthetic",
         "config": {"workload": "%s: N=%d/GPU T=%d U=%d(L=%d) A=%d %s, loss+grad via compute_rnnt_loss%s"
                                % (args.workload, w["N"], w["T"], U, w["L"], w["A"], w["dtype"],
@@ -612,12 +701,12 @@ def main():
                                   + (", PACKED layout (compute_rnnt_loss_packed)" if args.packed else "")
                                   + (", host costs in pinned memory" if args.pinned_costs else "")
                                   + (", compute_rnnt_loss_async replayed from a HIP graph" if args.graph else "")),
-                   "global_batch": w["N"] * world, "per_gpu_batch": w["N"],
+                   "global_batch": r["global_batch"], "per_gpu_batch": w["N"],
                    "parallelism": "batch-sharded x%d, one RCCL all-reduce of the summed loss" % world
                    if sharded else "single GPU"},
         "check": dict({"loss_sum": r["loss_sum"], "note": "summed loss of the last step (all ranks when sharded)"},
                       **(r.get("verify") or {})),
-        "samples_per_s": round(w["N"] * world / (ms * 1e-3), 1),
+        "samples_per_s": round(r["global_batch"] / (ms * 1e-3), 1),
         "step_ms": r["step_ms"],
         "plain_step_ms": r["plain_step_ms"],
         "path_roofline": {"bound": "hbm", "achieved": round(ab["path"] / (ms * 1e-3) / 1e9, 1),

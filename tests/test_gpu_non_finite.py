@@ -203,7 +203,8 @@ def test_additive_joint(shape, bad):
             assert np.isnan(c1[1]), (dtype, which)
             # (not bit for bit here: an +inf trips the guard of the sampled row references, and the exact pass that then
             # re-runs covers the whole batch -- the other samples come out of a differently rounded, equally valid pass)
-            assert np.allclose(c1[keep], c0[keep], rtol=1e-6) and np.allclose(df1[keep], df0[keep], rtol=1e-4, atol=1e-5) \
-                and np.allclose(dg1[keep], dg0[keep], rtol=1e-4, atol=1e-5)
+            rt = 1e-4 if dtype == torch.float32 else 1.6e-2           # (bf16 gradients: two storage quanta)
+            assert np.allclose(c1[keep], c0[keep], rtol=1e-6) and np.allclose(df1[keep], df0[keep], rtol=rt, atol=rt * 0.1) \
+                and np.allclose(dg1[keep], dg0[keep], rtol=rt, atol=rt * 0.1)
             assert np.isfinite(df1[keep]).all() and np.isfinite(dg1[keep]).all()
             assert np.isnan(df1[1, :tl[1]]).any() and np.isnan(dg1[1, :ll[1] + 1]).any()

@@ -128,7 +128,37 @@ def test_bench_self_launches_two_ranks():
                          capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-2000:]
     line = json.loads(out.stdout.strip().splitlines()[-1])
-    assert line["n_gpus"] == 2 and line["config"]["global_batch"] == 256 and line["dtype"] == "bf16"
+    # BASELINE config 5 at every N: the FIXED global batch of 1024 samples, 512 per GPU here
+    assert line["n_gpus"] == 2 and line["config"]["global_batch"] == 1024 and line["config"]["per_gpu_batch"] == 512
+    assert line["dtype"] == "bf16" and line["scaling"] == "strong"
+    m = line["multi_gpu"]
+    assert m["ranks_seen"] == 2 and m["backend"] == "nccl" and len(m["per_rank_ms"]) == 2 and m["devices"] == [0, 1]
+    assert m["one_gpu_full_batch_ms"] > 0 and m["speedup"] > 1.0 and m["reduced_loss_agrees"]
+
+
+def test_bench_two_ranks_on_one_gpu():
+    """`bench.py --gpus 2 --oversubscribe-gloo` on whatever devices there are (a one-GPU box: both ranks on cuda:0, gloo
+    instead of RCCL, which refuses two ranks on one device): the self-launcher, the shard sizes of the fixed global
+    batch, rank 0's whole-batch run, the per-rank gather and the rank-0-only JSON line all run with world_size 2."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--oversubscribe-gloo", "--global-batch", "64",
+                          "--steps", "4", "--warmup", "1"], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    assert len(out.stdout.strip().splitlines()) == 1, out.stdout[:600]          # ONE line, from rank 0 only
+    line = json.loads(out.stdout.strip())
+    assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["dtype"] == "bf16"
+    assert line["config"]["global_batch"] == 64 and line["config"]["per_gpu_batch"] == 32 and "c5" in line["config"]["workload"]
+    m = line["multi_gpu"]
+    assert m["ranks_seen"] == 2 and m["backend"] == "gloo" and len(m["per_rank_ms"]) == 2 and len(m["per_rank_single_gpu_ms"]) == 2
+    assert "oversubscribed" in m and m["reduced_loss_agrees"]
+    assert m["one_gpu_full_batch_ms"] > 0 and m["speedup"] > 0 and abs(m["strong_scaling_efficiency"] - m["speedup"] / 2) < 1e-3
+    assert abs(max(m["per_rank_ms"]) - line["value"]) <= 1e-3 * line["value"]
+    assert line["check"]["passed"], line["check"]
+    # the weak form is still there
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--oversubscribe-gloo", "--per-gpu-batch", "16",
+                          "--steps", "2", "--warmup", "1", "--no-verify"], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = json.loads(out.stdout.strip())
+    assert line["scaling"] == "weak" and line["config"]["global_batch"] == 32 and "one_gpu_full_batch_ms" not in line["multi_gpu"]
 
 
 def test_bench_sharded_step_on_one_rank():
@@ -217,6 +247,25 @@ def _sharded_call(acts, labels, tl, ll, comm):
     return costs, grads, pair
 
 
+def test_which_rccl_the_library_calls():
+    """compute_rnnt_loss_sharded must call the ncclAllReduce of the RCCL copy that made the communicator.  Unregistered it
+    takes the ONE librccl mapped into the process (here: the one PyTorch loaded) and says so; a registered pointer wins;
+    NULL forgets it again."""
+    from warprnnt_pytorch import _lib
+    lib = _lib.lib()
+    rccl = _rccl()
+    lib.rnnt_set_rccl_all_reduce(None)
+    src = lib.rnnt_rccl_source().decode()
+    assert "librccl" in src, src
+    import re
+    mapped = {os.path.realpath(m.group(0)) for m in re.finditer(r"/\S*librccl\.so\S*", open("/proc/self/maps").read())}
+    assert len(mapped) == 1 and os.path.realpath(src) in mapped, (src, mapped)      # the copy this process already holds
+    lib.rnnt_set_rccl_all_reduce(C.cast(rccl.ncclAllReduce, C.c_void_p))
+    assert lib.rnnt_rccl_source() == b"registered by the caller"
+    lib.rnnt_set_rccl_all_reduce(None)
+    assert lib.rnnt_rccl_source().decode() == src
+
+
 def test_native_sharded_entry_on_one_rank():
     """compute_rnnt_loss_sharded without a communicator (the local [sum, count] pair) and over a ONE-rank RCCL communicator
     created here (a 1-GPU box can run that): costs and gradients of compute_rnnt_loss_async, pair = [sum of the costs in
@@ -245,6 +294,24 @@ def test_native_sharded_entry_on_one_rank():
     opt = _lib.rnntOptions(loc=1, num_threads=0, stream=None, blank_label=0, maxT=acts.shape[1], maxU=acts.shape[2], batch_first=True)
     assert lib.compute_rnnt_loss_sharded(acts.data_ptr(), None, labels.data_ptr(), ll.data_ptr(), tl.data_ptr(), acts.shape[3],
                                          acts.shape[0], costs.data_ptr(), None, None, None, costs.data_ptr(), opt, 0) == 2
+    # ALL RANKS OR NONE: a rank whose own part fails (here: a blank label outside the vocabulary) still joins the collective,
+    # with a NaN pair, and returns its own status -- its peers are not left waiting in ncclAllReduce
+    uid = _NcclUniqueId()
+    assert rccl.ncclGetUniqueId(C.byref(uid)) == 0
+    comm = C.c_void_p()
+    assert rccl.ncclCommInitRank(C.byref(comm), 1, uid, 0) == 0
+    try:
+        bad = _lib.rnntOptions(loc=1, num_threads=0, stream=torch.cuda.current_stream(dev).cuda_stream, blank_label=10 ** 6,
+                               maxT=acts.shape[1], maxU=acts.shape[2], batch_first=True)
+        pair3 = torch.zeros(2, dtype=torch.float64, device=dev)
+        ws = torch.empty(_lib.workspace_bytes(acts.shape[1], acts.shape[2], acts.shape[0], True, 4), dtype=torch.uint8, device=dev)
+        st = lib.compute_rnnt_loss_sharded(acts.data_ptr(), grads.data_ptr(), labels.data_ptr(), ll.data_ptr(), tl.data_ptr(),
+                                           acts.shape[3], acts.shape[0], costs.data_ptr(), None, pair3.data_ptr(), comm,
+                                           ws.data_ptr(), bad, 0)
+        torch.cuda.synchronize(dev)
+        assert st == 2 and torch.isnan(pair3).all()
+    finally:
+        rccl.ncclCommDestroy(comm)
 
 
 def _native_worker(rank, world, uid_bytes, q):

@@ -1731,15 +1731,38 @@ __global__ __launch_bounds__(256) void fill_row_scale_kernel(
 // here, so no memset of the gradient tensor exists (the reference does one: gpu_rnnt.h:107-110).
 // Measured on MI355X (tools/microbench/stream_variants.hip): this structure sustains
 // 6.4-6.5 TB/s read+write with the exp included, the wavefront-per-row form 5.1 TB/s.
-template <typename Tag, int SCALE, int PPT, int PADSKIP>   // SCALE: 0 none, 1 per sample (padded layout), 2 per row (packed); PPT = packets per thread and iteration;
+// FUSED form (short rows under large lattices, c4): no coefficient kernel and no record table in HBM.  A chunk of the
+// stream covers a few dozen consecutive rows of (mostly) one time step; the block first REQUESTS ITS PACKETS, then its
+// first threads build the records of exactly those rows -- coef_fetch / coef_eval, the coefficient kernels' own code, so
+// the gradients are bit for bit the unfused ones -- from the skewed lattice arrays into LDS, and the packet code reads
+// them from there.  What that removes on c4: the 16-byte record per cell written once and read once (0.92 GB) and a
+// 0.27 ms kernel; what it costs: the lattice operands of a natural row lie on consecutive anti-diagonals, i.e. six
+// scattered 4-byte loads per cell (they share their lines with the rows of the neighbouring time steps, which the SAME
+// XCD streams a few hundred chunks later: block i runs on XCD i % 8 and takes chunk (i % 8) * per + i / 8, so every
+// XCD walks one contiguous eighth of the tensor and the lines are fetched from HBM once).  Everything a record needs:
+template <typename L> struct FuseArgs {
+    const LogPair<L>* lp2; const L* logz; const L* alpha; const L* beta;
+    const double* offa; const double* offb; const double* ll_fwd;
+    const int* labels; const int* xlen; const int* ylen;
+    int maxT, maxU, Up, lw, lsh;
+    float fastemit;
+};
+// rows a chunk of CH elements can touch (A >= kFuseMinRowElems(CH) keeps it within one row per thread)
+constexpr int kFuseMaxRows = 258;
+
+template <typename Tag, int SCALE, int PPT, int PADSKIP, bool FUSED = false>   // SCALE: 0 none, 1 per sample (padded layout), 2 per row (packed); PPT = packets per thread and iteration;
                                                             // PADSKIP: the logits of padded rows are not read -- 0 never, 1 always, 2 when the batch has padding (padflag)
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(typename Tag::comp) == 8 ? 1 : 8))) void grad_flat_kernel(
         const typename Tag::store* __restrict__ acts, typename Tag::store* __restrict__ grads,
         const Cell<typename Tag::comp>* __restrict__ rowtab, const typename Tag::comp* __restrict__ grad_scale,
         unsigned long long E, unsigned long long R, int A, int blank, int TU, float invA,
-        unsigned long long dq, int drem, const typename Tag::comp* __restrict__ rowscale, const int* __restrict__ padflag) {
+        unsigned long long dq, int drem, const typename Tag::comp* __restrict__ rowscale, const int* __restrict__ padflag,
+        const FuseArgs<typename Tag::comp> fa) {
     using C = typename Tag::comp;
     constexpr bool SCALED = SCALE != 0;
+    static_assert(!FUSED || (PADSKIP == 0 && SCALE != 2), "the fused form serves the padded layout, packets always read");
+    __shared__ Cell<C> recs[FUSED ? kFuseMaxRows + 2 : 1];
+    (void)recs;
     // Short rows (PADSKIP == 2): testing the record before the load is a dependent memory latency per block and costs a
     // batch WITHOUT padding 7 % (2 KB rows); whether there is any padding is one word the coefficient kernel has left
     // behind -- a scalar load that is back before the index arithmetic below is through.
@@ -1754,6 +1777,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(type
     u32x4* out = reinterpret_cast<u32x4*>(grads);
 
     unsigned long long c = blockIdx.x;
+    if constexpr (FUSED) {
+        // one chunk per block (host: grid = chunks rounded up to 8), XCD-contiguous order
+        const unsigned long long per = gridDim.x >> 3;
+        c = static_cast<unsigned long long>(blockIdx.x & 7u) * per + (blockIdx.x >> 3);
+        if (c >= nchunks) return;
+    }
     unsigned long long r = (c * CH) / static_cast<unsigned>(A);                   // row of the chunk start
     int rem = static_cast<int>((c * CH) - r * static_cast<unsigned>(A));          // offset inside it
 
@@ -1791,8 +1820,40 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(type
         return g;
     };
 
+    // FUSED: the record of one row, as the coefficient kernels compute it (b, q = the row's sample and its cell index in it)
+    auto make_record = [&](int b, unsigned q) -> Cell<C> {
+        const int t = static_cast<int>(q / static_cast<unsigned>(fa.maxU)), u = static_cast<int>(q) - t * fa.maxU;
+        int Tb, Ub;
+        coef_lens(fa.xlen, fa.ylen, b, fa.maxT, fa.maxU, Tb, Ub);
+        const CoefRaw<C> raw = coef_fetch<C>(fa.lp2, fa.logz, fa.alpha, fa.beta, fa.offa, fa.offb, fa.labels, b, t + u, u,
+                                             fa.maxT, fa.maxU, fa.Up, fa.lw, fa.lsh, -1);
+        return coef_eval<C>(raw, fa.ll_fwd[b], t, u, Tb, Ub, fa.fastemit);
+    };
+
     for (; c < nchunks; c += gridDim.x) {
         const unsigned long long pk0 = c * kChunkPackets;
+        uint4 raw[PPT];
+        if constexpr (FUSED) {
+            // the chunk's packets go out FIRST: the records' operands then travel beside them, not in front of them
+#pragma unroll
+            for (int k = 0; k < PPT; ++k) {
+                const int p = k * 256 + threadIdx.x;
+                if (pk0 + p < npk) raw[k] = load_packet<true>(in + pk0 + p);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            const unsigned long long last_e = (c * CH + CH < npk * V ? c * CH + CH : npk * V) - 1;   // last element of the chunk
+            const int nrows = static_cast<int>((static_cast<unsigned>(rem) + static_cast<unsigned>(last_e - c * CH)) / static_cast<unsigned>(A)) + 1;
+            // sample and cell of the chunk's first row (block-uniform), then one row per thread
+            const unsigned long long b0 = (R <= 0xffffffffull) ? static_cast<unsigned>(r) / static_cast<unsigned>(TU) : r / static_cast<unsigned>(TU);
+            const unsigned q0 = static_cast<unsigned>(r - b0 * static_cast<unsigned>(TU));
+            if (static_cast<int>(threadIdx.x) < nrows && r + threadIdx.x < R) {
+                int b = static_cast<int>(b0);
+                unsigned q = q0 + threadIdx.x;
+                while (q >= static_cast<unsigned>(TU)) { q -= static_cast<unsigned>(TU); ++b; }
+                recs[threadIdx.x] = make_record(b, q);
+            }
+            __syncthreads();
+        }
         if constexpr (SCALE == 1) {
             {                                               // padded layout: sample = row / (maxT*maxU)
                 const unsigned long long rl0 = r + static_cast<unsigned>(CH / A + 1);
@@ -1819,7 +1880,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(type
                         const unsigned long long rw = r + q;
                         unsigned long long sb = b0, next = (b0 + 1) * static_cast<unsigned>(TU);
                         while (rw >= next) { ++sb; next += static_cast<unsigned>(TU); }
-                        store1<Tag>(grads + e0 + i, elem(rowtab[rw], pos, load1<Tag>(acts + e0 + i), grad_scale[sb]));
+                        const Cell<C> rc = FUSED ? recs[static_cast<unsigned>(rw - r)] : rowtab[rw];
+                        store1<Tag>(grads + e0 + i, elem(rc, pos, load1<Tag>(acts + e0 + i), grad_scale[sb]));
                     }
                     r += dq;
                     rem += drem;
@@ -1828,7 +1890,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(type
                 }
             }
         }
-        uint4 raw[PPT];
         Cell<C> rec[PPT], rec2[PPT];                        // rec2: the NEXT row's record, for packets that straddle
         int v0[PPT];
         unsigned long long row[PPT];
@@ -1843,7 +1904,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(type
             if (rr < 0) { rr += A; --q; } else if (rr >= A) { rr -= A; ++q; }
             v0[k] = rr;
             row[k] = r + q;
-            if (live[k]) {
+            if constexpr (FUSED) {
+                if (live[k]) {
+                    rec[k] = recs[q];
+                    if (rr + V > A) rec2[k] = recs[q + 1];     // (the next row holds the packet's last element: it is one of the chunk's rows)
+                }
+            } else if (live[k]) {
                 rec[k] = rowtab[row[k]];
                 if (PADSKIP == 0 || !ps) raw[k] = load_packet<true>(in + pk0 + p);
                 // a packet that crosses into the next row (A % V != 0) needs that row's record too: asked
@@ -1916,7 +1982,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(type
                         while (pos >= A) {
                             pos -= A;
                             ++rw;
-                            if (rw < R) cur = rowtab[rw];
+                            if (rw < R) cur = FUSED ? recs[static_cast<unsigned>(rw - r)] : rowtab[rw];
                             gs = scale_of(rw < R ? rw : R - 1);
                         }
                         v[j] = elem(cur, pos, v[j], gs);
@@ -1926,6 +1992,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(type
             }
             store_packet<true>(out + pk0 + p, pack<Tag>(v));
         }
+        if constexpr (FUSED) break;                         // one chunk per block (recs is not double-buffered)
         r += dq;
         rem += drem;
         if (rem >= A) { rem -= A; ++r; }
@@ -1939,7 +2006,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(type
             C gs = C(1);
             if constexpr (SCALE == 2) gs = rowscale[rw];
             else if constexpr (SCALE == 1) gs = sample_scale(rw);
-            store1<Tag>(grads + e, elem(rowtab[rw], pos, load1<Tag>(acts + e), gs));
+            Cell<C> rc;
+            if constexpr (FUSED) { const unsigned long long bb = rw / static_cast<unsigned>(TU); rc = make_record(static_cast<int>(bb), static_cast<unsigned>(rw - bb * static_cast<unsigned>(TU))); }
+            else rc = rowtab[rw];
+            store1<Tag>(grads + e, elem(rc, pos, load1<Tag>(acts + e), gs));
         }
     }
 }

@@ -90,6 +90,19 @@ def algorithmic_bytes(w, valid_rows=None, packed=False):
                 stats_kernel=Ev * s + 16 * Rv)
 
 
+def cpu_model():
+    """The host CPU's model string (core count AND model stated next to the CPU baseline)."""
+    try:
+        names = [l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.lower().startswith("model name")]
+        if names:
+            sockets = len({l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.lower().startswith("physical id")}) or 1
+            return "%s (%d logical CPUs, %d socket(s))" % (names[0], len(names), sockets)
+    except OSError:
+        pass
+    import platform
+    return platform.processor() or platform.machine() or "unknown"
+
+
 def cpu_baseline(w, acts, labels, act_lens, label_lens, budget_samples):
     """The REFERENCE's own CPU path (oracle/_ref, compiled from /root/reference) on the host
     cores of this box, on a bounded sample of the same workload (last row).  Three legs:
@@ -145,7 +158,7 @@ def cpu_baseline(w, acts, labels, act_lens, label_lens, budget_samples):
         return xx.grad
     ms_full = timed(full, reps=2) * (N / n2)
     shape = "T=%d,U=%d,A=%d" % (w["T"], w["L"] + 1, w["A"])
-    return dict(value=round(ms_all, 3), unit="ms/batch", cores=threads, kind=kind,
+    return dict(value=round(ms_all, 3), unit="ms/batch", cores=threads, cpu_model=cpu_model(), kind=kind,
                 sample="%d of %d samples (%s, fp32 log-probs in, sparse log-prob grads out), "
                        "median of 3 warmed calls, scaled x%.2f to the full batch; host has %d cores"
                        % (n, N, shape, N / n, cores),

@@ -34,8 +34,10 @@ static void launch_row_stats(Plan<typename Tag::comp>& p, const typename Tag::st
     const Tune& tn = tune();
     const size_t row_bytes = static_cast<size_t>(p.A) * sizeof(S);
     // short rows under a wide lattice (c4): 2-D cell tiles, results stored along the anti-diagonals
-    if (tn.tile2d && p.offsets == nullptr && row_bytes % 8 == 0 && (reinterpret_cast<uintptr_t>(acts) & 7u) == 0 &&
-        row_bytes <= 208 && p.maxU >= 64) {
+    // (the kernel loads the aligned 16-byte packets that COVER a piece of rows: with the tensor's first and last byte on
+    // 16-byte boundaries no packet reaches outside it, whatever phase the pieces inside have)
+    if (tn.tile2d && p.offsets == nullptr && row_bytes % 8 == 0 && (reinterpret_cast<uintptr_t>(acts) & 15u) == 0 &&
+        (static_cast<unsigned long long>(p.N) * p.cells_per_sample * row_bytes) % 16 == 0 && row_bytes <= 208 && p.maxU >= 64) {
         // tile shape: 8 x 32 (64-byte runs along the anti-diagonals, pieces of 32 rows) | 16 x 16 (128-byte runs, pieces of 16 rows)
         const bool sq = tn.tile2d == 2;
         const int TT = sq ? 16 : 8, TU = sq ? 16 : 32;
@@ -124,10 +126,31 @@ static void launch_row_stats(Plan<typename Tag::comp>& p, const typename Tag::st
     p.check();
 }
 
+// Short rows under large lattices: the gradient kernel builds the records of its chunk itself (grad_flat_kernel, FUSED)
+// and the coefficient kernel does not run.  A function of the problem's shape and element type alone, so that the two
+// halves of a two-phase step (compute_rnnt_loss_fwd / _bwd) agree; padded layout only.  Rows up to kFuseRowBytes: a
+// chunk then holds >= 32 rows (the scattered operand loads are shared by many packets); lattices from kFuseMinCells on:
+// below, the coefficient kernel is a few microseconds and the dependent operand fetch in front of every block's packet
+// code costs more than it saves (measured on c2 in round 2: +3..7 %).
+constexpr size_t kFuseRowBytes = 256;
+constexpr unsigned long long kFuseMinCells = 1ull << 20;
+template <typename Tag> static bool fused_shape(const Plan<typename Tag::comp>& p) {
+    using S = typename Tag::store;
+    constexpr int V = Vec<Tag>::N;
+    const Tune& tn = tune();
+    if (!tn.fuse || p.offsets != nullptr) return false;
+    const size_t row_bytes = static_cast<size_t>(p.A) * sizeof(S);
+    const unsigned long long R = static_cast<unsigned long long>(p.N) * p.cells_per_sample;
+    const size_t maxrow = tn.fuse > 1 ? static_cast<size_t>(tn.fuse) : kFuseRowBytes;     // (dev build: fuse=<row bytes>)
+    const unsigned long long mincells = tn.fusemin >= 0 ? static_cast<unsigned long long>(tn.fusemin) : kFuseMinCells;
+    // one row per thread: a chunk of 512 packets touches at most 512 V / A + 2 rows
+    return row_bytes <= maxrow && R >= mincells && 512 * V / p.A + 2 <= kFuseMaxRows && p.A >= V;
+}
+
 // Stage 4 (materialised path): dense gradient write-back.
 template <typename Tag>
 static void launch_grad(Plan<typename Tag::comp>& p, const typename Tag::store* acts, typename Tag::store* grads,
-                        const typename Tag::comp* grad_scale, int vec_ok) {
+                        const typename Tag::comp* grad_scale, int vec_ok, bool may_fuse) {
     using S = typename Tag::store;
     constexpr int V = Vec<Tag>::N;
     const Tune& tn = tune();
@@ -138,7 +161,24 @@ static void launch_grad(Plan<typename Tag::comp>& p, const typename Tag::store* 
     const unsigned long long E = R * p.A;
     const bool flat_ok = vec_ok && (pa & 15u) == 0 && (pg & 15u) == 0 && p.A <= (1 << 23) && (!tn.rows || packed);
     if (packed && !flat_ok) { p.failed = true; return; }   // (run_gpu has validated the alignment: not reached)
-    if (flat_ok) {
+    const bool fused = may_fuse && fused_shape<Tag>(p);
+    if (fused && !flat_ok) launch_coef(p);                 // (tensors that cannot be streamed as packets: the records after all)
+    if (fused && flat_ok) {
+        using CC = typename Tag::comp;
+        const unsigned long long cpk = 512;                // PPT = 2
+        const unsigned long long nchunks = (E / V + cpk - 1) / cpk;
+        if (nchunks + 8 > 0x7fffffffull) { p.failed = true; return; }      // (2^31 chunks = 16 TB of fp32: not reachable)
+        const unsigned grid = static_cast<unsigned>((nchunks + 7) / 8 * 8);   // XCD-contiguous chunk order wants a multiple of 8
+        const FuseArgs<CC> fa{p.lp2, p.logz, p.alpha, p.beta, p.offa, p.offb, p.llf, p.labels, p.input_lengths, p.label_lengths,
+                              p.maxT, p.maxU, p.Up, p.lat_w, p.lat_sh, p.fastemit, tn.fdev};
+        const float invA = 1.0f / static_cast<float>(p.A);
+        if (grad_scale)
+            hipLaunchKernelGGL((grad_flat_kernel<Tag, 1, 2, 0, true>), dim3(grid), dim3(256), 0, p.stream, acts, grads, p.rowtab, grad_scale,
+                               E, R, p.A, p.blank, p.cells_per_sample, invA, 0ull, 0, static_cast<const CC*>(nullptr), p.padflag, fa);
+        else
+            hipLaunchKernelGGL((grad_flat_kernel<Tag, 0, 2, 0, true>), dim3(grid), dim3(256), 0, p.stream, acts, grads, p.rowtab, grad_scale,
+                               E, R, p.A, p.blank, p.cells_per_sample, invA, 0ull, 0, static_cast<const CC*>(nullptr), p.padflag, fa);
+    } else if (flat_ok) {
         const unsigned long long npk = E / V;
 #ifdef RNNT_DEV
         const int ppt = (tn.ppt == 1 || tn.ppt == 4) ? tn.ppt : 2;
@@ -163,7 +203,8 @@ static void launch_grad(Plan<typename Tag::comp>& p, const typename Tag::store* 
         }
 #define RNNT_FLAT(SC, PP, PS)                                                                                       \
     hipLaunchKernelGGL((grad_flat_kernel<Tag, SC, PP, PS>), dim3(grid), dim3(256), 0, p.stream, acts, grads,        \
-                       p.rowtab, grad_scale, E, R, p.A, p.blank, p.cells_per_sample, invA, dq, drem, rowscale, p.padflag)
+                       p.rowtab, grad_scale, E, R, p.A, p.blank, p.cells_per_sample, invA, dq, drem, rowscale, p.padflag,  \
+                       FuseArgs<typename Tag::comp>{})
         // padded rows are not read: always for long rows (the record is asked for first), for shorter ones when the
         // coefficient kernel has seen padding in this batch (packed layout: there are no padded rows)
         const int padskip = (!tn.pskip || packed) ? 0 : row_bytes >= static_cast<size_t>(tn.pskipb) ? 1
@@ -322,8 +363,8 @@ static rnntStatus_t run_gpu(const typename Tag::store* acts, typename Tag::store
         return RNNT_STATUS_INVALID_VALUE;
 
     std::unique_lock<std::mutex> prof_lock;
-    if (g_prof.on) prof_lock = std::unique_lock<std::mutex>(g_prof_mu);
-    const bool prof = prof_prepare();
+    if (g_prof.on.load(std::memory_order_relaxed)) prof_lock = std::unique_lock<std::mutex>(g_prof_mu);
+    const bool prof = prof_prepare(prof_lock.owns_lock());
     const bool ranges = ranges_prepare();
     static const char* const kStages[4] = {"warprnnt:row_stats", "warprnnt:lattice", "warprnnt:coefficients", "warprnnt:gradient"};
     auto mark = [&](int i) {
@@ -336,9 +377,12 @@ static rnntStatus_t run_gpu(const typename Tag::store* acts, typename Tag::store
     mark(1);
     if (do_fwd) launch_lattice(p, training);
     mark(2);
-    if (do_fwd && training) launch_coef(p);
+    // the fused gradient kernel needs the labels and the lengths: a one-call entry has them, the backward half of a
+    // two-phase step (compute_rnnt_loss_bwd) does not -- that pair keeps the record table
+    const bool may_fuse = do_fwd && do_bwd;
+    if (do_fwd && training && !(may_fuse && fused_shape<Tag>(p))) launch_coef(p);      // (fused: the gradient kernel builds its records itself)
     mark(3);
-    if (do_bwd) launch_grad<Tag>(p, acts, grads, grad_scale, vec_ok);
+    if (do_bwd) launch_grad<Tag>(p, acts, grads, grad_scale, vec_ok, may_fuse);
     mark(4);
     if (p.failed) return RNNT_STATUS_EXECUTION_FAILED;
 

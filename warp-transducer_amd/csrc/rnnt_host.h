@@ -73,7 +73,7 @@ static Layout make_layout(int maxT, int maxU, int N, size_t lat, bool joint) {
 // enqueues between the two calls is in neither stage.  One rnnt_profile_collect() reads what has been recorded since
 // the last one as ONE step.
 struct Profile {
-    bool on = false;
+    std::atomic<bool> on{false};   // read without the mutex to decide whether to take it; everything else below is guarded by g_prof_mu
     bool ready = false;
     hipEvent_t ev[6];
     double ms[5] = {0, 0, 0, 0, 0};   // statistics, lattice, coefficients, gradient, first event to last
@@ -86,8 +86,9 @@ extern std::mutex g_prof_mu;   // held by a profiled call from its first event r
                                // rnnt_profile_* entries: concurrent callers cannot tear the shared event set (their
                                // calls are serialised while the timers are on; off -- the default -- nobody takes it)
 
-static bool prof_prepare() {
-    if (!g_prof.on) return false;
+// `locked`: the caller holds g_prof_mu (it took it because it saw `on`); without the lock nothing of the shared event set is touched
+static bool prof_prepare(bool locked) {
+    if (!locked || !g_prof.on.load(std::memory_order_relaxed)) return false;   // (switched off between the caller's test and its lock: a plain, unprofiled call)
     if (!g_prof.ready) {
         for (auto& e : g_prof.ev)
             if (hipEventCreate(&e) != hipSuccess) return false;
@@ -127,30 +128,31 @@ static inline void prof_accumulate() {
 // timeline as the kernels.  The marker library is looked up at run time (librocprofiler-sdk-roctx, else libroctx64):
 // the library does not link against a profiler, and without one the switch does nothing.
 struct Ranges {
-    int mode = -1;                 // -1: not decided (environment), 0 off, 1 on
-    bool tried = false;
+    std::atomic<int> mode{-1};     // -1: not decided (environment), 0 off, 1 on
+    std::once_flag resolved;       // the two entry points below are written once, inside call_once, and only read afterwards
     int (*push)(const char*) = nullptr;
     int (*pop)() = nullptr;
 };
 extern Ranges g_ranges;            // one instance for the library (defined in rnnt_gpu.hip)
 
 static bool ranges_prepare() {
-    if (g_ranges.mode < 0) {
+    int mode = g_ranges.mode.load(std::memory_order_relaxed);
+    if (mode < 0) {
         const char* e = getenv("WARPRNNT_ROCTX");
-        g_ranges.mode = (e != nullptr && atoi(e) > 0) ? 1 : 0;
+        int expected = -1;
+        mode = (e != nullptr && atoi(e) > 0) ? 1 : 0;
+        if (!g_ranges.mode.compare_exchange_strong(expected, mode, std::memory_order_relaxed)) mode = expected;   // (rnnt_profile_enable got there first)
     }
-    if (g_ranges.mode != 1) return false;
-    if (!g_ranges.tried) {
-        g_ranges.tried = true;
+    if (mode != 1) return false;
+    std::call_once(g_ranges.resolved, [] {          // concurrent first calls: one resolves, the others wait; both pointers or neither
         for (const char* name : {"librocprofiler-sdk-roctx.so.1", "librocprofiler-sdk-roctx.so", "libroctx64.so.4", "libroctx64.so"}) {
             void* h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
             if (h == nullptr) continue;
-            g_ranges.push = reinterpret_cast<int (*)(const char*)>(dlsym(h, "roctxRangePushA"));
-            g_ranges.pop = reinterpret_cast<int (*)()>(dlsym(h, "roctxRangePop"));
-            if (g_ranges.push != nullptr && g_ranges.pop != nullptr) break;
-            g_ranges.push = nullptr; g_ranges.pop = nullptr;
+            auto push = reinterpret_cast<int (*)(const char*)>(dlsym(h, "roctxRangePushA"));
+            auto pop = reinterpret_cast<int (*)()>(dlsym(h, "roctxRangePop"));
+            if (push != nullptr && pop != nullptr) { g_ranges.push = push; g_ranges.pop = pop; break; }
         }
-    }
+    });
     return g_ranges.push != nullptr;
 }
 
@@ -178,10 +180,12 @@ static void ranges_mark(int i, bool do_fwd, bool do_bwd, const char* const names
 // j16 = bf16 storage on the bf16 matrix cores (rnnt_joint16_kernels.h), bit 0 DG, bit 1 DF, bit 2 Z; j16pf = operand ping-pong there, j16nt = columns per lane of its DF / DG (8 | 4),
 // latlin = linear-domain lattice kernel (chain + helper wavefronts) for one-wavefront fp32 lattices: 0 off, 1 up to one block per CU,
 //          2 at any size and every block takes the log-domain fallback (tests), 3 at any size,
-// tile2d = 2-D cell-tile statistics kernel for short rows under wide lattices on/off.
+// tile2d = 2-D cell-tile statistics kernel for short rows under wide lattices on/off,
+// fuse = the gradient kernel builds its chunk's records itself, no coefficient kernel: 0 off, 1 rows <= 256 bytes, n > 1 rows <= n bytes;
+//        fusemin = lattice cells from which on (-1: 2^20).
 struct Tune { int sw = 4, nta = 1, gmax = 4194304, rows = 0, tile = 1, tilekb = 52, ppt = 2;
               int jfnk = 0, jfpf = 1, jgnk = 0, jgpf = 1, blk = 1, jzs = 0, xcd = 1, ctile = 1, pskip = 1, joh = -1;
-              int lat2 = -1, xst = 0, jsamp = 1, tilemax = kTileMaxRowBytes, j16 = 7, j16pf = 1, j16nt = 4, tile2d = 1, latlin = 1, pskipb = 8192, pskipmin = 2048; };
+              int lat2 = -1, xst = 0, jsamp = 1, tilemax = kTileMaxRowBytes, j16 = 7, j16pf = 1, j16nt = 4, tile2d = 1, latlin = 1, pskipb = 8192, pskipmin = 2048, fuse = 0, fusemin = -1, fdev = 0; };
 #ifdef RNNT_DEV
 static Tune read_tune() {
     Tune t;
@@ -192,7 +196,7 @@ static Tune read_tune() {
         {"tilekb", &t.tilekb}, {"ppt", &t.ppt}, {"jfnk", &t.jfnk}, {"jfpf", &t.jfpf}, {"jgnk", &t.jgnk},
         {"jgpf", &t.jgpf}, {"blk", &t.blk}, {"jzs", &t.jzs}, {"xcd", &t.xcd}, {"ctile", &t.ctile},
         {"pskip", &t.pskip}, {"joh", &t.joh}, {"lat2", &t.lat2}, {"xst", &t.xst}, {"jsamp", &t.jsamp}, {"tilemax", &t.tilemax},
-        {"j16", &t.j16}, {"j16pf", &t.j16pf}, {"j16nt", &t.j16nt}, {"tile2d", &t.tile2d}, {"latlin", &t.latlin}, {"pskipb", &t.pskipb}, {"pskipmin", &t.pskipmin}};
+        {"j16", &t.j16}, {"j16pf", &t.j16pf}, {"j16nt", &t.j16nt}, {"tile2d", &t.tile2d}, {"latlin", &t.latlin}, {"pskipb", &t.pskipb}, {"pskipmin", &t.pskipmin}, {"fuse", &t.fuse}, {"fusemin", &t.fusemin}, {"fdev", &t.fdev}};
     // tokens are separated by ',', a token is key=value with the WHOLE key compared
     for (const char* p = e; *p;) {
         const char* end = strchr(p, ',');

@@ -44,8 +44,8 @@ static rnntStatus_t run_gpu_joint(const typename Tag::store* f, const typename T
         return RNNT_STATUS_INVALID_VALUE;
     const bool training = want_grad;
     std::unique_lock<std::mutex> prof_lock;
-    if (g_prof.on) prof_lock = std::unique_lock<std::mutex>(g_prof_mu);
-    const bool prof = prof_prepare();
+    if (g_prof.on.load(std::memory_order_relaxed)) prof_lock = std::unique_lock<std::mutex>(g_prof_mu);
+    const bool prof = prof_prepare(prof_lock.owns_lock());
     const bool ranges = ranges_prepare();
     static const char* const kStages[4] = {"warprnnt:joint_partition", "warprnnt:lattice", "warprnnt:coefficients",
                                            "warprnnt:joint_gradients"};

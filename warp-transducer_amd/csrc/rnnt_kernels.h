@@ -1746,6 +1746,7 @@ template <typename L> struct FuseArgs {
     const int* labels; const int* xlen; const int* ylen;
     int maxT, maxU, Up, lw, lsh;
     float fastemit;
+    int dev;          // development build only (RNNT_TUNE=fdev=..): bit 0 launch-order chunks, bit 1 records without their operands (timing only, results WRONG)
 };
 // rows a chunk of CH elements can touch (A >= kFuseMinRowElems(CH) keeps it within one row per thread)
 constexpr int kFuseMaxRows = 258;
@@ -1781,6 +1782,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(type
         // one chunk per block (host: grid = chunks rounded up to 8), XCD-contiguous order
         const unsigned long long per = gridDim.x >> 3;
         c = static_cast<unsigned long long>(blockIdx.x & 7u) * per + (blockIdx.x >> 3);
+#ifdef RNNT_DEV
+        if (fa.dev & 1) c = blockIdx.x;
+#endif
         if (c >= nchunks) return;
     }
     unsigned long long r = (c * CH) / static_cast<unsigned>(A);                   // row of the chunk start
@@ -1850,6 +1854,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(type
                 int b = static_cast<int>(b0);
                 unsigned q = q0 + threadIdx.x;
                 while (q >= static_cast<unsigned>(TU)) { q -= static_cast<unsigned>(TU); ++b; }
+#ifdef RNNT_DEV
+                if (fa.dev & 2) recs[threadIdx.x] = Cell<C>{C(-3), C(0), C(0), C(-1)}; else
+#endif
                 recs[threadIdx.x] = make_record(b, q);
             }
             __syncthreads();

@@ -48,8 +48,8 @@ class _RNNT(Function):
             # the workspace (lattice + coefficient table) behind; backward runs the gradient kernel
             # once with the 1/N and grad_output factors folded in.  Same values, costs stay on device.
             costs = torch.empty(minibatch_size, dtype=cost_dtype, device=acts.device)
-            # (the workspace is allocated on, and only ever used on, the stream that is current here: the allocator's
-            # own stream bookkeeping covers it, no record_stream)
+            # (the workspace is allocated on the stream that is current here; gpu_rnnt_bwd records a different backward
+            # stream with the allocator if there ever is one)
             ws = warp_rnnt.gpu_rnnt_fwd(acts, labels, act_lens, label_lens, costs, blank, acts.requires_grad,
                                         fastemit_lambda)
             ctx.save_for_backward(acts)

@@ -32,8 +32,7 @@ class _ShardedRNNT(Function):
             # table to backward (compute_rnnt_loss_fwd / _bwd), no gradient tensor is kept
             costs = torch.empty(n, dtype=cost_dtype, device=acts.device)
             ws = warp_rnnt.gpu_rnnt_fwd(acts, labels, act_lens, label_lens, costs, blank, acts.requires_grad)
-            ws.record_stream(torch.cuda.current_stream(acts.device))
-            ctx.save_for_backward(acts)
+            ctx.save_for_backward(acts)         # (the workspace's stream bookkeeping: warp_rnnt.gpu_rnnt_fwd / _bwd)
             ctx.workspace, ctx.blank, grads = ws, blank, None
         else:
             costs = torch.zeros(n, dtype=cost_dtype)

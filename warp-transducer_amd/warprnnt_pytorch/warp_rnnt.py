@@ -123,8 +123,18 @@ def _workspace_bytes_cached(T, U, N, esz):
     return n
 
 
-def _raw_stream(index):
-    return torch._C._cuda_getCurrentRawStream(index)
+# torch._C._cuda_getCurrentRawStream / _cuda_getDevice are private: a torch build without them takes the public route
+# (a Stream object per call: a few microseconds more, nothing else changes).
+try:
+    _raw_stream = torch._C._cuda_getCurrentRawStream
+    _current_device = torch._C._cuda_getDevice
+    _raw_stream.__call__, _current_device.__call__
+except AttributeError:                                           # pragma: no cover -- depends on the torch build
+    def _raw_stream(index):
+        return torch.cuda.current_stream(index).cuda_stream
+
+    def _current_device():
+        return torch.cuda.current_device()
 
 
 class _on_device(object):
@@ -133,7 +143,7 @@ class _on_device(object):
     __slots__ = ("guard",)
 
     def __init__(self, index):
-        self.guard = None if torch._C._cuda_getDevice() == index else torch.cuda.device(index)
+        self.guard = None if _current_device() == index else torch.cuda.device(index)
 
     def __enter__(self):
         if self.guard is not None:
@@ -159,7 +169,12 @@ def gpu_rnnt_fwd(acts, labels, input_lengths, label_lengths, costs_device, blank
     index = acts.device.index
     with _on_device(index):
         ws = torch.empty(_workspace_bytes_cached(T, U, N, esz), dtype=torch.uint8, device=acts.device)
-        opt = _lib.rnntOptions(_lib.RNNT_GPU, 0, _raw_stream(index), int(blank_label), T, U, True)
+        stream = _raw_stream(index)
+        # The workspace is allocated on, and used on, the stream that is current HERE: the caching allocator's own
+        # bookkeeping covers that stream, so no record_stream.  gpu_rnnt_bwd checks that it runs on the same stream
+        # (autograd replays backward on the forward stream) and tells the allocator if it does not.
+        ws._rnnt_stream = stream
+        opt = _lib.rnntOptions(_lib.RNNT_GPU, 0, stream, int(blank_label), T, U, True)
         lab_ptr = labels.data_ptr() if labels.numel() else costs_device.data_ptr()   # maxU == 1: never read
         if fastemit_lambda:
             st = lib.compute_rnnt_loss_fwd_fastemit(acts.data_ptr(), lab_ptr, label_lengths.data_ptr(),
@@ -183,7 +198,12 @@ def gpu_rnnt_bwd(acts, grads, grad_scale, workspace, blank_label):
     code, _ = _DT[acts.dtype]
     index = acts.device.index
     with _on_device(index):
-        opt = _lib.rnntOptions(_lib.RNNT_GPU, 0, _raw_stream(index), int(blank_label), T, U, True)
+        stream = _raw_stream(index)
+        if getattr(workspace, "_rnnt_stream", stream) != stream:
+            # backward under another torch.cuda.stream than forward (a custom engine, retain_graph replays): the
+            # workspace is now in use on a stream its allocation does not know about
+            workspace.record_stream(torch.cuda.current_stream(index))
+        opt = _lib.rnntOptions(_lib.RNNT_GPU, 0, stream, int(blank_label), T, U, True)
         st = lib.compute_rnnt_loss_bwd(acts.data_ptr(), grads.data_ptr(), _ptr(grad_scale), A, N,
                                        workspace.data_ptr(), opt, code)
     if st != 0:

@@ -132,6 +132,10 @@ static void launch_row_stats(Plan<typename Tag::comp>& p, const typename Tag::st
 // chunk then holds >= 32 rows (the scattered operand loads are shared by many packets); lattices from kFuseMinCells on:
 // below, the coefficient kernel is a few microseconds and the dependent operand fetch in front of every block's packet
 // code costs more than it saves (measured on c2 in round 2: +3..7 %).
+#ifndef FUSE_PPT
+#define FUSE_PPT 2
+#endif
+constexpr int kFusePPT = FUSE_PPT;                        // packets per thread of the fused form
 constexpr size_t kFuseRowBytes = 256;
 constexpr unsigned long long kFuseMinCells = 1ull << 20;
 template <typename Tag> static bool fused_shape(const Plan<typename Tag::comp>& p) {
@@ -144,7 +148,7 @@ template <typename Tag> static bool fused_shape(const Plan<typename Tag::comp>& 
     const size_t maxrow = tn.fuse > 1 ? static_cast<size_t>(tn.fuse) : kFuseRowBytes;     // (dev build: fuse=<row bytes>)
     const unsigned long long mincells = tn.fusemin >= 0 ? static_cast<unsigned long long>(tn.fusemin) : kFuseMinCells;
     // one row per thread: a chunk of 512 packets touches at most 512 V / A + 2 rows
-    return row_bytes <= maxrow && R >= mincells && 512 * V / p.A + 2 <= kFuseMaxRows && p.A >= V;
+    return row_bytes <= maxrow && R >= mincells && kFusePPT * 256 * V / p.A + 2 <= kFuseMaxRows && p.A >= V && (R * p.A) % V == 0;
 }
 
 // Stage 4 (materialised path): dense gradient write-back.
@@ -165,7 +169,7 @@ static void launch_grad(Plan<typename Tag::comp>& p, const typename Tag::store* 
     if (fused && !flat_ok) launch_coef(p);                 // (tensors that cannot be streamed as packets: the records after all)
     if (fused && flat_ok) {
         using CC = typename Tag::comp;
-        const unsigned long long cpk = 512;                // PPT = 2
+        const unsigned long long cpk = 256ull * kFusePPT;
         const unsigned long long nchunks = (E / V + cpk - 1) / cpk;
         if (nchunks + 8 > 0x7fffffffull) { p.failed = true; return; }      // (2^31 chunks = 16 TB of fp32: not reachable)
         const unsigned grid = static_cast<unsigned>((nchunks + 7) / 8 * 8);   // XCD-contiguous chunk order wants a multiple of 8
@@ -173,10 +177,10 @@ static void launch_grad(Plan<typename Tag::comp>& p, const typename Tag::store* 
                               p.maxT, p.maxU, p.Up, p.lat_w, p.lat_sh, p.fastemit, tn.fdev};
         const float invA = 1.0f / static_cast<float>(p.A);
         if (grad_scale)
-            hipLaunchKernelGGL((grad_flat_kernel<Tag, 1, 2, 0, true>), dim3(grid), dim3(256), 0, p.stream, acts, grads, p.rowtab, grad_scale,
+            hipLaunchKernelGGL((grad_flat_kernel<Tag, 1, kFusePPT, 0, true>), dim3(grid), dim3(256), 0, p.stream, acts, grads, p.rowtab, grad_scale,
                                E, R, p.A, p.blank, p.cells_per_sample, invA, 0ull, 0, static_cast<const CC*>(nullptr), p.padflag, fa);
         else
-            hipLaunchKernelGGL((grad_flat_kernel<Tag, 0, 2, 0, true>), dim3(grid), dim3(256), 0, p.stream, acts, grads, p.rowtab, grad_scale,
+            hipLaunchKernelGGL((grad_flat_kernel<Tag, 0, kFusePPT, 0, true>), dim3(grid), dim3(256), 0, p.stream, acts, grads, p.rowtab, grad_scale,
                                E, R, p.A, p.blank, p.cells_per_sample, invA, 0ull, 0, static_cast<const CC*>(nullptr), p.padflag, fa);
     } else if (flat_ok) {
         const unsigned long long npk = E / V;
@@ -187,8 +191,15 @@ static void launch_grad(Plan<typename Tag::comp>& p, const typename Tag::store* 
 #endif
         const unsigned long long cpk = static_cast<unsigned long long>(ppt) * 256;
         const unsigned long long nchunks = (npk + cpk - 1) / cpk;
-        const unsigned grid = static_cast<unsigned>(nchunks < static_cast<unsigned long long>(tn.gmax)
+        unsigned grid = static_cast<unsigned>(nchunks < static_cast<unsigned long long>(tn.gmax)
                                                         ? (nchunks ? nchunks : 1) : tn.gmax);
+        FuseArgs<typename Tag::comp> nofuse{};
+#ifdef RNNT_DEV
+        if ((tn.fdev & 4) && nchunks + 8 <= static_cast<unsigned long long>(tn.gmax)) {   // A/B: XCD-contiguous chunk order
+            grid = static_cast<unsigned>((nchunks + 7) / 8 * 8);
+            nofuse.dev = 4;
+        }
+#endif
         const unsigned long long stride = static_cast<unsigned long long>(grid) * cpk * V;
         const unsigned long long dq = stride / p.A;
         const int drem = static_cast<int>(stride % p.A);
@@ -204,7 +215,7 @@ static void launch_grad(Plan<typename Tag::comp>& p, const typename Tag::store* 
 #define RNNT_FLAT(SC, PP, PS)                                                                                       \
     hipLaunchKernelGGL((grad_flat_kernel<Tag, SC, PP, PS>), dim3(grid), dim3(256), 0, p.stream, acts, grads,        \
                        p.rowtab, grad_scale, E, R, p.A, p.blank, p.cells_per_sample, invA, dq, drem, rowscale, p.padflag,  \
-                       FuseArgs<typename Tag::comp>{})
+                       nofuse)
         // padded rows are not read: always for long rows (the record is asked for first), for shorter ones when the
         // coefficient kernel has seen padding in this batch (packed layout: there are no padded rows)
         const int padskip = (!tn.pskip || packed) ? 0 : row_bytes >= static_cast<size_t>(tn.pskipb) ? 1

@@ -1751,9 +1751,59 @@ template <typename L> struct FuseArgs {
 // rows a chunk of CH elements can touch (A >= kFuseMinRowElems(CH) keeps it within one row per thread)
 constexpr int kFuseMaxRows = 258;
 
+// The records of rows r .. r + nrows - 1 (natural order) into recs[0 .. nrows), by ONE wavefront (lane = 0 .. 63).  Rows of
+// one sample at a time, so that everything per sample is scalar: base pointers in SGPRs, 32-bit cell offsets per lane,
+// lengths and likelihood loaded once (a sample's slab is megabytes, a chunk 8 KB: nearly always one pass).
+template <typename C>
+__device__ __forceinline__ void fused_build_records(Cell<C>* __restrict__ recs, const FuseArgs<C>& fa, unsigned long long r,
+                                                    int nrows, int TU, unsigned long long R, int lane) {
+    unsigned long long bb = (R <= 0xffffffffull) ? static_cast<unsigned>(r) / static_cast<unsigned>(TU) : r / static_cast<unsigned>(TU);
+    unsigned q0 = static_cast<unsigned>(r - bb * static_cast<unsigned>(TU));      // cell of the first row in its sample
+    const size_t Dp = lat_rows(fa.maxT, fa.maxU);
+    const unsigned Dpu = static_cast<unsigned>(Dp), maxU = static_cast<unsigned>(fa.maxU), Up = static_cast<unsigned>(fa.Up);
+    const float invU = 1.0f / static_cast<float>(fa.maxU);
+    for (int done = 0; done < nrows; ++bb, q0 = 0) {
+        const int b = uniform(static_cast<int>(bb));
+        const int here = uniform(static_cast<int>(static_cast<unsigned>(TU) - q0) < nrows - done ? static_cast<int>(static_cast<unsigned>(TU) - q0) : nrows - done);
+        const size_t sample0 = static_cast<size_t>(b) * Dp * Up;
+        const LogPair<C>* lp2s = fa.lp2 + sample0;
+        const C *lzs = fa.logz + sample0, *als = fa.alpha + sample0, *bes = fa.beta + sample0;
+        const double* oas = fa.offa + static_cast<size_t>(b) * fa.lw * Dp + kLatPad;
+        const double* obs = fa.offb + static_cast<size_t>(b) * fa.lw * Dp + kLatPad;
+        const int* labs = fa.labels + static_cast<size_t>(b) * (maxU - 1);
+        int Tb, Ub;
+        coef_lens(fa.xlen, fa.ylen, b, fa.maxT, fa.maxU, Tb, Ub);
+        const double ll2 = fa.ll_fwd[b];
+        const unsigned t0 = q0 / maxU, u0 = q0 - t0 * maxU;
+        for (int i = lane; i < here; i += 64) {
+            const unsigned qq = u0 + static_cast<unsigned>(i);                       // < maxU + 258: exact in fp32
+            unsigned dt = static_cast<unsigned>(static_cast<float>(qq) * invU);
+            int u = static_cast<int>(qq - dt * maxU);
+            if (u < 0) { u += fa.maxU; --dt; } else if (u >= fa.maxU) { u -= fa.maxU; ++dt; }
+            const int t = static_cast<int>(t0 + dt), n = t + u;
+            const unsigned cell = static_cast<unsigned>(kLatPad + n) * Up + static_cast<unsigned>(u);
+            CoefRaw<C> rw;
+            rw.p = lp2s[cell]; rw.lz = lzs[cell]; rw.al = als[cell];
+            rw.b0 = bes[cell]; rw.b1 = bes[cell + Up]; rw.b2 = bes[cell + Up + 1];
+            const unsigned wo = static_cast<unsigned>(u >> fa.lsh) * Dpu + static_cast<unsigned>(n);
+            const unsigned wr = static_cast<unsigned>((u + 1) >> fa.lsh) * Dpu + static_cast<unsigned>(n + 1);
+            rw.oa = oas[wo]; rw.ob = obs[wo]; rw.ob1 = obs[wo + 1]; rw.obr = obs[wr];
+            rw.lab = maxU > 1 ? labs[u < fa.maxU - 1 ? u : fa.maxU - 2] : 0;
+#ifdef RNNT_DEV
+            if (fa.dev & 2) { recs[done + i] = Cell<C>{C(-3), C(0), C(0), C(-1)}; continue; }
+#endif
+            recs[done + i] = coef_eval<C>(rw, ll2, t, u, Tb, Ub, fa.fastemit);
+        }
+        done += here;
+    }
+}
+
 template <typename Tag, int SCALE, int PPT, int PADSKIP, bool FUSED = false>   // SCALE: 0 none, 1 per sample (padded layout), 2 per row (packed); PPT = packets per thread and iteration;
                                                             // PADSKIP: the logits of padded rows are not read -- 0 never, 1 always, 2 when the batch has padding (padflag)
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(typename Tag::comp) == 8 ? 1 : 8))) void grad_flat_kernel(
+#ifndef FUSE_WPE
+#define FUSE_WPE 8
+#endif
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(typename Tag::comp) == 8 ? 1 : (FUSED ? FUSE_WPE : 8)))) void grad_flat_kernel(
         const typename Tag::store* __restrict__ acts, typename Tag::store* __restrict__ grads,
         const Cell<typename Tag::comp>* __restrict__ rowtab, const typename Tag::comp* __restrict__ grad_scale,
         unsigned long long E, unsigned long long R, int A, int blank, int TU, float invA,
@@ -1787,6 +1837,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(type
 #endif
         if (c >= nchunks) return;
     }
+#ifdef RNNT_DEV
+    else if (fa.dev & 4) {       // A/B: the plain form with one chunk per block in XCD-contiguous order (host: grid = chunks rounded up to 8)
+        const unsigned long long per = gridDim.x >> 3;
+        c = static_cast<unsigned long long>(blockIdx.x & 7u) * per + (blockIdx.x >> 3);
+        if (c >= nchunks) return;
+    }
+#endif
     unsigned long long r = (c * CH) / static_cast<unsigned>(A);                   // row of the chunk start
     int rem = static_cast<int>((c * CH) - r * static_cast<unsigned>(A));          // offset inside it
 
@@ -1824,16 +1881,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(type
         return g;
     };
 
-    // FUSED: the record of one row, as the coefficient kernels compute it (b, q = the row's sample and its cell index in it)
-    auto make_record = [&](int b, unsigned q) -> Cell<C> {
-        const int t = static_cast<int>(q / static_cast<unsigned>(fa.maxU)), u = static_cast<int>(q) - t * fa.maxU;
-        int Tb, Ub;
-        coef_lens(fa.xlen, fa.ylen, b, fa.maxT, fa.maxU, Tb, Ub);
-        const CoefRaw<C> raw = coef_fetch<C>(fa.lp2, fa.logz, fa.alpha, fa.beta, fa.offa, fa.offb, fa.labels, b, t + u, u,
-                                             fa.maxT, fa.maxU, fa.Up, fa.lw, fa.lsh, -1);
-        return coef_eval<C>(raw, fa.ll_fwd[b], t, u, Tb, Ub, fa.fastemit);
-    };
-
     for (; c < nchunks; c += gridDim.x) {
         const unsigned long long pk0 = c * kChunkPackets;
         uint4 raw[PPT];
@@ -1846,19 +1893,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(type
             }
             __builtin_amdgcn_sched_barrier(0);
             const unsigned long long last_e = (c * CH + CH < npk * V ? c * CH + CH : npk * V) - 1;   // last element of the chunk
-            const int nrows = static_cast<int>((static_cast<unsigned>(rem) + static_cast<unsigned>(last_e - c * CH)) / static_cast<unsigned>(A)) + 1;
-            // sample and cell of the chunk's first row (block-uniform), then one row per thread
-            const unsigned long long b0 = (R <= 0xffffffffull) ? static_cast<unsigned>(r) / static_cast<unsigned>(TU) : r / static_cast<unsigned>(TU);
-            const unsigned q0 = static_cast<unsigned>(r - b0 * static_cast<unsigned>(TU));
-            if (static_cast<int>(threadIdx.x) < nrows && r + threadIdx.x < R) {
-                int b = static_cast<int>(b0);
-                unsigned q = q0 + threadIdx.x;
-                while (q >= static_cast<unsigned>(TU)) { q -= static_cast<unsigned>(TU); ++b; }
-#ifdef RNNT_DEV
-                if (fa.dev & 2) recs[threadIdx.x] = Cell<C>{C(-3), C(0), C(0), C(-1)}; else
-#endif
-                recs[threadIdx.x] = make_record(b, q);
-            }
+            int nrows = static_cast<int>((static_cast<unsigned>(rem) + static_cast<unsigned>(last_e - c * CH)) / static_cast<unsigned>(A)) + 1;
+            if (r + static_cast<unsigned>(nrows) > R) nrows = static_cast<int>(R - r);
+            // ONE wavefront builds them (a record is ~150 instructions whatever the number of active lanes), and which one
+            // rotates with the chunk: wavefront w of every block sits on SIMD w, so a fixed builder would put the record
+            // work of all the CU's blocks on one SIMD -- measured: 2.41 ms against 1.76 for the kernel without the operands
+            if (static_cast<int>(threadIdx.x >> 6) == static_cast<int>(c & 3u))
+                fused_build_records<C>(recs, fa, r, nrows, TU, R, static_cast<int>(threadIdx.x & 63u));
             __syncthreads();
         }
         if constexpr (SCALE == 1) {
@@ -2005,18 +2046,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(type
         if (rem >= A) { rem -= A; ++r; }
     }
 
-    // the E % V elements after the last whole packet
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
+    // the E % V elements after the last whole packet (the fused form is only launched on tensors of whole packets)
+    if (!FUSED && blockIdx.x == 0 && threadIdx.x == 0) {
         for (unsigned long long e = npk * V; e < E; ++e) {
             const unsigned long long rw = e / static_cast<unsigned>(A);
             const int pos = static_cast<int>(e - rw * static_cast<unsigned>(A));
             C gs = C(1);
             if constexpr (SCALE == 2) gs = rowscale[rw];
             else if constexpr (SCALE == 1) gs = sample_scale(rw);
-            Cell<C> rc;
-            if constexpr (FUSED) { const unsigned long long bb = rw / static_cast<unsigned>(TU); rc = make_record(static_cast<int>(bb), static_cast<unsigned>(rw - bb * static_cast<unsigned>(TU))); }
-            else rc = rowtab[rw];
-            store1<Tag>(grads + e, elem(rc, pos, load1<Tag>(acts + e), gs));
+            store1<Tag>(grads + e, elem(rowtab[rw], pos, load1<Tag>(acts + e), gs));
         }
     }
 }

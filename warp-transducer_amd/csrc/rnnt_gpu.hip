@@ -126,35 +126,10 @@ static void launch_row_stats(Plan<typename Tag::comp>& p, const typename Tag::st
     p.check();
 }
 
-// Short rows under large lattices: the gradient kernel builds the records of its chunk itself (grad_flat_kernel, FUSED)
-// and the coefficient kernel does not run.  A function of the problem's shape and element type alone, so that the two
-// halves of a two-phase step (compute_rnnt_loss_fwd / _bwd) agree; padded layout only.  Rows up to kFuseRowBytes: a
-// chunk then holds >= 32 rows (the scattered operand loads are shared by many packets); lattices from kFuseMinCells on:
-// below, the coefficient kernel is a few microseconds and the dependent operand fetch in front of every block's packet
-// code costs more than it saves (measured on c2 in round 2: +3..7 %).
-#ifndef FUSE_PPT
-#define FUSE_PPT 2
-#endif
-constexpr int kFusePPT = FUSE_PPT;                        // packets per thread of the fused form
-constexpr size_t kFuseRowBytes = 256;
-constexpr unsigned long long kFuseMinCells = 1ull << 20;
-template <typename Tag> static bool fused_shape(const Plan<typename Tag::comp>& p) {
-    using S = typename Tag::store;
-    constexpr int V = Vec<Tag>::N;
-    const Tune& tn = tune();
-    if (!tn.fuse || p.offsets != nullptr) return false;
-    const size_t row_bytes = static_cast<size_t>(p.A) * sizeof(S);
-    const unsigned long long R = static_cast<unsigned long long>(p.N) * p.cells_per_sample;
-    const size_t maxrow = tn.fuse > 1 ? static_cast<size_t>(tn.fuse) : kFuseRowBytes;     // (dev build: fuse=<row bytes>)
-    const unsigned long long mincells = tn.fusemin >= 0 ? static_cast<unsigned long long>(tn.fusemin) : kFuseMinCells;
-    // one row per thread: a chunk of 512 packets touches at most 512 V / A + 2 rows
-    return row_bytes <= maxrow && R >= mincells && kFusePPT * 256 * V / p.A + 2 <= kFuseMaxRows && p.A >= V && (R * p.A) % V == 0;
-}
-
 // Stage 4 (materialised path): dense gradient write-back.
 template <typename Tag>
 static void launch_grad(Plan<typename Tag::comp>& p, const typename Tag::store* acts, typename Tag::store* grads,
-                        const typename Tag::comp* grad_scale, int vec_ok, bool may_fuse) {
+                        const typename Tag::comp* grad_scale, int vec_ok) {
     using S = typename Tag::store;
     constexpr int V = Vec<Tag>::N;
     const Tune& tn = tune();
@@ -165,24 +140,7 @@ static void launch_grad(Plan<typename Tag::comp>& p, const typename Tag::store* 
     const unsigned long long E = R * p.A;
     const bool flat_ok = vec_ok && (pa & 15u) == 0 && (pg & 15u) == 0 && p.A <= (1 << 23) && (!tn.rows || packed);
     if (packed && !flat_ok) { p.failed = true; return; }   // (run_gpu has validated the alignment: not reached)
-    const bool fused = may_fuse && fused_shape<Tag>(p);
-    if (fused && !flat_ok) launch_coef(p);                 // (tensors that cannot be streamed as packets: the records after all)
-    if (fused && flat_ok) {
-        using CC = typename Tag::comp;
-        const unsigned long long cpk = 256ull * kFusePPT;
-        const unsigned long long nchunks = (E / V + cpk - 1) / cpk;
-        if (nchunks + 8 > 0x7fffffffull) { p.failed = true; return; }      // (2^31 chunks = 16 TB of fp32: not reachable)
-        const unsigned grid = static_cast<unsigned>((nchunks + 7) / 8 * 8);   // XCD-contiguous chunk order wants a multiple of 8
-        const FuseArgs<CC> fa{p.lp2, p.logz, p.alpha, p.beta, p.offa, p.offb, p.llf, p.labels, p.input_lengths, p.label_lengths,
-                              p.maxT, p.maxU, p.Up, p.lat_w, p.lat_sh, p.fastemit, tn.fdev};
-        const float invA = 1.0f / static_cast<float>(p.A);
-        if (grad_scale)
-            hipLaunchKernelGGL((grad_flat_kernel<Tag, 1, kFusePPT, 0, true>), dim3(grid), dim3(256), 0, p.stream, acts, grads, p.rowtab, grad_scale,
-                               E, R, p.A, p.blank, p.cells_per_sample, invA, 0ull, 0, static_cast<const CC*>(nullptr), p.padflag, fa);
-        else
-            hipLaunchKernelGGL((grad_flat_kernel<Tag, 0, kFusePPT, 0, true>), dim3(grid), dim3(256), 0, p.stream, acts, grads, p.rowtab, grad_scale,
-                               E, R, p.A, p.blank, p.cells_per_sample, invA, 0ull, 0, static_cast<const CC*>(nullptr), p.padflag, fa);
-    } else if (flat_ok) {
+    if (flat_ok) {
         const unsigned long long npk = E / V;
 #ifdef RNNT_DEV
         const int ppt = (tn.ppt == 1 || tn.ppt == 4) ? tn.ppt : 2;
@@ -191,15 +149,8 @@ static void launch_grad(Plan<typename Tag::comp>& p, const typename Tag::store* 
 #endif
         const unsigned long long cpk = static_cast<unsigned long long>(ppt) * 256;
         const unsigned long long nchunks = (npk + cpk - 1) / cpk;
-        unsigned grid = static_cast<unsigned>(nchunks < static_cast<unsigned long long>(tn.gmax)
+        const unsigned grid = static_cast<unsigned>(nchunks < static_cast<unsigned long long>(tn.gmax)
                                                         ? (nchunks ? nchunks : 1) : tn.gmax);
-        FuseArgs<typename Tag::comp> nofuse{};
-#ifdef RNNT_DEV
-        if ((tn.fdev & 4) && nchunks + 8 <= static_cast<unsigned long long>(tn.gmax)) {   // A/B: XCD-contiguous chunk order
-            grid = static_cast<unsigned>((nchunks + 7) / 8 * 8);
-            nofuse.dev = 4;
-        }
-#endif
         const unsigned long long stride = static_cast<unsigned long long>(grid) * cpk * V;
         const unsigned long long dq = stride / p.A;
         const int drem = static_cast<int>(stride % p.A);
@@ -214,8 +165,7 @@ static void launch_grad(Plan<typename Tag::comp>& p, const typename Tag::store* 
         }
 #define RNNT_FLAT(SC, PP, PS)                                                                                       \
     hipLaunchKernelGGL((grad_flat_kernel<Tag, SC, PP, PS>), dim3(grid), dim3(256), 0, p.stream, acts, grads,        \
-                       p.rowtab, grad_scale, E, R, p.A, p.blank, p.cells_per_sample, invA, dq, drem, rowscale, p.padflag,  \
-                       nofuse)
+                       p.rowtab, grad_scale, E, R, p.A, p.blank, p.cells_per_sample, invA, dq, drem, rowscale, p.padflag)
         // padded rows are not read: always for long rows (the record is asked for first), for shorter ones when the
         // coefficient kernel has seen padding in this batch (packed layout: there are no padded rows)
         const int padskip = (!tn.pskip || packed) ? 0 : row_bytes >= static_cast<size_t>(tn.pskipb) ? 1
@@ -388,12 +338,9 @@ static rnntStatus_t run_gpu(const typename Tag::store* acts, typename Tag::store
     mark(1);
     if (do_fwd) launch_lattice(p, training);
     mark(2);
-    // the fused gradient kernel needs the labels and the lengths: a one-call entry has them, the backward half of a
-    // two-phase step (compute_rnnt_loss_bwd) does not -- that pair keeps the record table
-    const bool may_fuse = do_fwd && do_bwd;
-    if (do_fwd && training && !(may_fuse && fused_shape<Tag>(p))) launch_coef(p);      // (fused: the gradient kernel builds its records itself)
+    if (do_fwd && training) launch_coef(p);
     mark(3);
-    if (do_bwd) launch_grad<Tag>(p, acts, grads, grad_scale, vec_ok, may_fuse);
+    if (do_bwd) launch_grad<Tag>(p, acts, grads, grad_scale, vec_ok);
     mark(4);
     if (p.failed) return RNNT_STATUS_EXECUTION_FAILED;
 

@@ -180,12 +180,10 @@ static void ranges_mark(int i, bool do_fwd, bool do_bwd, const char* const names
 // j16 = bf16 storage on the bf16 matrix cores (rnnt_joint16_kernels.h), bit 0 DG, bit 1 DF, bit 2 Z; j16pf = operand ping-pong there, j16nt = columns per lane of its DF / DG (8 | 4),
 // latlin = linear-domain lattice kernel (chain + helper wavefronts) for one-wavefront fp32 lattices: 0 off, 1 up to one block per CU,
 //          2 at any size and every block takes the log-domain fallback (tests), 3 at any size,
-// tile2d = 2-D cell-tile statistics kernel for short rows under wide lattices on/off,
-// fuse = the gradient kernel builds its chunk's records itself, no coefficient kernel: 0 off, 1 rows <= 256 bytes, n > 1 rows <= n bytes;
-//        fusemin = lattice cells from which on (-1: 2^20).
+// tile2d = 2-D cell-tile statistics kernel for short rows under wide lattices on/off.
 struct Tune { int sw = 4, nta = 1, gmax = 4194304, rows = 0, tile = 1, tilekb = 52, ppt = 2;
               int jfnk = 0, jfpf = 1, jgnk = 0, jgpf = 1, blk = 1, jzs = 0, xcd = 1, ctile = 1, pskip = 1, joh = -1;
-              int lat2 = -1, xst = 0, jsamp = 1, tilemax = kTileMaxRowBytes, j16 = 7, j16pf = 1, j16nt = 4, tile2d = 1, latlin = 1, pskipb = 8192, pskipmin = 2048, fuse = 0, fusemin = -1, fdev = 0; };
+              int lat2 = -1, xst = 0, jsamp = 1, tilemax = kTileMaxRowBytes, j16 = 7, j16pf = 1, j16nt = 4, tile2d = 1, latlin = 1, pskipb = 8192, pskipmin = 2048; };
 #ifdef RNNT_DEV
 static Tune read_tune() {
     Tune t;
@@ -196,7 +194,7 @@ static Tune read_tune() {
         {"tilekb", &t.tilekb}, {"ppt", &t.ppt}, {"jfnk", &t.jfnk}, {"jfpf", &t.jfpf}, {"jgnk", &t.jgnk},
         {"jgpf", &t.jgpf}, {"blk", &t.blk}, {"jzs", &t.jzs}, {"xcd", &t.xcd}, {"ctile", &t.ctile},
         {"pskip", &t.pskip}, {"joh", &t.joh}, {"lat2", &t.lat2}, {"xst", &t.xst}, {"jsamp", &t.jsamp}, {"tilemax", &t.tilemax},
-        {"j16", &t.j16}, {"j16pf", &t.j16pf}, {"j16nt", &t.j16nt}, {"tile2d", &t.tile2d}, {"latlin", &t.latlin}, {"pskipb", &t.pskipb}, {"pskipmin", &t.pskipmin}, {"fuse", &t.fuse}, {"fusemin", &t.fusemin}, {"fdev", &t.fdev}};
+        {"j16", &t.j16}, {"j16pf", &t.j16pf}, {"j16nt", &t.j16nt}, {"tile2d", &t.tile2d}, {"latlin", &t.latlin}, {"pskipb", &t.pskipb}, {"pskipmin", &t.pskipmin}};
     // tokens are separated by ',', a token is key=value with the WHOLE key compared
     for (const char* p = e; *p;) {
         const char* end = strchr(p, ',');

@@ -1731,89 +1731,15 @@ __global__ __launch_bounds__(256) void fill_row_scale_kernel(
 // here, so no memset of the gradient tensor exists (the reference does one: gpu_rnnt.h:107-110).
 // Measured on MI355X (tools/microbench/stream_variants.hip): this structure sustains
 // 6.4-6.5 TB/s read+write with the exp included, the wavefront-per-row form 5.1 TB/s.
-// FUSED form (short rows under large lattices, c4): no coefficient kernel and no record table in HBM.  A chunk of the
-// stream covers a few dozen consecutive rows of (mostly) one time step; the block first REQUESTS ITS PACKETS, then its
-// first threads build the records of exactly those rows -- coef_fetch / coef_eval, the coefficient kernels' own code, so
-// the gradients are bit for bit the unfused ones -- from the skewed lattice arrays into LDS, and the packet code reads
-// them from there.  What that removes on c4: the 16-byte record per cell written once and read once (0.92 GB) and a
-// 0.27 ms kernel; what it costs: the lattice operands of a natural row lie on consecutive anti-diagonals, i.e. six
-// scattered 4-byte loads per cell (they share their lines with the rows of the neighbouring time steps, which the SAME
-// XCD streams a few hundred chunks later: block i runs on XCD i % 8 and takes chunk (i % 8) * per + i / 8, so every
-// XCD walks one contiguous eighth of the tensor and the lines are fetched from HBM once).  Everything a record needs:
-template <typename L> struct FuseArgs {
-    const LogPair<L>* lp2; const L* logz; const L* alpha; const L* beta;
-    const double* offa; const double* offb; const double* ll_fwd;
-    const int* labels; const int* xlen; const int* ylen;
-    int maxT, maxU, Up, lw, lsh;
-    float fastemit;
-    int dev;          // development build only (RNNT_TUNE=fdev=..): bit 0 launch-order chunks, bit 1 records without their operands (timing only, results WRONG)
-};
-// rows a chunk of CH elements can touch (A >= kFuseMinRowElems(CH) keeps it within one row per thread)
-constexpr int kFuseMaxRows = 258;
-
-// The records of rows r .. r + nrows - 1 (natural order) into recs[0 .. nrows), by ONE wavefront (lane = 0 .. 63).  Rows of
-// one sample at a time, so that everything per sample is scalar: base pointers in SGPRs, 32-bit cell offsets per lane,
-// lengths and likelihood loaded once (a sample's slab is megabytes, a chunk 8 KB: nearly always one pass).
-template <typename C>
-__device__ __forceinline__ void fused_build_records(Cell<C>* __restrict__ recs, const FuseArgs<C>& fa, unsigned long long r,
-                                                    int nrows, int TU, unsigned long long R, int lane) {
-    unsigned long long bb = (R <= 0xffffffffull) ? static_cast<unsigned>(r) / static_cast<unsigned>(TU) : r / static_cast<unsigned>(TU);
-    unsigned q0 = static_cast<unsigned>(r - bb * static_cast<unsigned>(TU));      // cell of the first row in its sample
-    const size_t Dp = lat_rows(fa.maxT, fa.maxU);
-    const unsigned Dpu = static_cast<unsigned>(Dp), maxU = static_cast<unsigned>(fa.maxU), Up = static_cast<unsigned>(fa.Up);
-    const float invU = 1.0f / static_cast<float>(fa.maxU);
-    for (int done = 0; done < nrows; ++bb, q0 = 0) {
-        const int b = uniform(static_cast<int>(bb));
-        const int here = uniform(static_cast<int>(static_cast<unsigned>(TU) - q0) < nrows - done ? static_cast<int>(static_cast<unsigned>(TU) - q0) : nrows - done);
-        const size_t sample0 = static_cast<size_t>(b) * Dp * Up;
-        const LogPair<C>* lp2s = fa.lp2 + sample0;
-        const C *lzs = fa.logz + sample0, *als = fa.alpha + sample0, *bes = fa.beta + sample0;
-        const double* oas = fa.offa + static_cast<size_t>(b) * fa.lw * Dp + kLatPad;
-        const double* obs = fa.offb + static_cast<size_t>(b) * fa.lw * Dp + kLatPad;
-        const int* labs = fa.labels + static_cast<size_t>(b) * (maxU - 1);
-        int Tb, Ub;
-        coef_lens(fa.xlen, fa.ylen, b, fa.maxT, fa.maxU, Tb, Ub);
-        const double ll2 = fa.ll_fwd[b];
-        const unsigned t0 = q0 / maxU, u0 = q0 - t0 * maxU;
-        for (int i = lane; i < here; i += 64) {
-            const unsigned qq = u0 + static_cast<unsigned>(i);                       // < maxU + 258: exact in fp32
-            unsigned dt = static_cast<unsigned>(static_cast<float>(qq) * invU);
-            int u = static_cast<int>(qq - dt * maxU);
-            if (u < 0) { u += fa.maxU; --dt; } else if (u >= fa.maxU) { u -= fa.maxU; ++dt; }
-            const int t = static_cast<int>(t0 + dt), n = t + u;
-            const unsigned cell = static_cast<unsigned>(kLatPad + n) * Up + static_cast<unsigned>(u);
-            CoefRaw<C> rw;
-            rw.p = lp2s[cell]; rw.lz = lzs[cell]; rw.al = als[cell];
-            rw.b0 = bes[cell]; rw.b1 = bes[cell + Up]; rw.b2 = bes[cell + Up + 1];
-            const unsigned wo = static_cast<unsigned>(u >> fa.lsh) * Dpu + static_cast<unsigned>(n);
-            const unsigned wr = static_cast<unsigned>((u + 1) >> fa.lsh) * Dpu + static_cast<unsigned>(n + 1);
-            rw.oa = oas[wo]; rw.ob = obs[wo]; rw.ob1 = obs[wo + 1]; rw.obr = obs[wr];
-            rw.lab = maxU > 1 ? labs[u < fa.maxU - 1 ? u : fa.maxU - 2] : 0;
-#ifdef RNNT_DEV
-            if (fa.dev & 2) { recs[done + i] = Cell<C>{C(-3), C(0), C(0), C(-1)}; continue; }
-#endif
-            recs[done + i] = coef_eval<C>(rw, ll2, t, u, Tb, Ub, fa.fastemit);
-        }
-        done += here;
-    }
-}
-
-template <typename Tag, int SCALE, int PPT, int PADSKIP, bool FUSED = false>   // SCALE: 0 none, 1 per sample (padded layout), 2 per row (packed); PPT = packets per thread and iteration;
+template <typename Tag, int SCALE, int PPT, int PADSKIP>   // SCALE: 0 none, 1 per sample (padded layout), 2 per row (packed); PPT = packets per thread and iteration;
                                                             // PADSKIP: the logits of padded rows are not read -- 0 never, 1 always, 2 when the batch has padding (padflag)
-#ifndef FUSE_WPE
-#define FUSE_WPE 8
-#endif
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(typename Tag::comp) == 8 ? 1 : (FUSED ? FUSE_WPE : 8)))) void grad_flat_kernel(
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(typename Tag::comp) == 8 ? 1 : 8))) void grad_flat_kernel(
         const typename Tag::store* __restrict__ acts, typename Tag::store* __restrict__ grads,
         const Cell<typename Tag::comp>* __restrict__ rowtab, const typename Tag::comp* __restrict__ grad_scale,
         unsigned long long E, unsigned long long R, int A, int blank, int TU, float invA,
-        unsigned long long dq, int drem, const typename Tag::comp* __restrict__ rowscale, const int* __restrict__ padflag,
-        const FuseArgs<typename Tag::comp> fa) {
+        unsigned long long dq, int drem, const typename Tag::comp* __restrict__ rowscale, const int* __restrict__ padflag) {
     using C = typename Tag::comp;
     constexpr bool SCALED = SCALE != 0;
-    static_assert(!FUSED || (PADSKIP == 0 && SCALE != 2), "the fused form serves the padded layout, packets always read");
-    __shared__ Cell<C> recs[FUSED ? kFuseMaxRows + 2 : 1];
-    (void)recs;
     // Short rows (PADSKIP == 2): testing the record before the load is a dependent memory latency per block and costs a
     // batch WITHOUT padding 7 % (2 KB rows); whether there is any padding is one word the coefficient kernel has left
     // behind -- a scalar load that is back before the index arithmetic below is through.
@@ -1828,22 +1754,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(type
     u32x4* out = reinterpret_cast<u32x4*>(grads);
 
     unsigned long long c = blockIdx.x;
-    if constexpr (FUSED) {
-        // one chunk per block (host: grid = chunks rounded up to 8), XCD-contiguous order
-        const unsigned long long per = gridDim.x >> 3;
-        c = static_cast<unsigned long long>(blockIdx.x & 7u) * per + (blockIdx.x >> 3);
-#ifdef RNNT_DEV
-        if (fa.dev & 1) c = blockIdx.x;
-#endif
-        if (c >= nchunks) return;
-    }
-#ifdef RNNT_DEV
-    else if (fa.dev & 4) {       // A/B: the plain form with one chunk per block in XCD-contiguous order (host: grid = chunks rounded up to 8)
-        const unsigned long long per = gridDim.x >> 3;
-        c = static_cast<unsigned long long>(blockIdx.x & 7u) * per + (blockIdx.x >> 3);
-        if (c >= nchunks) return;
-    }
-#endif
     unsigned long long r = (c * CH) / static_cast<unsigned>(A);                   // row of the chunk start
     int rem = static_cast<int>((c * CH) - r * static_cast<unsigned>(A));          // offset inside it
 
@@ -1883,25 +1793,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(type
 
     for (; c < nchunks; c += gridDim.x) {
         const unsigned long long pk0 = c * kChunkPackets;
-        uint4 raw[PPT];
-        if constexpr (FUSED) {
-            // the chunk's packets go out FIRST: the records' operands then travel beside them, not in front of them
-#pragma unroll
-            for (int k = 0; k < PPT; ++k) {
-                const int p = k * 256 + threadIdx.x;
-                if (pk0 + p < npk) raw[k] = load_packet<true>(in + pk0 + p);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            const unsigned long long last_e = (c * CH + CH < npk * V ? c * CH + CH : npk * V) - 1;   // last element of the chunk
-            int nrows = static_cast<int>((static_cast<unsigned>(rem) + static_cast<unsigned>(last_e - c * CH)) / static_cast<unsigned>(A)) + 1;
-            if (r + static_cast<unsigned>(nrows) > R) nrows = static_cast<int>(R - r);
-            // ONE wavefront builds them (a record is ~150 instructions whatever the number of active lanes), and which one
-            // rotates with the chunk: wavefront w of every block sits on SIMD w, so a fixed builder would put the record
-            // work of all the CU's blocks on one SIMD -- measured: 2.41 ms against 1.76 for the kernel without the operands
-            if (static_cast<int>(threadIdx.x >> 6) == static_cast<int>(c & 3u))
-                fused_build_records<C>(recs, fa, r, nrows, TU, R, static_cast<int>(threadIdx.x & 63u));
-            __syncthreads();
-        }
         if constexpr (SCALE == 1) {
             {                                               // padded layout: sample = row / (maxT*maxU)
                 const unsigned long long rl0 = r + static_cast<unsigned>(CH / A + 1);
@@ -1928,8 +1819,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(type
                         const unsigned long long rw = r + q;
                         unsigned long long sb = b0, next = (b0 + 1) * static_cast<unsigned>(TU);
                         while (rw >= next) { ++sb; next += static_cast<unsigned>(TU); }
-                        const Cell<C> rc = FUSED ? recs[static_cast<unsigned>(rw - r)] : rowtab[rw];
-                        store1<Tag>(grads + e0 + i, elem(rc, pos, load1<Tag>(acts + e0 + i), grad_scale[sb]));
+                        store1<Tag>(grads + e0 + i, elem(rowtab[rw], pos, load1<Tag>(acts + e0 + i), grad_scale[sb]));
                     }
                     r += dq;
                     rem += drem;
@@ -1938,6 +1828,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(type
                 }
             }
         }
+        uint4 raw[PPT];
         Cell<C> rec[PPT], rec2[PPT];                        // rec2: the NEXT row's record, for packets that straddle
         int v0[PPT];
         unsigned long long row[PPT];
@@ -1952,12 +1843,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(type
             if (rr < 0) { rr += A; --q; } else if (rr >= A) { rr -= A; ++q; }
             v0[k] = rr;
             row[k] = r + q;
-            if constexpr (FUSED) {
-                if (live[k]) {
-                    rec[k] = recs[q];
-                    if (rr + V > A) rec2[k] = recs[q + 1];     // (the next row holds the packet's last element: it is one of the chunk's rows)
-                }
-            } else if (live[k]) {
+            if (live[k]) {
                 rec[k] = rowtab[row[k]];
                 if (PADSKIP == 0 || !ps) raw[k] = load_packet<true>(in + pk0 + p);
                 // a packet that crosses into the next row (A % V != 0) needs that row's record too: asked
@@ -2030,7 +1916,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(type
                         while (pos >= A) {
                             pos -= A;
                             ++rw;
-                            if (rw < R) cur = FUSED ? recs[static_cast<unsigned>(rw - r)] : rowtab[rw];
+                            if (rw < R) cur = rowtab[rw];
                             gs = scale_of(rw < R ? rw : R - 1);
                         }
                         v[j] = elem(cur, pos, v[j], gs);
@@ -2040,14 +1926,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(type
             }
             store_packet<true>(out + pk0 + p, pack<Tag>(v));
         }
-        if constexpr (FUSED) break;                         // one chunk per block (recs is not double-buffered)
         r += dq;
         rem += drem;
         if (rem >= A) { rem -= A; ++r; }
     }
 
-    // the E % V elements after the last whole packet (the fused form is only launched on tensors of whole packets)
-    if (!FUSED && blockIdx.x == 0 && threadIdx.x == 0) {
+    // the E % V elements after the last whole packet
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
         for (unsigned long long e = npk * V; e < E; ++e) {
             const unsigned long long rw = e / static_cast<unsigned>(A);
             const int pos = static_cast<int>(e - rw * static_cast<unsigned>(A));

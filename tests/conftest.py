@@ -18,6 +18,10 @@ def pytest_configure(config):
     if not os.path.exists(os.path.join(ROOT, "warp-transducer_amd", "lib", "libwarprnnt.so")):
         subprocess.run(["make", "-C", os.path.join(ROOT, "warp-transducer_amd")], check=True,
                        stdout=subprocess.DEVNULL)
+    import glob
+    if not glob.glob(os.path.join(ROOT, "warp-transducer_amd", "warprnnt_pytorch", "_warp_rnnt_ext*.so")):
+        subprocess.run([sys.executable, os.path.join(ROOT, "warp-transducer_amd", "warprnnt_pytorch", "build_ext.py")], check=True,
+                       stdout=subprocess.DEVNULL)
     if not os.path.exists(os.path.join(ROOT, "oracle", "liboracle.so")):
         subprocess.run(["make", "-C", os.path.join(ROOT, "oracle")], check=True, stdout=subprocess.DEVNULL)
 

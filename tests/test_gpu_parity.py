@@ -217,13 +217,20 @@ def test_async_entry_and_fused_grad_scale(oracle):
     assert np.abs(grads.cpu().numpy() - ref_g).max() < 3e-4
 
 
+@pytest.mark.parametrize("loader", ["ext", "ctypes"])
 @pytest.mark.parametrize("async_entry", [True, False])
-def test_pytorch_binding_on_gpu(monkeypatch, async_entry):
+def test_pytorch_binding_on_gpu(monkeypatch, async_entry, loader):
     """pytorch_binding/test/test.py on the device: CPU and GPU must give identical grads.  Both
     routes of the wrapper: the asynchronous entry (device costs) and the reference's host-costs
-    entry compute_rnnt_loss."""
+    entry compute_rnnt_loss -- and both bindings: the compiled extension module (csrc/binding.cpp, the
+    reference's form: pytorch_binding/src/binding.cpp) and the ctypes loader."""
     import warprnnt_pytorch
-    from warprnnt_pytorch import RNNTLoss
+    from warprnnt_pytorch import RNNTLoss, warp_rnnt
+    if loader == "ext":
+        assert warp_rnnt.binding() == "ext", "the compiled extension module was not built (python -c 'import __graft_entry__ as g; g.build()')"
+    else:
+        monkeypatch.setattr(warp_rnnt, "_EXT", None)
+        assert warp_rnnt.binding() == "ctypes"
     monkeypatch.setattr(warprnnt_pytorch, "_ASYNC_GPU", async_entry)
     dev = torch.device("cuda:0")
     for acts_np, labels, cost, grads_ref in ((G.SMALL_ACTS, [[1, 2]], G.SMALL_COST, G.SMALL_GRADS),
@@ -240,6 +247,23 @@ def test_pytorch_binding_on_gpu(monkeypatch, async_entry):
         assert np.allclose(x.grad.cpu().numpy(), grads_ref, rtol=1e-3, atol=1e-6)
         m = RNNTLoss(reduction='mean')(x.detach().requires_grad_(True), lab, tl, ll)
         assert np.allclose(m.item(), cost / n, rtol=1e-5)
+        # per-sample losses with a per-sample grad_output, the reference's validation errors, and a no-grad call
+        x2 = x.detach().clone().requires_grad_(True)
+        per = RNNTLoss(reduction='none')(x2, lab, tl, ll)
+        w = torch.arange(1, n + 1, dtype=per.dtype, device=dev)
+        (per * w).sum().backward()
+        assert np.allclose(x2.grad.cpu().numpy(), grads_ref * w.cpu().numpy()[:, None, None, None], rtol=1e-3, atol=1e-6)
+        with pytest.raises(ValueError, match="Input length mismatch"):
+            RNNTLoss()(x, lab, tl - 1, ll)
+        with pytest.raises(ValueError, match="Output length mismatch"):
+            RNNTLoss()(x, lab, tl, ll - 1)
+        with pytest.raises(TypeError, match="labels must be"):
+            RNNTLoss()(x, lab.long(), tl, ll)
+        with pytest.raises(ValueError, match="must be contiguous"):
+            RNNTLoss()(x.transpose(1, 2).contiguous().transpose(1, 2), lab, tl, ll)
+        with torch.no_grad():
+            assert np.allclose(RNNTLoss(reduction='sum')(x, lab, tl, ll).item(), cost, rtol=1e-5)
+        assert RNNTLoss(validate=False)(x, lab, tl, ll).shape == (1,)
 
 
 def test_pinned_host_costs_are_written_directly():

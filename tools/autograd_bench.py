@@ -10,7 +10,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "warp-transducer_amd"))
 import numpy as np
 import torch
-from warprnnt_pytorch import RNNTLoss
+from warprnnt_pytorch import RNNTLoss, warp_rnnt
+print("binding: %s (WARPRNNT_BINDING=ctypes selects the ctypes loader)" % warp_rnnt.binding())
 
 SHAPES = {"c2": (16, 150, 41, 28, torch.float32), "c3": (128, 150, 21, 5000, torch.float32),
           "c5": (128, 200, 41, 1024, torch.bfloat16)}

@@ -114,6 +114,21 @@ class _RNNT(Function):
         return ctx.grads * grad_output, None, None, None, None, None, None, None
 
 
+_REDUCTIONS = {'none': 0, 'sum': 1, 'mean': 2}
+
+
+def _apply(acts, labels, act_lens, label_lens, blank, reduction, fastemit_lambda, validate):
+    """GPU tensors on the default (two-phase) route go through the compiled module's C++ autograd function when it is
+    there (warp_rnnt.binding() == 'ext': checks, allocations, both library calls and the reduction without returning to
+    Python); everything else -- the CPU location, WARPRNNT_SYNC_API=1, the ctypes binding -- through `_RNNT` above.
+    Same values either way (tests run both)."""
+    ext = warp_rnnt._EXT
+    if ext is not None and acts.is_cuda and _ASYNC_GPU and reduction in _REDUCTIONS:
+        return ext.rnnt_loss(acts, labels, act_lens, label_lens, int(blank), _REDUCTIONS[reduction], float(fastemit_lambda),
+                             bool(validate))
+    return _RNNT.apply(acts, labels, act_lens, label_lens, blank, reduction, fastemit_lambda, validate)
+
+
 def rnnt_loss(acts, labels, act_lens, label_lens, blank=0, reduction='mean', fastemit_lambda=0.0, validate=True):
     """RNN Transducer loss.
 
@@ -136,7 +151,7 @@ def rnnt_loss(acts, labels, act_lens, label_lens, blank=0, reduction='mean', fas
     """
     if not acts.is_cuda:
         acts = torch.nn.functional.log_softmax(acts, -1)
-    return _RNNT.apply(acts, labels, act_lens, label_lens, blank, reduction, fastemit_lambda, validate)
+    return _apply(acts, labels, act_lens, label_lens, blank, reduction, fastemit_lambda, validate)
 
 
 class RNNTLoss(Module):
@@ -155,7 +170,7 @@ class RNNTLoss(Module):
         self.reduction = reduction
         self.fastemit_lambda = fastemit_lambda
         self.validate = validate
-        self.loss = _RNNT.apply
+        self.loss = _apply
 
     def forward(self, acts, labels, act_lens, label_lens):
         if not acts.is_cuda:

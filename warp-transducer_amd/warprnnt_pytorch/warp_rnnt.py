@@ -12,9 +12,34 @@ workspace from the framework allocator (binding.cpp:115-120), use the current st
 as the reference, plus bfloat16/float16 on the GPU.  An empty ``grads`` tensor means
 "score only" (reference __init__.py:24 passes torch.zeros(0)).
 """
+import os as _os
+
 import torch
 
 from . import _lib
+
+# The compiled module (csrc/binding.cpp, built in tree by build_ext.py / setup.py) is the default binding, as in the
+# reference (a pybind11 extension, pytorch_binding/src/binding.cpp:157-162); the ctypes route below is the fallback when it
+# has not been built, and WARPRNNT_BINDING=ctypes | ext selects one explicitly ("ext" fails loudly if it is missing).
+# Either way every call ends in the C-ABI of libwarprnnt.so: there is no Python or CPU fallback for the HIP path.
+_EXT = None
+_want = _os.environ.get("WARPRNNT_BINDING", "auto").lower()
+if _want != "ctypes":
+    try:
+        from . import _warp_rnnt_ext as _EXT
+    except ImportError:
+        if _want == "ext":
+            raise
+        _EXT = None
+
+
+_DT = {torch.float32: (_lib.DT_F32, 4), torch.float64: (_lib.DT_F64, 8),
+       torch.bfloat16: (_lib.DT_BF16, 2), torch.float16: (_lib.DT_F16, 2)}
+
+
+def binding():
+    """'ext' (the compiled PyTorch extension module) or 'ctypes'."""
+    return "ext" if _EXT is not None else "ctypes"
 
 
 def _options(loc, acts, blank_label, num_threads, stream):
@@ -29,6 +54,8 @@ def _ptr(t):
 
 def cpu_rnnt(acts, labels, input_lengths, label_lengths, costs, grads, blank_label, num_threads):
     """RNNT_CPU: acts are LOG-PROBS, grads the sparse d/d(log-probs).  Returns 0 / -1."""
+    if _EXT is not None and acts.dtype in (torch.float32, torch.float64):    # (an unsupported dtype: the line on stderr and -1 below)
+        return _EXT.cpu_rnnt(acts, labels, input_lengths, label_lengths, costs, grads, int(blank_label), int(num_threads))
     lib = _lib.lib()
     N, T, U, A = acts.shape
     if acts.dtype == torch.float32:
@@ -52,9 +79,11 @@ def gpu_rnnt(acts, labels, input_lengths, label_lengths, costs, grads, blank_lab
     labels/lengths are device tensors, ``costs`` is a HOST tensor.  Returns 0 / -1.
     (``workspace``: optional caller-owned uint8 device tensor of get_workspace_size bytes; the
     reference's 8-argument form allocates a temporary one from the framework allocator, binding.cpp:120,128.)"""
-    lib = _lib.lib()
     if not acts.is_cuda:
         raise ValueError("gpu_rnnt needs device tensors")
+    if _EXT is not None and acts.dtype in _DT:
+        return _EXT.gpu_rnnt(acts, labels, input_lengths, label_lengths, costs, grads, int(blank_label), int(num_threads), workspace)
+    lib = _lib.lib()
     N, T, U, A = acts.shape
     table = {torch.float32: (lib.compute_rnnt_loss, 4), torch.float64: (lib.compute_rnnt_loss_fp64, 8),
              torch.bfloat16: (lib.compute_rnnt_loss_bf16, 2), torch.float16: (lib.compute_rnnt_loss_fp16, 2)}
@@ -102,10 +131,6 @@ def gpu_rnnt_async(acts, labels, input_lengths, label_lengths, costs_device, gra
                                              opt, code[0])
     _lib.check(st, "compute_rnnt_loss_async")
     return workspace
-
-
-_DT = {torch.float32: (_lib.DT_F32, 4), torch.float64: (_lib.DT_F64, 8),
-       torch.bfloat16: (_lib.DT_BF16, 2), torch.float16: (_lib.DT_F16, 2)}
 
 
 # Host-side cost of the two-phase entries (what a PyTorch user of SMALL problems sees: on N=16,T=150,U=41,A=28 the
@@ -160,6 +185,11 @@ def gpu_rnnt_fwd(acts, labels, input_lengths, label_lengths, costs_device, blank
     """Extension: forward phase only (compute_rnnt_loss_fwd; compute_rnnt_loss_fwd_fastemit when
     ``fastemit_lambda`` is not 0).  Returns the workspace tensor; with ``prepare_backward`` it holds the
     gradient-coefficient table `gpu_rnnt_bwd` needs and must be kept (untouched) until then.  Enqueue only."""
+    if _EXT is not None:
+        ws = _EXT.gpu_rnnt_fwd(acts, labels, input_lengths, label_lengths, costs_device, int(blank_label), bool(prepare_backward),
+                               float(fastemit_lambda))
+        ws._rnnt_stream = _raw_stream(acts.device.index)
+        return ws
     lib = _lib.lib()
     N, T, U, A = acts.shape
     dt = _DT.get(acts.dtype)
@@ -193,6 +223,9 @@ def gpu_rnnt_fwd(acts, labels, input_lengths, label_lengths, costs_device, blank
 def gpu_rnnt_bwd(acts, grads, grad_scale, workspace, blank_label):
     """Extension: gradient phase (compute_rnnt_loss_bwd) from the workspace of `gpu_rnnt_fwd`;
     ``grad_scale`` is a per-sample device vector (float32; float64 for float64 acts) or None."""
+    if _EXT is not None:
+        _EXT.gpu_rnnt_bwd(acts, grads, grad_scale, workspace, int(blank_label), int(getattr(workspace, "_rnnt_stream", 0) or 0))
+        return 0
     lib = _lib.lib()
     N, T, U, A = acts.shape
     code, _ = _DT[acts.dtype]

@@ -88,7 +88,10 @@ def library_path():
     env = os.environ.get("WARP_RNNT_PATH")
     if env:
         return os.path.join(env, "libwarprnnt.so") if os.path.isdir(env) else env
-    return os.path.normpath(os.path.join(_HERE, "..", "lib", "libwarprnnt.so"))
+    installed = os.path.join(_HERE, "lib", "libwarprnnt.so")          # pip-installed package: the library travels inside it
+    if os.path.exists(installed):
+        return installed
+    return os.path.normpath(os.path.join(_HERE, "..", "lib", "libwarprnnt.so"))   # source tree: warp-transducer_amd/lib
 
 
 def lib():

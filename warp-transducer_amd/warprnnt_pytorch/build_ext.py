@@ -35,7 +35,7 @@ def command(lib_dir, out_dir=HERE, include_dir=None):
     cmd += ["-I" + d for d in inc]
     cmd += [os.path.join(HERE, "csrc", "binding.cpp"), "-o", target(out_dir)]
     rel = os.path.relpath(os.path.abspath(lib_dir), os.path.abspath(out_dir))
-    cmd += ["-L" + lib_dir, "-lwarprnnt", "-Wl,-rpath,$ORIGIN/" + rel,
+    cmd += ["-L" + lib_dir, "-lwarprnnt", "-Wl,-rpath,$ORIGIN/" + rel, "-Wl,-rpath,$ORIGIN/lib",    # (source tree | installed package)
             "-L" + tlib, "-lc10", "-lc10_hip", "-ltorch_cpu", "-ltorch_hip", "-ltorch", "-ltorch_python", "-Wl,-rpath," + tlib,
             "-L" + os.path.join(rocm, "lib"), "-lamdhip64"]
     return cmd

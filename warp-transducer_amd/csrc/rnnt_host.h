@@ -180,10 +180,11 @@ static void ranges_mark(int i, bool do_fwd, bool do_bwd, const char* const names
 // j16 = bf16 storage on the bf16 matrix cores (rnnt_joint16_kernels.h), bit 0 DG, bit 1 DF, bit 2 Z; j16pf = operand ping-pong there, j16nt = columns per lane of its DF / DG (8 | 4),
 // latlin = linear-domain lattice kernel (chain + helper wavefronts) for one-wavefront fp32 lattices: 0 off, 1 up to one block per CU,
 //          2 at any size and every block takes the log-domain fallback (tests), 3 at any size,
-// tile2d = 2-D cell-tile statistics kernel for short rows under wide lattices on/off.
+// tile2d = 2-D cell-tile statistics kernel for short rows under wide lattices on/off,
+// jfsum = additive joint: the correction sums of the gradient GEMMs formed inside the tiled coefficient kernel on/off.
 struct Tune { int sw = 4, nta = 1, gmax = 4194304, rows = 0, tile = 1, tilekb = 52, ppt = 2;
               int jfnk = 0, jfpf = 1, jgnk = 0, jgpf = 1, blk = 1, jzs = 0, xcd = 1, ctile = 1, pskip = 1, joh = -1;
-              int lat2 = -1, xst = 0, jsamp = 1, tilemax = kTileMaxRowBytes, j16 = 7, j16pf = 1, j16nt = 4, tile2d = 1, latlin = 1, pskipb = 8192, pskipmin = 2048; };
+              int lat2 = -1, xst = 0, jsamp = 1, tilemax = kTileMaxRowBytes, j16 = 7, j16pf = 1, j16nt = 4, tile2d = 1, latlin = 1, pskipb = 8192, pskipmin = 2048, jfsum = 1; };
 #ifdef RNNT_DEV
 static Tune read_tune() {
     Tune t;
@@ -194,7 +195,7 @@ static Tune read_tune() {
         {"tilekb", &t.tilekb}, {"ppt", &t.ppt}, {"jfnk", &t.jfnk}, {"jfpf", &t.jfpf}, {"jgnk", &t.jgnk},
         {"jgpf", &t.jgpf}, {"blk", &t.blk}, {"jzs", &t.jzs}, {"xcd", &t.xcd}, {"ctile", &t.ctile},
         {"pskip", &t.pskip}, {"joh", &t.joh}, {"lat2", &t.lat2}, {"xst", &t.xst}, {"jsamp", &t.jsamp}, {"tilemax", &t.tilemax},
-        {"j16", &t.j16}, {"j16pf", &t.j16pf}, {"j16nt", &t.j16nt}, {"tile2d", &t.tile2d}, {"latlin", &t.latlin}, {"pskipb", &t.pskipb}, {"pskipmin", &t.pskipmin}};
+        {"j16", &t.j16}, {"j16pf", &t.j16pf}, {"j16nt", &t.j16nt}, {"tile2d", &t.tile2d}, {"latlin", &t.latlin}, {"pskipb", &t.pskipb}, {"pskipmin", &t.pskipmin}, {"jfsum", &t.jfsum}};
     // tokens are separated by ',', a token is key=value with the WHOLE key compared
     for (const char* p = e; *p;) {
         const char* end = strchr(p, ',');
@@ -324,7 +325,11 @@ template <typename C> static void launch_lattice(Plan<C>& p, bool with_beta) {
 }
 
 // Stage 3: gradient coefficients per row into the natural-order row table.
-template <typename C> static void launch_coef(Plan<C>& p, bool joint = false, bool onehot = false) {
+// joint: the additive-joint path (dense planes for its gradient GEMMs); sums != nullptr: also their correction sums
+// {sfb, sgb, sgl, farflag} -- formed inside the tiled kernel; returns false when the caller still has to run
+// joint_sums_kernel (the cell-per-thread form of small lattices leaves them to it)
+struct JointSums { float *sfb, *sgb, *sgl; int* farflag; };
+template <typename C> static bool launch_coef(Plan<C>& p, bool joint = false, bool onehot = false, const JointSums* sums = nullptr) {
     float* wmat = joint ? p.wmat : nullptr;
     const int Upad = joint_upad(p.maxU);
     // additive joint: W and CL planes always (the DF kernel takes its label corrections from CL); small
@@ -345,12 +350,23 @@ template <typename C> static void launch_coef(Plan<C>& p, bool joint = false, bo
         const int tilesU = (p.maxU + 63) / 64, tilesN = (p.maxT + p.maxU - 1 + DN - 1) / DN;
         for (int b0 = 0; b0 < p.N; b0 += kGridSamples) {
             const dim3 cgrid(static_cast<unsigned>(tilesU * tilesN), p.N - b0 < kGridSamples ? p.N - b0 : kGridSamples);
-            hipLaunchKernelGGL((coef_kernel<C>), cgrid, dim3(256), 0, p.stream, p.lp2, p.logz, p.alpha, p.beta, p.offa,
-                               p.offb, p.llf, p.labels, p.input_lengths, p.label_lengths, p.rowtab, p.maxT, p.maxU, p.Up,
-                               wmat, Upad, tilesU, p.fastemit, planes, p.offsets, p.lat_w, p.lat_sh, b0, p.N, p.padflag);
+            if (sums != nullptr)
+                hipLaunchKernelGGL((coef_kernel<C, true>), cgrid, dim3(256), 0, p.stream, p.lp2, p.logz, p.alpha, p.beta, p.offa,
+                                   p.offb, p.llf, p.labels, p.input_lengths, p.label_lengths, p.rowtab, p.maxT, p.maxU, p.Up,
+                                   wmat, Upad, tilesU, p.fastemit, planes, p.offsets, p.lat_w, p.lat_sh, b0, p.N, p.padflag,
+                                   sums->sfb, sums->sgb, sums->sgl, sums->farflag);
+            else
+                hipLaunchKernelGGL((coef_kernel<C, false>), cgrid, dim3(256), 0, p.stream, p.lp2, p.logz, p.alpha, p.beta, p.offa,
+                                   p.offb, p.llf, p.labels, p.input_lengths, p.label_lengths, p.rowtab, p.maxT, p.maxU, p.Up,
+                                   wmat, Upad, tilesU, p.fastemit, planes, p.offsets, p.lat_w, p.lat_sh, b0, p.N, p.padflag,
+                                   static_cast<float*>(nullptr), static_cast<float*>(nullptr), static_cast<float*>(nullptr),
+                                   static_cast<int*>(nullptr));
         }
+        p.check();
+        return sums != nullptr;
     }
     p.check();
+    return false;
 }
 
 static bool bad_args(const void* acts, const int* labels, const int* label_lengths,

@@ -152,9 +152,11 @@ static rnntStatus_t run_gpu_joint(const typename Tag::store* f, const typename T
     const float* cplanes = onehot && joint_planes_onehot(maxU) == 4 ? p.wmat : nullptr;   // c / cb / cl as dense planes
     const dim3 fixgrid((maxU + 63) / 64, (maxT + kJointFixT - 1) / kJointFixT, N);
     if (do_fwd && training) {
-        launch_coef(p, /*joint=*/true, onehot);
-        hipLaunchKernelGGL(joint_sums_kernel, fixgrid, dim3(256), 0, p.stream, p.rowtab, input_lengths, label_lengths, sfb,
-                           sgb, sgl, farflag, maxT, maxU, N, cplanes, joint_upad(maxU));
+        const JointSums sums{sfb, sgb, sgl, farflag};
+        // (the tiled coefficient kernel forms the correction sums itself; the cell-per-thread form leaves them to a pass of their own)
+        if (!launch_coef(p, /*joint=*/true, onehot, tune().jfsum ? &sums : nullptr))
+            hipLaunchKernelGGL(joint_sums_kernel, fixgrid, dim3(256), 0, p.stream, p.rowtab, input_lengths, label_lengths, sfb,
+                               sgb, sgl, farflag, maxT, maxU, N, cplanes, joint_upad(maxU));
         p.check();
     }
     mark(3);

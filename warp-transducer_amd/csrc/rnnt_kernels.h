@@ -1606,17 +1606,24 @@ __global__ __launch_bounds__(256) void coef_cell_kernel(
 #ifndef COEF_KB
 #define COEF_KB 4
 #endif
-template <typename L>
-__global__ __launch_bounds__(256) void coef_kernel(
+template <typename L, bool SUMS = false>   // SUMS: additive joint, the correction sums of the gradient GEMMs' epilogues (see below)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SUMS ? 3 : 4))) void coef_kernel(
         const LogPair<L>* __restrict__ lp2, const L* __restrict__ logz, const L* __restrict__ alpha_arr,
         const L* __restrict__ beta, const double* __restrict__ offa,
         const double* __restrict__ offb, const double* __restrict__ ll_fwd,
         const int* __restrict__ labels, const int* __restrict__ xlen, const int* __restrict__ ylen,
         Cell<L>* __restrict__ rowtab, int maxT, int maxU, int Up, float* __restrict__ wmat, int Upad, int tilesU,
         float fastemit, int planes, const long long* __restrict__ offsets, int lw, int lsh, int b0, int N,
-        int* __restrict__ padflag) {
+        int* __restrict__ padflag, float* __restrict__ sfb, float* __restrict__ sgb, float* __restrict__ sgl,
+        int* __restrict__ farflag) {      // additive joint (sfb != nullptr): the correction sums of the gradient GEMMs' epilogues, see below
     constexpr int DN = sizeof(L) == 4 ? 32 : 16;           // diagonals per tile (LDS: DN * 64 records)
     __shared__ Cell<L> recs[DN][64];
+    // Additive joint: sfb[b][t] = sum_u cb(t,u), sgb[b][u] = sum_t cb(t,u), sgl[b][u] = sum_t cl(t,u) and the "has far cells"
+    // flag of the sample (rnnt_joint_kernels.h) are formed HERE, from the tile's records while they are in registers / LDS:
+    // as a kernel of its own (joint_sums_kernel, still used behind the cell-per-thread form) they were a second pass over
+    // the planes -- 0.11 ms of the 1.3 ms c4-shaped step.  Tile sums go to the side vectors as float atomics (as before).
+    __shared__ float colsum[SUMS ? 2 : 1][4][SUMS ? 64 : 1];
+    (void)colsum;
     const int b = b0 + blockIdx.y;
     const int lane = threadIdx.x & 63, wave = uniform(threadIdx.x >> 6);
     const int tu = static_cast<int>(blockIdx.x) % tilesU, tn = static_cast<int>(blockIdx.x) / tilesU;
@@ -1632,6 +1639,10 @@ __global__ __launch_bounds__(256) void coef_kernel(
         const int u = u0 + lane;
         const int uc = u < maxU ? u : maxU - 1;            // columns past the lattice fetch a valid one, their record is padding
         const double ll2 = ll_fwd[b];
+        // this wavefront's share of the tile's column sums lives in ITS slots of `colsum` (LDS read-modify-write: the kernel
+        // sits at the 128-register line of four wavefronts per SIMD), the far test in a scalar mask
+        unsigned long long far_mask = 0;
+        if constexpr (SUMS) { colsum[0][wave][lane] = 0.0f; colsum[1][wave][lane] = 0.0f; }
 #pragma unroll 1
         for (int i0 = 0; i0 < K; i0 += KB) {
             CoefRaw<L> raw[KB];
@@ -1649,10 +1660,23 @@ __global__ __launch_bounds__(256) void coef_kernel(
                 o.x = log_zero<L>(); o.y = 0; o.z = 0; o.w = static_cast<L>(kPadded);
                 if (n < D && u < maxU && t >= 0 && t < maxT) o = coef_eval<L>(raw[i], ll2, t, u, Tb, Ub, fastemit);
                 recs[dn][lane] = o;
+                if constexpr (SUMS) {
+                    colsum[0][wave][lane] += static_cast<float>(o.y);       // (padded cells carry zeros)
+                    colsum[1][wave][lane] += static_cast<float>(o.z);
+                    far_mask |= __ballot(static_cast<int>(o.w) != kPadded && static_cast<float>(o.x) > kJointFarC);
+                }
             }
         }
+        if constexpr (SUMS)
+            if (far_mask != 0 && lane == 0) farflag[b] = 1;
     }
     __syncthreads();
+    if (SUMS && wave == 0 && u0 + lane < maxU) {
+        const float cb = colsum[0][0][lane] + colsum[0][1][lane] + colsum[0][2][lane] + colsum[0][3][lane];
+        const float cl = colsum[1][0][lane] + colsum[1][1][lane] + colsum[1][2][lane] + colsum[1][3][lane];
+        if (cb != 0.0f) unsafeAtomicAdd(sgb + static_cast<size_t>(b) * maxU + u0 + lane, cb);
+        if (cl != 0.0f) unsafeAtomicAdd(sgl + static_cast<size_t>(b) * maxU + u0 + lane, cl);
+    }
     // ---- store, natural order: groups of DN lanes take one time row each
     const size_t plane = static_cast<size_t>(N) * maxT * Upad;
     constexpr int GROUPS = 256 / DN;
@@ -1663,7 +1687,15 @@ __global__ __launch_bounds__(256) void coef_kernel(
         if (t < 0 || t >= maxT) continue;
         const int ulo = n0 - t > u0 ? n0 - t : u0;         // columns of row t inside the tile
         const int u = ulo + c;
-        if (u > u0 + 63 || u >= maxU || t + u >= n0 + DN || t + u >= D) continue;
+        const bool in_run = !(u > u0 + 63 || u >= maxU || t + u >= n0 + DN || t + u >= D);
+        if constexpr (SUMS) {
+            // row sum of the blank corrections over this run of the time row: the DN lanes of the group, then one atomic
+            float rs = in_run ? static_cast<float>(recs[t + u - n0][u - u0].y) : 0.0f;
+#pragma unroll
+            for (int off = DN / 2; off > 0; off >>= 1) rs += __shfl_xor(rs, off, DN);
+            if (c == 0 && rs != 0.0f) unsafeAtomicAdd(sfb + static_cast<size_t>(b) * maxT + t, rs);
+        }
+        if (!in_run) continue;
         const Cell<L> o = recs[t + u - n0][u - u0];
         if (offsets != nullptr) {                          // packed row order: the run of a time row stays contiguous
             const size_t at = static_cast<size_t>(offsets[b]) + static_cast<size_t>(t) * Ub + u;

@@ -1,0 +1,42 @@
+"""The hand-counted vmcnt of lattice_lin_kernel's operand wavefronts (inline-asm buffer loads + s_waitcnt vmcnt(28)) is only
+right while the compiler adds no vector-memory instruction of its own to that role.  tools/check_lattice_lin_isa.py reads the
+device ISA of THIS toolchain's build and checks exactly that; here it must hold for the shipped source, and it must trip on
+ISA that has such an instruction planted (so a compiler upgrade cannot break the count silently)."""
+import os
+import shutil
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+
+@pytest.fixture(scope="module")
+def device_asm():
+    if shutil.which("hipcc") is None:
+        pytest.skip("needs hipcc")
+    import check_lattice_lin_isa as guard
+    return guard, guard.device_asm()
+
+
+def test_operand_role_holds_only_its_own_memory_instructions(device_asm):
+    guard, asm = device_asm
+    assert guard.check(asm) == []
+
+
+def test_guard_trips_on_a_planted_instruction(device_asm):
+    guard, asm = device_asm
+    lines = asm.split("\n")
+    start = next(i for i, l in enumerate(lines) if l.startswith("_ZN4rnnt18lattice_lin_kernel") and ":" in l)
+    waits = [i for i in range(start, len(lines)) if "vmcnt(%d)" % ((guard.PFD - 1) * guard.KW) in lines[i]]
+    for where, what in ((waits[2] + 5, "\tglobal_load_dword v99, v98, s[0:1]"), (waits[11] + 3, "\tscratch_load_dword v7, off, s32")):
+        bad = list(lines)
+        bad.insert(where, what)                       # what a spill reload or a re-materialised load would look like
+        probs = guard.check("\n".join(bad))
+        assert probs and any("compiler-issued" in p for p in probs), probs
+    # and on a changed request count (a ring refill the compiler dropped or duplicated)
+    req = next(i for i in range(waits[0], waits[1]) if "buffer_load_dwordx2" in lines[i])
+    bad = list(lines)
+    del bad[req]
+    assert guard.check("\n".join(bad))

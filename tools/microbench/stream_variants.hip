@@ -98,7 +98,7 @@ int main(int argc, char** argv) {
         timeit("exp_chunk U=4 grid=all", [&] { hipLaunchKernelGGL((exp_chunk<4, false, true>), dim3(chunks), dim3(256), 0, 0, in, out, npk, 0.5f); }, rw);
     }
     // (the wavefront-per-row gradient kernel this file once raced against the flat form is gone from the tree:
-    //  5.1 vs 6.4 TB/s)
+    //  5.1 vs 6.4 TB/s, EXPERIMENTS.md section 3)
     timeit("hipMemcpyDtoD", [&] { CK(hipMemcpyAsync(grads, acts, E * 4, hipMemcpyDeviceToDevice, 0)); }, rw);
     timeit("hipMemset (write only)", [&] { CK(hipMemsetAsync(grads, 0, E * 4, 0)); }, ro);
     return 0;

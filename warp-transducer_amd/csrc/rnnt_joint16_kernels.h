@@ -5,7 +5,7 @@
 //
 // rnnt_joint_kernels.h runs the three contractions (Z = Ef Eg^T, DF = Ef .* (W Eg), DG = Eg .* (W^T Ef)) on
 // v_mfma_f32_32x32x2_f32, which issues at the fp32 VALU rate and does not overlap with VALU work: with 16-bit
-// storage those kernels are bound by instruction issue, not by bytes.  Here the operands are
+// storage those kernels are bound by instruction issue, not by bytes (EXPERIMENTS.md 8).  Here the operands are
 // bf16 and the instruction is v_mfma_f32_32x32x16_bf16 (16x the multiply-accumulates per cycle), so the matrix
 // work all but disappears behind the element-wise work (one exp per element of f or g per pass) and the
 // kernels stream.  What makes that possible without an LDS transposition:

@@ -443,7 +443,7 @@ __device__ __forceinline__ void tile_reduce_words(const W* __restrict__ words, i
     m_out = m; shift_out = shift; sum_out = sum;
 }
 
-constexpr int kTileMaxRowBytes = 4096;   // (2048 until the reduce phase learned rows at any byte phase: A/B on 2-4 KB rows in DESIGN.md 3)
+constexpr int kTileMaxRowBytes = 4096;   // (2048 until the reduce phase learned rows at any byte phase: A/B on 2-4 KB rows in EXPERIMENTS.md 6)
 
 template <typename Tag, int G>
 __global__ __launch_bounds__(256) void row_stats_tile_kernel(
@@ -638,7 +638,7 @@ __global__ __launch_bounds__(256) void row_stats_tile_kernel(
 // Pass A, 2-D CELL-TILE form for short rows under wide lattices (c4: 200-byte rows, U = 301).  The flat tile kernel
 // above streams 256 consecutive rows -- less than one time row of such a lattice -- so its 256 results belong to 256
 // different anti-diagonals and leave as two scattered stores per row, 64 distinct lines per store instruction: request
-// rate, not bytes, is what bounds it there (1.05 ms as shipped, 0.90 with coalesced stores, 0.78 with
+// rate, not bytes, is what bounds it there (EXPERIMENTS.md 3: 1.05 ms as shipped, 0.90 with coalesced stores, 0.78 with
 // none).  Here a block owns TT time rows x TU label rows of ONE sample: TT contiguous pieces of TU rows each, loaded as
 // the aligned 16-byte packets that cover them (all requested before the first is stored, as above), one lane per row
 // for the reduction, and the 256 results are turned through LDS so that they leave ALONG the anti-diagonals: the

@@ -343,6 +343,9 @@ def main():
     ap.add_argument("--oversubscribe-gloo", action="store_true",
                     help="dev: the N ranks share the visible device(s) (rank r -> device r %% visible) and talk over gloo; "
                          "exercises the launcher / gather / JSON plumbing on a one-GPU box.  NOT a scaling measurement")
+    ap.add_argument("--aux-stream", action="store_true",
+                    help="hand the library a second stream (rnnt_set_aux_stream): long lattices (c4) then run the two-half "
+                         "schedule -- the lattice kernel of one half of the batch beside the streaming kernels of the other")
     ap.add_argument("--force-sharded", action="store_true",
                     help="dev: run the multi-GPU step (async entry + RCCL all-reduce) even with one rank")
     ap.add_argument("--no-full-batch", action="store_true",
@@ -409,6 +412,10 @@ def main():
 
     from warprnnt_pytorch import _lib, warp_rnnt
     lib = _lib.lib()
+    aux_stream = None
+    if args.aux_stream:
+        aux_stream = torch.cuda.Stream(dev)                       # the caller's stream: the library creates none
+        lib.rnnt_set_aux_stream(aux_stream.cuda_stream)
 
     def gather_ints(v):
         mine = torch.tensor([int(v)], dtype=torch.int64, device=meta_dev)
@@ -713,7 +720,9 @@ def main():
                                   (", VARIABLE lengths T_b~U[T/2,T] L_b~U[L/2,L]" if args.varlen else "")
                                   + (", PACKED layout (compute_rnnt_loss_packed)" if args.packed else "")
                                   + (", host costs in pinned memory" if args.pinned_costs else "")
-                                  + (", compute_rnnt_loss_async replayed from a HIP graph" if args.graph else "")),
+                                  + (", compute_rnnt_loss_async replayed from a HIP graph" if args.graph else "")
+                                  + (", second stream handed to the library (rnnt_set_aux_stream: two-half schedule on long lattices)"
+                                     if args.aux_stream else "")),
                    "global_batch": r["global_batch"], "per_gpu_batch": w["N"],
                    "parallelism": "batch-sharded x%d, one RCCL all-reduce of the summed loss" % world
                    if sharded else "single GPU"},
@@ -735,7 +744,7 @@ def main():
         traffic_file = None
         traffic_source = None
         if not sharded and not args.no_traffic_pass and not args.packed and not args.graph:
-            tail = ["--workload", args.workload]
+            tail = ["--workload", args.workload] + (["--aux-stream"] if args.aux_stream else [])
             if args.override:
                 tail += ["--override", args.override]
             if args.varlen:

@@ -464,6 +464,20 @@ rnntStatus_t compute_rnnt_loss_add_bwd_dt(const void* trans_acts,
                                           rnntOptions options,
                                           int dtype_code);
 
+/* Two-half schedule for long lattices (extension).  The alpha/beta recursion is a dependent chain: on long utterances (T + U in the
+ * thousands) it takes hundreds of microseconds during which a few small blocks hold the device and HBM idles, between the two
+ * streaming stages.  Given a SECOND stream, the one-call gradient-computing entry points above (compute_rnnt_loss and its fp64 /
+ * bf16 / fp16 / async / fastemit / sharded forms; not the two-phase pair, not score-only calls, not the packed ones) split the batch into two
+ * halves of samples and run the lattice kernel of one half on that stream while options.stream streams the other half's
+ * statistics / gradient kernels (fork and join through events; still no synchronisation, still capturable into a HIP graph, still
+ * nothing allocated: the stream is the caller's).  Results are bit-identical to the one-stream schedule.  Measured on N=64,T=1500,U=301,A=50
+ * (lattice 0.27 ms of a 3.6 ms call): 3.4-3.6 -> 3.3-3.5 ms through the one-call entries -- the lattice disappears from the critical
+ * path, the streaming kernels slow by 0.1 ms beside it -- but the forward half of a two-phase pair gets SLOWER (its second lattice
+ * has only the first half's coefficient kernel to hide behind): opt-in, for the one-call entries.  Applies to calls from the
+ * thread that set it, for lattices of 768 anti-diagonals and more and batches of two samples and more; NULL (the default)
+ * switches it off.  The stream must belong to the device of the call and must outlive the calls that use it. */
+void rnnt_set_aux_stream(CUstream stream);
+
 /* Revision of the extension entry points below (the reference's get_warprnnt_version() stays 1).
  *   3: the additive-joint entries (compute_rnnt_loss_add*) must be given a workspace sized by
  *      get_workspace_size_add(); get_workspace_size() covers the materialised entries only.

@@ -310,3 +310,74 @@ def test_wide_lattice_sweep(oracle):
         assert np.abs(grads - ref_g).max() < tol_g, (it, N, T, U, A, ul.tolist(), str(dtype))
         for b in range(N):
             assert not grads[b, tl[b]:].any() and not grads[b, :, ll[b] + 1:].any()
+
+
+@pytest.mark.parametrize("case", [((5, 790, 12, 33), torch.float32), ((4, 700, 90, 20), torch.float32), ((3, 400, 400, 9), torch.float32),
+                                  ((6, 800, 20, 1024), torch.bfloat16), ((2, 780, 5, 7), torch.float64)],
+                         ids=lambda c: "x".join(map(str, c[0])) + "-" + str(c[1]).split(".")[-1])
+def test_two_half_schedule_on_a_second_stream(oracle, case):
+    """rnnt_set_aux_stream: on long lattices the batch is split in two and the lattice kernel of one half runs on the caller's second
+    stream beside the other half's streaming kernels.  Same bits as the one-stream schedule (costs, gradients, score-only costs,
+    the two-phase pair), ragged lengths and an odd batch included; a NaN logit still poisons its own sample only; capturable."""
+    from warprnnt_pytorch import _lib, warp_rnnt
+    shape, dtype = case
+    N, T, U, A = shape
+    lib = _lib.lib()
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(sum(shape))
+    acts = torch.tensor(rng.standard_normal(shape).astype(np.float32), device=dev).to(dtype)
+    labels = torch.tensor(rng.integers(1, A, size=(N, U - 1)).astype(np.int32), device=dev)
+    tl = np.full(N, T, dtype=np.int32); ll = np.full(N, U - 1, dtype=np.int32)
+    tl[-1] = T - 7; ll[-1] = max(0, U - 3)
+    if N > 2:
+        tl[1] = T // 2
+    t_tl, t_ll = torch.tensor(tl, device=dev), torch.tensor(ll, device=dev)
+    cdt = torch.float64 if dtype == torch.float64 else torch.float32
+
+    def run(want_grad=True, two_phase=False, x=acts):
+        costs = torch.zeros(N, dtype=cdt, device=dev)
+        grads = torch.full_like(x, 7.0) if want_grad else torch.zeros(0, device=dev, dtype=dtype)
+        if two_phase:
+            ws = warp_rnnt.gpu_rnnt_fwd(x, labels, t_tl, t_ll, costs, 0, True)
+            warp_rnnt.gpu_rnnt_bwd(x, grads, None, ws, 0)
+        else:
+            warp_rnnt.gpu_rnnt_async(x, labels, t_tl, t_ll, costs, grads, 0)
+        torch.cuda.synchronize()
+        return costs.cpu().numpy(), grads.float().cpu().numpy()
+
+    modes = (("full", {}), ("score", dict(want_grad=False)), ("two", dict(two_phase=True)))
+    lib.rnnt_set_aux_stream(None)
+    ref = {k: run(**kw) for k, kw in modes}
+    bad = acts.clone(); bad[N - 1, 3, 0, 1] = float("nan")
+    ref_bad = run(x=bad)
+    side = torch.cuda.Stream(dev)
+    warp_rnnt.set_aux_stream(side)
+    try:
+        got = {k: run(**kw) for k, kw in modes}
+        got_bad = run(x=bad)
+        # capture: the second stream joins the capture through the fork event
+        costs = torch.zeros(N, dtype=cdt, device=dev); grads = torch.zeros_like(acts)
+        cap = torch.cuda.Stream(dev)
+        cap.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(cap):
+            ws = warp_rnnt.gpu_rnnt_async(acts, labels, t_tl, t_ll, costs, grads, 0)       # warm-up outside the capture
+            cap.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, stream=cap):
+                warp_rnnt.gpu_rnnt_async(acts, labels, t_tl, t_ll, costs, grads, 0, workspace=ws)
+        torch.cuda.current_stream(dev).wait_stream(cap)
+        costs.zero_(); grads.zero_()
+        graph.replay(); torch.cuda.synchronize()
+        replay = (costs.cpu().numpy(), grads.float().cpu().numpy())
+    finally:
+        warp_rnnt.set_aux_stream(None)
+    for k in ref:
+        assert np.array_equal(got[k][0], ref[k][0]) and np.array_equal(got[k][1], ref[k][1]), k
+    assert np.array_equal(replay[0], ref["full"][0]) and np.array_equal(replay[1], ref["full"][1])
+    assert np.isnan(got_bad[0][N - 1]) and np.array_equal(got_bad[0][:N - 1], ref_bad[0][:N - 1])
+    assert np.array_equal(np.isnan(got_bad[1]), np.isnan(ref_bad[1]))
+    # and the one-stream result is the oracle's (first and last sample)
+    pick = [0, N - 1]
+    rc, rg = oracle.rnnt_logits(acts[pick].double().cpu().numpy(), labels[pick].cpu().numpy(), tl[pick], ll[pick])
+    assert np.abs(got["full"][0][pick] - rc).max() <= 1e-4 * np.abs(rc).max()
+    assert np.abs(got["full"][1][pick] - rg).max() <= (1e-3 if dtype != torch.bfloat16 else 4e-3)

@@ -13,7 +13,7 @@ import torch
 from warprnnt_pytorch import RNNTLoss, warp_rnnt
 print("binding: %s (WARPRNNT_BINDING=ctypes selects the ctypes loader)" % warp_rnnt.binding())
 
-SHAPES = {"c2": (16, 150, 41, 28, torch.float32), "c3": (128, 150, 21, 5000, torch.float32),
+SHAPES = {"c2": (16, 150, 41, 28, torch.float32), "c3": (128, 150, 21, 5000, torch.float32), "c4": (64, 1500, 301, 50, torch.float32),
           "c5": (128, 200, 41, 1024, torch.bfloat16)}
 dev = torch.device("cuda:0")
 for name in sys.argv[1:] or ["c2", "c3", "c5"]:

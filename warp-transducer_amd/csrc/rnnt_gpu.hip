@@ -266,6 +266,52 @@ static HostStage* stage_acquire(size_t bytes) {
     return st;
 }
 
+// TWO-HALF SCHEDULE (long lattices).  The lattice kernel is a dependent chain -- 1800 anti-diagonals x 139 ns on
+// N=64,T=1500,U=301 = 0.27 ms during which 128 small blocks hold the device and HBM idles -- and it sits between the two
+// streaming stages.  When the caller has handed the library a second stream (rnnt_set_aux_stream: the library creates none),
+// the batch is split into two halves of samples and the lattice of one half runs on that stream WHILE the caller's stream
+// streams the other half:
+//     caller's stream:  stats(h0) | stats(h1)          | coef(h0) grad(h0)       | coef(h1) grad(h1)
+//     auxiliary stream:           | lattice(h0)        | lattice(h1)             |
+// (fork / join through four events; capturable: the auxiliary stream joins a capture through its first wait).  Samples are
+// independent and every per-sample array of the workspace is indexed by the sample, so a half is the same Plan with its
+// pointers advanced (sub_plan).  Used for lattices of kOverlapMinDiagonals diagonals and more: below, the lattice is a few
+// microseconds and the four extra launches cost more than it.
+constexpr int kOverlapMinDiagonals = 768;
+struct AuxStream {
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[4];
+    bool ready = false;
+};
+static thread_local AuxStream t_aux;            // per calling thread, like options.stream is per call
+
+static bool aux_prepare() {
+    if (t_aux.stream == nullptr) return false;
+    if (!t_aux.ready) {
+        for (auto& e : t_aux.ev)
+            if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); return false; }
+        t_aux.ready = true;
+    }
+    return true;
+}
+
+// samples [b0, b0 + n) of plan p as a plan of their own
+template <typename C> static Plan<C> sub_plan(const Plan<C>& p, int b0, int n) {
+    Plan<C> q = p;
+    const size_t Dp = lat_rows(p.maxT, p.maxU), sk = static_cast<size_t>(b0) * Dp * p.Up;
+    q.N = n;
+    q.labels = p.labels + static_cast<size_t>(b0) * (p.maxU - 1);
+    q.input_lengths = p.input_lengths + b0;
+    q.label_lengths = p.label_lengths + b0;
+    q.lp2 = p.lp2 + sk; q.logz = p.logz + sk; q.alpha = p.alpha + sk; q.beta = p.beta + sk;
+    q.rowtab = p.rowtab + static_cast<size_t>(b0) * p.cells_per_sample;
+    q.offa = p.offa + static_cast<size_t>(b0) * p.lat_w * Dp;
+    q.offb = p.offb + static_cast<size_t>(b0) * p.lat_w * Dp;
+    q.llf = p.llf + b0; q.llb = p.llb + b0; q.poison = p.poison + b0;
+    q.costs_dev = p.costs_dev + b0;
+    return q;
+}
+
 // The materialised path.  phases: bit 0 = forward part (row statistics, lattice and -- when gradients
 // are wanted -- the coefficient table), bit 1 = gradient kernel; the two-call form
 // (compute_rnnt_loss_fwd / _bwd) keeps only the workspace alive in between.  want_grad < 0: decided by
@@ -333,15 +379,59 @@ static rnntStatus_t run_gpu(const typename Tag::store* acts, typename Tag::store
         if (ranges) ranges_mark(i, do_fwd, do_bwd, kStages);
     };
 
-    mark(0);
-    if (do_fwd) launch_row_stats<Tag>(p, acts, vec_ok);
-    mark(1);
-    if (do_fwd) launch_lattice(p, training);
-    mark(2);
-    if (do_fwd && training) launch_coef(p);
-    mark(3);
-    if (do_bwd) launch_grad<Tag>(p, acts, grads, grad_scale, vec_ok);
-    mark(4);
+    // (one-call training entries only: measured slower for the forward half of a two-phase pair -- its second lattice has only
+    //  the first half's coefficient kernel to hide behind -- and not measured for score-only calls)
+    const bool overlap = do_fwd && do_bwd && N >= 2 && p.offsets == nullptr && p.maxT + p.maxU - 1 >= kOverlapMinDiagonals &&
+                         t_aux.stream != p.stream && aux_prepare();
+    if (!overlap) {
+        mark(0);
+        if (do_fwd) launch_row_stats<Tag>(p, acts, vec_ok);
+        mark(1);
+        if (do_fwd) launch_lattice(p, training);
+        mark(2);
+        if (do_fwd && training) launch_coef(p);
+        mark(3);
+        if (do_bwd) launch_grad<Tag>(p, acts, grads, grad_scale, vec_ok);
+        mark(4);
+    } else {
+        // the two-half schedule (see AuxStream above)
+        const int n0 = N / 2;
+        Plan<C> half[2] = {sub_plan(p, 0, n0), sub_plan(p, n0, N - n0)};
+        const size_t slab = static_cast<size_t>(n0) * p.cells_per_sample * A;          // elements of acts / grads in front of the second half
+        const S* acts_h[2] = {acts, acts + slab};
+        S* grads_h[2] = {grads, grads != nullptr ? grads + slab : nullptr};
+        const C* scale_h[2] = {grad_scale, grad_scale != nullptr ? grad_scale + n0 : nullptr};
+        hipStream_t aux = t_aux.stream;
+        auto pev = [&](hipEvent_t e, hipStream_t st) { if (prof) (void)hipEventRecord(e, st); };
+        if (ranges) (void)g_ranges.push("warprnnt:two_half_schedule");
+        for (int h = 0; h < 2; ++h) {
+            pev(g_prof.hev[h][0], p.stream);
+            launch_row_stats<Tag>(half[h], acts_h[h], vec_ok);
+            pev(g_prof.hev[h][1], p.stream);
+            if (hipEventRecord(t_aux.ev[2 * h], p.stream) != hipSuccess || hipStreamWaitEvent(aux, t_aux.ev[2 * h], 0) != hipSuccess)
+                half[h].failed = true;
+            // (the lattice kernel zeroes the batch's "has padding" word when it starts: only the first half's may -- the
+            //  second runs beside the first half's coefficient kernel, which sets it -- so it gets a word of its own to clear)
+            Plan<C> lat = half[h];
+            lat.stream = aux;
+            if (h == 1) lat.padflag = p.padflag + 1;
+            pev(g_prof.lev[h][0], aux);
+            launch_lattice(lat, training);
+            pev(g_prof.lev[h][1], aux);
+            if (lat.failed || hipEventRecord(t_aux.ev[2 * h + 1], aux) != hipSuccess) half[h].failed = true;
+        }
+        for (int h = 0; h < 2; ++h) {
+            if (hipStreamWaitEvent(p.stream, t_aux.ev[2 * h + 1], 0) != hipSuccess) half[h].failed = true;   // the join
+            pev(g_prof.hev[h][2], p.stream);
+            if (training) launch_coef(half[h]);
+            pev(g_prof.hev[h][3], p.stream);
+            if (do_bwd) launch_grad<Tag>(half[h], acts_h[h], grads_h[h], scale_h[h], vec_ok);
+            pev(g_prof.hev[h][4], p.stream);
+            p.failed = p.failed || half[h].failed;
+        }
+        if (ranges) (void)g_ranges.pop();
+        if (prof) { g_prof.split = true; g_prof.has_fwd = true; g_prof.has_bwd = do_bwd; }
+    }
     if (p.failed) return RNNT_STATUS_EXECUTION_FAILED;
 
     if (costs_host) {
@@ -716,6 +806,8 @@ rnntStatus_t compute_rnnt_loss_packed_bwd(const void* activations, void* gradien
     return run_async(activations, gradients, nullptr, nullptr, nullptr, alphabet_size, minibatch, nullptr,
                      grad_scale_device, workspace, options, dtype_code, 2, 1, 0.0f, row_offsets, total_rows);
 }
+
+void rnnt_set_aux_stream(CUstream stream) { t_aux.stream = reinterpret_cast<hipStream_t>(stream); }
 
 int rnnt_host_staging(int mode) {
     const int before = stage_enabled() ? 1 : 0;

@@ -80,6 +80,11 @@ struct Profile {
     int calls = 0;
     bool pending = false;   // events of an asynchronous call recorded, not yet read
     bool has_fwd = false, has_bwd = false;
+    // A call in the two-half schedule (rnnt_set_aux_stream, run_gpu) records these instead of ev[1..4]: on the caller's stream
+    // h0 / h1 = {before the half's statistics, after them, before its coefficients, after them, after its gradient kernel};
+    // on the auxiliary stream the start and end of each half's lattice kernel.
+    bool split = false;
+    hipEvent_t hev[2][5], lev[2][2];
 };
 extern Profile g_prof;     // one instance for the library (defined in rnnt_gpu.hip)
 extern std::mutex g_prof_mu;   // held by a profiled call from its first event record to its last, and by the
@@ -92,6 +97,8 @@ static bool prof_prepare(bool locked) {
     if (!g_prof.ready) {
         for (auto& e : g_prof.ev)
             if (hipEventCreate(&e) != hipSuccess) return false;
+        for (auto& h : g_prof.hev) for (auto& e : h) if (hipEventCreate(&e) != hipSuccess) return false;
+        for (auto& h : g_prof.lev) for (auto& e : h) if (hipEventCreate(&e) != hipSuccess) return false;
         g_prof.ready = true;
     }
     return true;
@@ -110,6 +117,26 @@ static void prof_mark(int i, bool do_fwd, bool do_bwd, hipStream_t stream) {
 
 static inline void prof_accumulate() {
     float ms = 0.f;
+    if (g_prof.split) {
+        // two-half schedule: statistics, coefficients and gradient = the sums over the halves (they run back to back on the
+        // caller's stream); lattice = what the auxiliary stream spent on it, CONCURRENTLY with the other half's streaming
+        // kernels -- it is not part of the critical path, ms[4] (first event to last) is
+        auto add = [&](double& acc, hipEvent_t a, hipEvent_t b) { if (hipEventElapsedTime(&ms, a, b) == hipSuccess) acc += ms; };
+        for (int h = 0; h < 2; ++h) {
+            add(g_prof.ms[0], g_prof.hev[h][0], g_prof.hev[h][1]);
+            add(g_prof.ms[1], g_prof.lev[h][0], g_prof.lev[h][1]);
+            if (g_prof.has_fwd && g_prof.has_bwd) {
+                add(g_prof.ms[2], g_prof.hev[h][2], g_prof.hev[h][3]);
+                add(g_prof.ms[3], g_prof.hev[h][3], g_prof.hev[h][4]);
+            } else if (g_prof.has_fwd) {
+                add(g_prof.ms[2], g_prof.hev[h][2], g_prof.hev[h][3]);
+            }
+        }
+        add(g_prof.ms[4], g_prof.hev[0][0], g_prof.hev[1][g_prof.has_bwd ? 4 : 3]);
+        g_prof.calls++;
+        g_prof.pending = g_prof.has_fwd = g_prof.has_bwd = g_prof.split = false;
+        return;
+    }
     if (g_prof.has_fwd)
         for (int i = 0; i < 3; ++i)
             if (hipEventElapsedTime(&ms, g_prof.ev[i], g_prof.ev[i + 1]) == hipSuccess) g_prof.ms[i] += ms;

@@ -122,7 +122,7 @@ def _apply(acts, labels, act_lens, label_lens, blank, reduction, fastemit_lambda
     there (warp_rnnt.binding() == 'ext': checks, allocations, both library calls and the reduction without returning to
     Python); everything else -- the CPU location, WARPRNNT_SYNC_API=1, the ctypes binding -- through `_RNNT` above.
     Same values either way (tests run both)."""
-    ext = warp_rnnt._EXT
+    ext = getattr(warp_rnnt, "_EXT", None)        # (tests swap in the reference's own extension module, which has none)
     if ext is not None and acts.is_cuda and _ASYNC_GPU and reduction in _REDUCTIONS:
         return ext.rnnt_loss(acts, labels, act_lens, label_lens, int(blank), _REDUCTIONS[reduction], float(fastemit_lambda),
                              bool(validate))

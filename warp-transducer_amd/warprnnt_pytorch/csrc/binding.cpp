@@ -17,7 +17,9 @@
 #include <c10/hip/HIPStream.h>
 #include <hip/hip_runtime_api.h>
 
+#include <atomic>
 #include <cstdio>
+#include <cstdlib>
 #include <mutex>
 #include <string>
 #include <unordered_map>

@@ -37,6 +37,15 @@ _DT = {torch.float32: (_lib.DT_F32, 4), torch.float64: (_lib.DT_F64, 8),
        torch.bfloat16: (_lib.DT_BF16, 2), torch.float16: (_lib.DT_F16, 2)}
 
 
+def set_aux_stream(stream):
+    """Hand the library a second stream (a torch.cuda.Stream of the tensors' device, or None to take it back) for the CALLING
+    thread: on long lattices (768 anti-diagonals and more, two samples and more) the one-call entries then run the lattice
+    kernel of one half of the batch on it beside the streaming kernels of the other half (include/rnnt.h: rnnt_set_aux_stream;
+    same bits; measured on N=64,T=1500,U=301,A=50: 3.4-3.6 -> 3.3-3.5 ms through compute_rnnt_loss, but SLOWER through the
+    two-phase pair the autograd wrappers use -- 3.60 -> 3.95 ms -- which is why no wrapper sets it on its own)."""
+    _lib.lib().rnnt_set_aux_stream(None if stream is None else stream.cuda_stream)
+
+
 def binding():
     """'ext' (the compiled PyTorch extension module) or 'ctypes'."""
     return "ext" if _EXT is not None else "ctypes"

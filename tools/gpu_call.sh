@@ -17,3 +17,6 @@ python tools/autograd_bench.py c2 c3 c5 2>&1 | grep -v amdgpu.ids > gpurun_out/$
 ( cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/profj && rocprofv3 --kernel-trace --stats -d /tmp/profj -o trace -- python $OLDPWD/tools/add_network_bench.py --bf16 c3 > /dev/null 2>&1; db=$(find /tmp/profj -name "*.db" | head -1); [ -n "$db" ] && python $OLDPWD/tools/rocpd_summary.py "$db" "$TAG additive joint, bf16 storage, c3 shape: rocprofv3 --kernel-trace --stats -- python tools/add_network_bench.py --bf16 c3" > $OLDPWD/gpurun_out/${TAG}_add_bf16_c3_kernel_trace.md )
 python bench.py --workload c5 --force-sharded --no-cpu-baseline --no-traffic-pass > gpurun_out/${TAG}_bench_c5_sharded_one_rank.json 2> /dev/null
 python bench.py --workload c2 --pinned-costs --no-cpu-baseline --no-traffic-pass > gpurun_out/${TAG}_bench_c2_pinned.json 2> /dev/null
+python bench.py --workload c4 --aux-stream --steps 50 --no-cpu-baseline --no-traffic-pass > gpurun_out/${TAG}_bench_c4_aux_stream.json 2> /dev/null
+python bench.py --gpus 2 --oversubscribe-gloo --steps 5 --warmup 2 > gpurun_out/${TAG}_bench_2ranks_oversubscribed.json 2> /dev/null
+( cd /tmp && bash $OLDPWD/tools/joint_c4_profile.sh $TAG > /dev/null 2>&1 )

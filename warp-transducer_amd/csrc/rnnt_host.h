@@ -208,10 +208,11 @@ static void ranges_mark(int i, bool do_fwd, bool do_bwd, const char* const names
 // latlin = linear-domain lattice kernel (chain + helper wavefronts) for one-wavefront fp32 lattices: 0 off, 1 up to one block per CU,
 //          2 at any size and every block takes the log-domain fallback (tests), 3 at any size,
 // tile2d = 2-D cell-tile statistics kernel for short rows under wide lattices on/off,
-// jfsum = additive joint: the correction sums of the gradient GEMMs formed inside the tiled coefficient kernel on/off.
+// jfsum = additive joint: the correction sums of the gradient GEMMs formed inside the tiled coefficient kernel on/off,
+// jsplit = additive joint, small vocabularies: the wavefronts of a DF / DG block split the contraction instead of the columns on/off.
 struct Tune { int sw = 4, nta = 1, gmax = 4194304, rows = 0, tile = 1, tilekb = 52, ppt = 2;
               int jfnk = 0, jfpf = 1, jgnk = 0, jgpf = 1, blk = 1, jzs = 0, xcd = 1, ctile = 1, pskip = 1, joh = -1;
-              int lat2 = -1, xst = 0, jsamp = 1, tilemax = kTileMaxRowBytes, j16 = 7, j16pf = 1, j16nt = 4, tile2d = 1, latlin = 1, pskipb = 8192, pskipmin = 2048, jfsum = 1; };
+              int lat2 = -1, xst = 0, jsamp = 1, tilemax = kTileMaxRowBytes, j16 = 7, j16pf = 1, j16nt = 4, tile2d = 1, latlin = 1, pskipb = 8192, pskipmin = 2048, jfsum = 1, jsplit = 1; };
 #ifdef RNNT_DEV
 static Tune read_tune() {
     Tune t;
@@ -222,7 +223,7 @@ static Tune read_tune() {
         {"tilekb", &t.tilekb}, {"ppt", &t.ppt}, {"jfnk", &t.jfnk}, {"jfpf", &t.jfpf}, {"jgnk", &t.jgnk},
         {"jgpf", &t.jgpf}, {"blk", &t.blk}, {"jzs", &t.jzs}, {"xcd", &t.xcd}, {"ctile", &t.ctile},
         {"pskip", &t.pskip}, {"joh", &t.joh}, {"lat2", &t.lat2}, {"xst", &t.xst}, {"jsamp", &t.jsamp}, {"tilemax", &t.tilemax},
-        {"j16", &t.j16}, {"j16pf", &t.j16pf}, {"j16nt", &t.j16nt}, {"tile2d", &t.tile2d}, {"latlin", &t.latlin}, {"pskipb", &t.pskipb}, {"pskipmin", &t.pskipmin}, {"jfsum", &t.jfsum}};
+        {"j16", &t.j16}, {"j16pf", &t.j16pf}, {"j16nt", &t.j16nt}, {"tile2d", &t.tile2d}, {"latlin", &t.latlin}, {"pskipb", &t.pskipb}, {"pskipmin", &t.pskipmin}, {"jfsum", &t.jfsum}, {"jsplit", &t.jsplit}};
     // tokens are separated by ',', a token is key=value with the WHOLE key compared
     for (const char* p = e; *p;) {
         const char* end = strchr(p, ',');

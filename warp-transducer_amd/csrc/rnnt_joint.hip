@@ -172,6 +172,18 @@ static rnntStatus_t run_gpu_joint(const typename Tag::store* f, const typename T
         const Tune& tn = tune();
         auto pick = [&](int want) { int nk = want > 0 ? want : NKmax; while (nk > NKmax) nk >>= 1; return nk; };
         const int NKf = pick(tn.jfnk), NKg = pick(tn.jgnk);
+        // small vocabularies (one or two column groups): the four wavefronts of a block split the CONTRACTION instead of the
+        // columns (joint_df_kernel, SPLIT) -- when it is long enough to be worth the reduction
+        const bool split_f = tn.jsplit && (A + 32 * NKf - 1) / (32 * NKf) <= 2 && maxU >= 64;
+        const bool split_g = tn.jsplit && (A + 32 * NKg - 1) / (32 * NKg) <= 2 && maxT >= 64;
+#define RNNT_JDF_SPLIT(NN, OO)                                                                                   \
+    hipLaunchKernelGGL((joint_df_kernel<Tag, NN, true, OO, true>), dim3((A + 32 * NN - 1) / (32 * NN), tilesT, N), dim3(256), 0, \
+                       p.stream, f, g, p.rowmax, p.wmat, grad_scale, labels, input_lengths, label_lengths, df, maxT,  \
+                       maxU, Upad, A, N, p.blank, sfb)
+#define RNNT_JDG_SPLIT(NN)                                                                                       \
+    hipLaunchKernelGGL((joint_dg_kernel<Tag, NN, true, true>), dim3((A + 32 * NN - 1) / (32 * NN), tilesU, N), dim3(256), 0, \
+                       p.stream, f, g, p.rowmax, p.wmat, grad_scale, input_lengths, label_lengths, dg, maxT,     \
+                       maxU, Upad, A, N, labels, p.blank, sgb, sgl)
 #define RNNT_JDF(NN, PP, OO)                                                                                     \
     hipLaunchKernelGGL((joint_df_kernel<Tag, NN, PP, OO>), dim3((A + 128 * NN - 1) / (128 * NN), tilesT, N), dim3(256), 0, \
                        p.stream, f, g, p.rowmax, p.wmat, grad_scale, labels, input_lengths, label_lengths, df, maxT,  \
@@ -197,6 +209,8 @@ static rnntStatus_t run_gpu_joint(const typename Tag::store* f, const typename T
             }
         }
         if (df16) { /* launched above */ }
+        else if (split_f && onehot) { if (NKf == 4) RNNT_JDF_SPLIT(4, true); else if (NKf == 2) RNNT_JDF_SPLIT(2, true); else RNNT_JDF_SPLIT(1, true); }
+        else if (split_f) { if (NKf == 4) RNNT_JDF_SPLIT(4, false); else if (NKf == 2) RNNT_JDF_SPLIT(2, false); else RNNT_JDF_SPLIT(1, false); }
         else if (onehot)  { if (NKf == 4) RNNT_JDF(4, true, true); else if (NKf == 2) RNNT_JDF(2, true, true); else RNNT_JDF(1, true, true); }
         else if (pf_f) { if (NKf == 4) RNNT_JDF(4, true, false); else if (NKf == 2) RNNT_JDF(2, true, false); else RNNT_JDF(1, true, false); }
         else              { if (NKf == 4) RNNT_JDF(4, false, false); else if (NKf == 2) RNNT_JDF(2, false, false); else RNNT_JDF(1, false, false); }
@@ -215,10 +229,13 @@ static rnntStatus_t run_gpu_joint(const typename Tag::store* f, const typename T
             }
         }
         if (dg16) { /* launched above */ }
+        else if (split_g) { if (NKg == 4) RNNT_JDG_SPLIT(4); else if (NKg == 2) RNNT_JDG_SPLIT(2); else RNNT_JDG_SPLIT(1); }
         else if (pf_g) { if (NKg == 4) RNNT_JDG(4, true); else if (NKg == 2) RNNT_JDG(2, true); else RNNT_JDG(1, true); }
         else         { if (NKg == 4) RNNT_JDG(4, false); else if (NKg == 2) RNNT_JDG(2, false); else RNNT_JDG(1, false); }
 #undef RNNT_JDF
 #undef RNNT_JDG
+#undef RNNT_JDF_SPLIT
+#undef RNNT_JDG_SPLIT
         p.check();
         hipLaunchKernelGGL((joint_far_kernel<Tag>), fixgrid, dim3(256), 0, p.stream, f, g, p.rowmax, p.rowtab, grad_scale,
                            input_lengths, label_lengths, farflag, df, dg, maxT, maxU, A, N, cplanes, Upad);

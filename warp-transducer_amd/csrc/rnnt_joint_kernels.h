@@ -718,22 +718,50 @@ __device__ __forceinline__ void joint_mma(const JointOperands<NK>& s, f32x16 (&a
             acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(s.w[i], joint_exp(s.x[i][n], s.m[i]), acc[n], 0, 0, 0);
 }
 
+// SPLIT (small vocabularies): when the whole vocabulary fits one or two column groups, three of a block's four wavefronts
+// have no columns of their own -- and the one that works runs the WHOLE contraction alone, a chain of dependent operand
+// round trips (c4 shape, A = 50: DF 204 us with 3008 working wavefronts, DG 131 us with 640).  In this mode the four
+// wavefronts share ONE column group and each takes every fourth step of the contraction; the partial accumulators meet in
+// LDS (one wavefront's worth at a time, deterministic order 0 + 1 + 2 + 3) and wavefront 0 runs the epilogue.
+// grid.x = ceil(A / (32 NK)).
+template <int NV>
+__device__ __forceinline__ void joint_reduce_waves(f32x16 (&acc)[NV], float* __restrict__ red, int wave, int lane) {
+    for (int w = 1; w < 4; ++w) {
+        if (wave == w) {
+#pragma unroll
+            for (int n = 0; n < NV; ++n)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) red[(n * 16 + r) * 64 + lane] = acc[n][r];
+        }
+        __syncthreads();
+        if (wave == 0) {
+#pragma unroll
+            for (int n = 0; n < NV; ++n)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[n][r] += red[(n * 16 + r) * 64 + lane];
+        }
+        __syncthreads();
+    }
+}
+
 // OH (small vocabularies): the blank / label corrections of df are accumulated here as well,
 //     acc2 += CB[t][u] * [k == blank] + CL[t][u] * [k == y_u]       (two more MFMAs per step, one-hot B operands),
 // from the dense CB / CL planes the coefficient kernel writes next to W.  It replaces one global atomic per
 // lattice cell (the first version's fix-up kernel), which all land on the few cache lines of a short df row (c4 shape,
 // A = 50: 340 us of atomics against ~100 us of extra matrix work); above a few hundred symbols the atomics
 // are cheaper than the 3x contraction and the host keeps them.
-template <typename Tag, int NK, bool PF, bool OH>   // PF: operand ping-pong + epilogue values requested before the loop (more registers)
+template <typename Tag, int NK, bool PF, bool OH, bool SPLIT = false>   // PF: operand ping-pong + epilogue values requested before the loop (more registers)
 __global__ __launch_bounds__(256) void joint_df_kernel(
         const typename Tag::store* __restrict__ f, const typename Tag::store* __restrict__ g, const float* __restrict__ rowmax,
         const float* __restrict__ wmat, const float* __restrict__ scale, const int* __restrict__ labels,
         const int* __restrict__ xlen, const int* __restrict__ ylen, typename Tag::store* __restrict__ df, int maxT, int maxU,
         int Upad, int A, int N, int blank, const float* __restrict__ sfb) {
+    __shared__ float red[SPLIT ? NK * 16 * 64 : 1];
+    (void)red;
     const int b = blockIdx.z;
     const int lane = threadIdx.x & 63, wave = uniform(threadIdx.x >> 6), half = lane >> 5, col = lane & 31;
-    const int k0 = (static_cast<int>(blockIdx.x) * 4 + wave) * (32 * NK);
-    if (k0 >= A) return;
+    const int k0 = SPLIT ? static_cast<int>(blockIdx.x) * (32 * NK) : (static_cast<int>(blockIdx.x) * 4 + wave) * (32 * NK);
+    if (k0 >= A) return;                                   // (SPLIT: block-uniform)
     const int kc = k0 + NK * col;                          // first of this lane's NK columns
     const bool kin = kc < A;                               // A % NK == 0: all NK columns or none
     const int t0 = blockIdx.y * 32;
@@ -754,7 +782,7 @@ __global__ __launch_bounds__(256) void joint_df_kernel(
         for (int r = 0; r < 16; ++r) acc2[n][r] = 0.0f;
 
     if (t0 >= Tb) {                                        // time rows of the padding: zeros
-        if (!kin) return;
+        if (!kin || (SPLIT && wave != 0)) return;
         float z[NK];
 #pragma unroll
         for (int n = 0; n < NK; ++n) z[n] = 0.0f;
@@ -827,7 +855,30 @@ __global__ __launch_bounds__(256) void joint_df_kernel(
             joint_loadv<Tag, NK>(fb + static_cast<unsigned>(ts) * Au, fv[r]);
         }
     };
-    if constexpr (PF) {
+    if constexpr (SPLIT) {
+        // this wavefront's steps of the contraction: u2 = 8 (wave + 4 j); operand ping-pong as below
+        constexpr int ST = 32;
+        int u2 = 8 * wave;
+        JointOperands<NK> s0, s1;
+        if (u2 < Ub) load(s0, u2);
+        if (wave == 0) load_f();                           // the epilogue is wavefront 0's
+        __builtin_amdgcn_sched_barrier(0);
+        while (u2 + ST < Ub) {
+            load(s1, u2 + ST);
+            __builtin_amdgcn_sched_barrier(0);
+            joint_mma<NK>(s0, acc); corr(s0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (u2 + 2 * ST < Ub) load(s0, u2 + 2 * ST);   // (wave-uniform)
+            __builtin_amdgcn_sched_barrier(0);
+            joint_mma<NK>(s1, acc); corr(s1);
+            __builtin_amdgcn_sched_barrier(0);
+            u2 += 2 * ST;
+        }
+        if (u2 < Ub) { joint_mma<NK>(s0, acc); corr(s0); }
+        joint_reduce_waves<NK>(acc, red, wave, lane);
+        if constexpr (OH) joint_reduce_waves<NK>(acc2, red, wave, lane);
+        if (wave != 0) return;
+    } else if constexpr (PF) {
         JointOperands<NK> s0, s1;
         load(s0, 0);
         load_f();                                          // requested now, consumed after the contraction
@@ -941,16 +992,18 @@ __global__ __launch_bounds__(256) void joint_df_kernel(
 // A operand = W[t][u0+col] (coalesced along u), B operand = exp(f[t,k] - mf[t]), the streaming
 // read of f, again with two alternating operand sets.
 // grid = (ceil(A / (128 NK)), ceil(maxU/32), N), block = 256.
-template <typename Tag, int NK, bool PF>
+template <typename Tag, int NK, bool PF, bool SPLIT = false>      // SPLIT: see joint_df_kernel
 __global__ __launch_bounds__(256) void joint_dg_kernel(
         const typename Tag::store* __restrict__ f, const typename Tag::store* __restrict__ g, const float* __restrict__ rowmax,
         const float* __restrict__ wmat, const float* __restrict__ scale, const int* __restrict__ xlen,
         const int* __restrict__ ylen, typename Tag::store* __restrict__ dg, int maxT, int maxU, int Upad, int A, int N,
         const int* __restrict__ labels, int blank, const float* __restrict__ sgb, const float* __restrict__ sgl) {
+    __shared__ float red[SPLIT ? NK * 16 * 64 : 1];
+    (void)red;
     const int b = blockIdx.z;
     const int lane = threadIdx.x & 63, wave = uniform(threadIdx.x >> 6), half = lane >> 5, col = lane & 31;
-    const int k0 = (static_cast<int>(blockIdx.x) * 4 + wave) * (32 * NK);
-    if (k0 >= A) return;
+    const int k0 = SPLIT ? static_cast<int>(blockIdx.x) * (32 * NK) : (static_cast<int>(blockIdx.x) * 4 + wave) * (32 * NK);
+    if (k0 >= A) return;                                   // (SPLIT: block-uniform)
     const int kc = k0 + NK * col;
     const bool kin = kc < A;
     const int u0 = blockIdx.y * 32;
@@ -981,7 +1034,24 @@ __global__ __launch_bounds__(256) void joint_dg_kernel(
                 joint_loadv<Tag, NK>(fb + ts * Au, s.x[i]);
             }
         };
-        if constexpr (PF) {
+        if constexpr (SPLIT) {
+            constexpr int ST = 32;                             // this wavefront's steps: t2 = 8 (wave + 4 j)
+            int t2 = 8 * wave;
+            JointOperands<NK> s0, s1;
+            if (t2 < Tb) load(s0, t2);
+            while (t2 + ST < Tb) {
+                load(s1, t2 + ST);
+                __builtin_amdgcn_sched_barrier(0);
+                joint_mma<NK>(s0, acc);
+                __builtin_amdgcn_sched_barrier(0);
+                if (t2 + 2 * ST < Tb) load(s0, t2 + 2 * ST);
+                __builtin_amdgcn_sched_barrier(0);
+                joint_mma<NK>(s1, acc);
+                __builtin_amdgcn_sched_barrier(0);
+                t2 += 2 * ST;
+            }
+            if (t2 < Tb) joint_mma<NK>(s0, acc);
+        } else if constexpr (PF) {
             JointOperands<NK> s0, s1;
             load(s0, 0);
             int t2 = 0;
@@ -1006,6 +1076,10 @@ __global__ __launch_bounds__(256) void joint_dg_kernel(
                 joint_mma<NK>(s1, acc);
             }
         }
+    }
+    if constexpr (SPLIT) {
+        joint_reduce_waves<NK>(acc, red, wave, lane);          // (every wavefront of the block gets here: u0 < Ub is block-uniform)
+        if (wave != 0) return;
     }
     if (!kin) return;
     const float sc = scale != nullptr ? scale[b] : 1.0f;   // per-sample factor, applied once per output

@@ -1607,7 +1607,7 @@ __global__ __launch_bounds__(256) void coef_cell_kernel(
 #define COEF_KB 4
 #endif
 template <typename L, bool SUMS = false>   // SUMS: additive joint, the correction sums of the gradient GEMMs' epilogues (see below)
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SUMS ? 3 : 4))) void coef_kernel(
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void coef_kernel(
         const LogPair<L>* __restrict__ lp2, const L* __restrict__ logz, const L* __restrict__ alpha_arr,
         const L* __restrict__ beta, const double* __restrict__ offa,
         const double* __restrict__ offb, const double* __restrict__ ll_fwd,
@@ -1622,8 +1622,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SUMS ? 3 : 
     // flag of the sample (rnnt_joint_kernels.h) are formed HERE, from the tile's records while they are in registers / LDS:
     // as a kernel of its own (joint_sums_kernel, still used behind the cell-per-thread form) they were a second pass over
     // the planes -- 0.11 ms of the 1.3 ms c4-shaped step.  Tile sums go to the side vectors as float atomics (as before).
-    __shared__ float colsum[SUMS ? 2 : 1][4][SUMS ? 64 : 1];
-    (void)colsum;
+
     const int b = b0 + blockIdx.y;
     const int lane = threadIdx.x & 63, wave = uniform(threadIdx.x >> 6);
     const int tu = static_cast<int>(blockIdx.x) % tilesU, tn = static_cast<int>(blockIdx.x) / tilesU;
@@ -1639,10 +1638,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SUMS ? 3 : 
         const int u = u0 + lane;
         const int uc = u < maxU ? u : maxU - 1;            // columns past the lattice fetch a valid one, their record is padding
         const double ll2 = ll_fwd[b];
-        // this wavefront's share of the tile's column sums lives in ITS slots of `colsum` (LDS read-modify-write: the kernel
-        // sits at the 128-register line of four wavefronts per SIMD), the far test in a scalar mask
-        unsigned long long far_mask = 0;
-        if constexpr (SUMS) { colsum[0][wave][lane] = 0.0f; colsum[1][wave][lane] = 0.0f; }
 #pragma unroll 1
         for (int i0 = 0; i0 < K; i0 += KB) {
             CoefRaw<L> raw[KB];
@@ -1660,22 +1655,43 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SUMS ? 3 : 
                 o.x = log_zero<L>(); o.y = 0; o.z = 0; o.w = static_cast<L>(kPadded);
                 if (n < D && u < maxU && t >= 0 && t < maxT) o = coef_eval<L>(raw[i], ll2, t, u, Tb, Ub, fastemit);
                 recs[dn][lane] = o;
-                if constexpr (SUMS) {
-                    colsum[0][wave][lane] += static_cast<float>(o.y);       // (padded cells carry zeros)
-                    colsum[1][wave][lane] += static_cast<float>(o.z);
-                    far_mask |= __ballot(static_cast<int>(o.w) != kPadded && static_cast<float>(o.x) > kJointFarC);
-                }
             }
         }
-        if constexpr (SUMS)
-            if (far_mask != 0 && lane == 0) farflag[b] = 1;
     }
     __syncthreads();
-    if (SUMS && wave == 0 && u0 + lane < maxU) {
-        const float cb = colsum[0][0][lane] + colsum[0][1][lane] + colsum[0][2][lane] + colsum[0][3][lane];
-        const float cl = colsum[1][0][lane] + colsum[1][1][lane] + colsum[1][2][lane] + colsum[1][3][lane];
-        if (cb != 0.0f) unsafeAtomicAdd(sgb + static_cast<size_t>(b) * maxU + u0 + lane, cb);
-        if (cl != 0.0f) unsafeAtomicAdd(sgl + static_cast<size_t>(b) * maxU + u0 + lane, cl);
+    if constexpr (SUMS) {
+        // passes of their own over the records in LDS (inside the compute phase or the store loop the sums cost the kernel
+        // its fourth wavefront per SIMD: it sits at the 128-register line).  Wavefront 0: the tile's column sums of cb and
+        // cl and the far test, one column per lane (padded cells carry zeros)
+        if (wave == 0) {
+            float cb = 0.0f, cl = 0.0f;
+            bool far = false;
+#pragma unroll 4
+            for (int dn = 0; dn < DN; ++dn) {
+                const Cell<L> o = recs[dn][lane];
+                cb += static_cast<float>(o.y);
+                cl += static_cast<float>(o.z);
+                far |= static_cast<int>(o.w) != kPadded && static_cast<float>(o.x) > kJointFarC;
+            }
+            if (u0 + lane < maxU) {
+                if (cb != 0.0f) unsafeAtomicAdd(sgb + static_cast<size_t>(b) * maxU + u0 + lane, cb);
+                if (cl != 0.0f) unsafeAtomicAdd(sgl + static_cast<size_t>(b) * maxU + u0 + lane, cl);
+            }
+            if (__ballot(far) != 0 && lane == 0) farflag[b] = 1;
+        }
+        // wavefronts 1 .. 2: row sums of the blank corrections, one thread per time row that meets the tile walks its run
+        const int r = static_cast<int>(threadIdx.x) - 64;
+        const int t = n0 - (u0 + 63) + r;
+        if (r >= 0 && r < DN + 63 && t >= 0 && t < maxT) {
+            const int ulo = n0 - t > u0 ? n0 - t : u0;
+            int uhi = n0 + DN - 1 - t;                                      // last column of the run
+            if (uhi > u0 + 63) uhi = u0 + 63;
+            if (uhi > maxU - 1) uhi = maxU - 1;
+            if (uhi > D - 1 - t) uhi = D - 1 - t;
+            float rs = 0.0f;
+            for (int u = ulo; u <= uhi; ++u) rs += static_cast<float>(recs[t + u - n0][u - u0].y);
+            if (rs != 0.0f) unsafeAtomicAdd(sfb + static_cast<size_t>(b) * maxT + t, rs);
+        }
     }
     // ---- store, natural order: groups of DN lanes take one time row each
     const size_t plane = static_cast<size_t>(N) * maxT * Upad;
@@ -1687,15 +1703,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SUMS ? 3 : 
         if (t < 0 || t >= maxT) continue;
         const int ulo = n0 - t > u0 ? n0 - t : u0;         // columns of row t inside the tile
         const int u = ulo + c;
-        const bool in_run = !(u > u0 + 63 || u >= maxU || t + u >= n0 + DN || t + u >= D);
-        if constexpr (SUMS) {
-            // row sum of the blank corrections over this run of the time row: the DN lanes of the group, then one atomic
-            float rs = in_run ? static_cast<float>(recs[t + u - n0][u - u0].y) : 0.0f;
-#pragma unroll
-            for (int off = DN / 2; off > 0; off >>= 1) rs += __shfl_xor(rs, off, DN);
-            if (c == 0 && rs != 0.0f) unsafeAtomicAdd(sfb + static_cast<size_t>(b) * maxT + t, rs);
-        }
-        if (!in_run) continue;
+        if (u > u0 + 63 || u >= maxU || t + u >= n0 + DN || t + u >= D) continue;
         const Cell<L> o = recs[t + u - n0][u - u0];
         if (offsets != nullptr) {                          // packed row order: the run of a time row stays contiguous
             const size_t at = static_cast<size_t>(offsets[b]) + static_cast<size_t>(t) * Ub + u;

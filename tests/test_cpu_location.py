@@ -163,3 +163,30 @@ def test_packed_layout_on_the_cpu_location(oracle, dtype):
     assert call(offsets=bad) == 2                     # a sample whose row count is not T_b * U_b
     assert call(rows_total=0) == 2 and call(code=2) == 2 and call(lam=0.1) == 2
 
+
+
+@pytest.mark.parametrize("bad", [np.nan, np.inf, -np.inf], ids=["nan", "inf", "-inf"])
+def test_non_finite_log_probs_propagate_as_in_the_reference(oracle, bad):
+    """RNNT_CPU takes log-probs as they come (the reference's CPU contract): a NaN or +inf at a transition the lattice uses
+    makes that sample's cost NaN through log_sum_exp (include/detail/rnnt_helper.h:16-24), a -inf is a closed transition;
+    the other samples are untouched.  Same answer as the reference's own library where it has been built (oracle/_ref)."""
+    rng = np.random.default_rng(4)
+    N, T, U, A = 3, 6, 4, 7
+    lp = oracle.log_softmax(rng.standard_normal((N, T, U, A)))
+    labels = rng.integers(1, A, size=(N, U - 1)).astype(np.int32)
+    tl, ll = [T, T - 1, T], [U - 1, U - 2, U - 1]
+    c0, g0 = cpu_loss(lp, labels, tl, ll)
+    x = lp.copy()
+    x[1, 2, 1, 0] = bad                                   # the blank transition out of cell (2, 1) of sample 1
+    c, g = cpu_loss(x, labels, tl, ll)
+    assert np.array_equal(c[[0, 2]], c0[[0, 2]]) and np.array_equal(g[[0, 2]], g0[[0, 2]])
+    if bad == -np.inf:
+        assert np.isfinite(c[1]) and c[1] >= c0[1]        # a path less: the likelihood can only drop
+    else:
+        assert np.isnan(c[1])
+    rc, _ = oracle.rnnt_logprobs(x, labels, tl, ll)
+    assert np.array_equal(np.isnan(rc), np.isnan(c))
+    if oracle.have_ref():
+        fc, _ = oracle.ref_rnnt_logprobs(x, labels, tl, ll)
+        assert np.array_equal(np.isnan(fc), np.isnan(c))
+        assert np.allclose(fc[~np.isnan(fc)], c[~np.isnan(c)], rtol=1e-10)

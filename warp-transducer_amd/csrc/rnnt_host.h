@@ -212,7 +212,7 @@ static void ranges_mark(int i, bool do_fwd, bool do_bwd, const char* const names
 // jsplit = additive joint, small vocabularies: the wavefronts of a DF / DG block split the contraction instead of the columns on/off.
 struct Tune { int sw = 4, nta = 1, gmax = 4194304, rows = 0, tile = 1, tilekb = 52, ppt = 2;
               int jfnk = 0, jfpf = 1, jgnk = 0, jgpf = 1, blk = 1, jzs = 0, xcd = 1, ctile = 1, pskip = 1, joh = -1;
-              int lat2 = -1, xst = 0, jsamp = 1, tilemax = kTileMaxRowBytes, j16 = 7, j16pf = 1, j16nt = 4, tile2d = 1, latlin = 1, pskipb = 8192, pskipmin = 2048, jfsum = 1, jsplit = 1; };
+              int lat2 = -1, xst = 0, jsamp = 1, tilemax = kTileMaxRowBytes, j16 = 7, j16pf = 1, j16nt = 4, tile2d = 1, latlin = 1, pskipb = 8192, pskipmin = 128, jfsum = 1, jsplit = 1; };
 #ifdef RNNT_DEV
 static Tune read_tune() {
     Tune t;

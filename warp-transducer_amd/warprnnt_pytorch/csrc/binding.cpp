@@ -22,7 +22,8 @@
 #include <cstdlib>
 #include <mutex>
 #include <string>
-#include <unordered_map>
+#include <map>
+#include <tuple>
 
 #include "rnnt.h"
 
@@ -53,9 +54,8 @@ void check_status(rnntStatus_t st, const char* what) {
 // get_workspace_size per (T, U, N, element size): a handful of shapes per process, asked once each
 size_t workspace_bytes(int T, int U, int N, bool gpu, size_t esz) {
     static std::mutex mu;
-    static std::unordered_map<unsigned long long, size_t> cache;
-    const unsigned long long key = (static_cast<unsigned long long>(T) << 40) ^ (static_cast<unsigned long long>(U) << 28) ^
-                                   (static_cast<unsigned long long>(N) << 4) ^ (esz == 8 ? 2ull : 0ull) ^ (gpu ? 1ull : 0ull);
+    static std::map<std::tuple<int, int, int, int>, size_t> cache;
+    const auto key = std::make_tuple(T, U, N, (esz == 8 ? 2 : 0) | (gpu ? 1 : 0));
     {
         std::lock_guard<std::mutex> g(mu);
         auto it = cache.find(key);

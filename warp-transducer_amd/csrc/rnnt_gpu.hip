@@ -48,12 +48,18 @@ static void launch_row_stats(Plan<typename Tag::comp>& p, const typename Tag::st
             const unsigned xgrid = static_cast<unsigned>((ntile + 7) / 8 * 8);
             // (the 256 results overlay the tile: TT rows of TU + 1 {pair, log Z} records of the lattice type)
             const size_t lds2 = static_cast<size_t>(TT) * piece > 8192 ? static_cast<size_t>(TT) * piece : 8192;
+#ifdef RNNT_DEV
+#define RNNT_TILE2D_POISON (tn.xst == 2 ? static_cast<int*>(nullptr) : p.poison)      /* xst=2: natural-order result stores, timing only */
+#else
+#define RNNT_TILE2D_POISON p.poison
+#endif
 #define RNNT_TILE2D(T1, U1)                                                                                       \
     hipLaunchKernelGGL((row_stats_tile2d_kernel<Tag, T1, U1>), dim3(xgrid), dim3(256), lds2, p.stream, acts, p.labels, \
                        p.input_lengths, p.label_lengths, p.lp2, p.logz, p.maxT, p.maxU, p.Up, p.A, p.blank, p.N, tilesT, \
-                       tilesU, piece, p.poison)
+                       tilesU, piece, RNNT_TILE2D_POISON)
             if (sq) RNNT_TILE2D(16, 16); else RNNT_TILE2D(8, 32);
 #undef RNNT_TILE2D
+#undef RNNT_TILE2D_POISON
             p.check();
             return;
         }

@@ -645,6 +645,9 @@ __global__ __launch_bounds__(256) void row_stats_tile_kernel(
 // cells (t0 + i, u0 + d - i), i = 0 .. TT-1, of a tile's diagonal d are TT consecutive elements of a skewed row.
 // Rows are whole 8-byte words (A * s % 8 == 0, 8-byte aligned tensor); non-packed layout; LDS = TT * piece + results.
 // grid = (8 * ceil(tiles / 8), 1, 1) with tiles = N * ceil(maxT / TT) * ceil(maxU / TU), XCD-aware tile order, block = 256.
+#ifndef RNNT_TILE2D_KW
+#define RNNT_TILE2D_KW 26
+#endif
 template <typename Tag, int TT, int TU>
 __global__ __launch_bounds__(256) void row_stats_tile2d_kernel(
         const typename Tag::store* __restrict__ acts, const int* __restrict__ labels,
@@ -716,7 +719,10 @@ __global__ __launch_bounds__(256) void row_stats_tile2d_kernel(
         const char* start = base0 + static_cast<size_t>(i_row < nt ? i_row : nt - 1) * tstride;
         const int phase = static_cast<int>(reinterpret_cast<uintptr_t>(start) & 15u);
         const char* rowp = lds + static_cast<size_t>(i_row) * piece_bytes + phase + static_cast<size_t>(j_row < nu ? j_row : nu - 1) * row_bytes;
-        constexpr int KW = sizeof(S) == 2 ? kTileRegWords / 2 : kTileRegWords;
+        // one lane per row: the whole row (<= 208 bytes = 26 words) is read ONCE, back to back, into registers (LDS limits
+        // this kernel to three wavefronts per SIMD, so the 52 registers are free); with the flat tile kernel's 16 words the
+        // 25-word rows of c4 fell into the two rolled passes over LDS (12.8 VALU instructions per element)
+        constexpr int KW = RNNT_TILE2D_KW;
         tile_reduce_words<Tag, uint2, H, KW>(reinterpret_cast<const uint2*>(rowp), A / H, 0, 1, m, shift, sum,
                                              [](const uint2& w, C* v, int) { unpack_half<Tag>(w, v); });
         const C logZ = shift + fast_log(sum);
@@ -726,6 +732,14 @@ __global__ __launch_bounds__(256) void row_stats_tile2d_kernel(
         LogPair<C> rec;                                // lattice log-probs are kept in base 2
         rec.x = vmax((load1<Tag>(rp + blank) - logZ) * C(kLog2e), log_zero<C>());
         rec.y = has_lab ? vmax((load1<Tag>(rp + lab) - logZ) * C(kLog2e), log_zero<C>()) : log_zero<C>();
+#ifdef RNNT_DEV
+        // development build only (RNNT_TUNE=xst=2): timing experiment -- results stored in NATURAL row order (coalesced 32-cell
+        // runs), which the lattice kernel cannot read: the numbers that come out are WRONG
+        if (poison == nullptr) {
+            if (live) { const size_t nat = (static_cast<size_t>(b) * maxT + t) * maxU + u; lp2[nat] = rec; logz[nat] = logZ; }
+            return;
+        }
+#endif
         __syncthreads();                               // every lane is done with the tile: the results may overlay it
         if (live) {
             out_lp[i_row][j_row] = rec;

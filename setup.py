@@ -4,7 +4,8 @@
     WARP_RNNT_PATH=/dir/with/libwarprnnt.so pip install . --no-build-isolation      # a prebuilt library, as the reference asks for
 
 The installed package is self-contained: warprnnt_pytorch/{*.py, _warp_rnnt_ext*.so, lib/libwarprnnt.so, include/rnnt.h};
-no sys.path edits, no environment variables at run time (WARP_RNNT_PATH still overrides the library that is loaded).
+no sys.path edits, no environment variables at run time (a WARP_RNNT_PATH naming ANOTHER library at run time is honoured by switching to
+the ctypes loader: the compiled module is linked to the library it was built with).
 torch must be importable at build time (--no-build-isolation), exactly as for the reference's setup.py, which imports it.
 """
 import importlib.util

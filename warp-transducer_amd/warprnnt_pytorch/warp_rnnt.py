@@ -22,8 +22,15 @@ from . import _lib
 # reference (a pybind11 extension, pytorch_binding/src/binding.cpp:157-162); the ctypes route below is the fallback when it
 # has not been built, and WARPRNNT_BINDING=ctypes | ext selects one explicitly ("ext" fails loudly if it is missing).
 # Either way every call ends in the C-ABI of libwarprnnt.so: there is no Python or CPU fallback for the HIP path.
+# The compiled module is LINKED to the libwarprnnt.so it was built with (in tree: ../lib, installed: ./lib); a WARP_RNNT_PATH that
+# names another library (development builds: lib/dev) can only be honoured by the ctypes loader, so it selects that one -- two
+# copies of the library in one process would each have their own thread-local and profiling state.
 _EXT = None
 _want = _os.environ.get("WARPRNNT_BINDING", "auto").lower()
+if _want == "auto" and _os.environ.get("WARP_RNNT_PATH") and \
+        _os.path.realpath(_lib.library_path()) not in (_os.path.realpath(_os.path.join(_lib._HERE, "lib", "libwarprnnt.so")),
+                                                       _os.path.realpath(_os.path.join(_lib._HERE, "..", "lib", "libwarprnnt.so"))):
+    _want = "ctypes"
 if _want != "ctypes":
     try:
         from . import _warp_rnnt_ext as _EXT

@@ -63,6 +63,28 @@ def test_against_oracle_on_materialised_joint(oracle, shape):
         assert not df[b, tl[b]:].any() and not dg[b, ll[b] + 1:].any()
 
 
+@pytest.mark.parametrize("where", ["first", "last", "middle"])
+@pytest.mark.parametrize("shape", [(3, 70, 66, 50), (2, 40, 130, 200), (2, 33, 70, 131)])   # split contraction / 2 column groups / odd rows (one column per lane)
+def test_blank_column_from_row_sums(oracle, shape, where):
+    """fp32, U > 48, small vocabulary: the coefficient kernel writes NO cb plane; joint_df_kernel<..., BS> takes the blank
+    column's corrections from the row sums the coefficient kernel forms (rnnt_joint_kernels.h).  The blank symbol at either
+    end of the vocabulary and inside it, ragged lengths: df's blank column against the oracle on the materialised joint."""
+    f, g, labels, tl, ll, _ = problem(shape, 31 + sum(shape))
+    N, T, U, A = shape
+    blank = {"first": 0, "last": A - 1, "middle": A // 2}[where]
+    labels = np.where(labels == blank, (blank + 1) % A, labels).astype(np.int32)
+    z = f[:, :, None, :].astype(np.float64) + g[:, None, :, :].astype(np.float64)
+    ref_c, ref_gz = oracle.rnnt_logits(z, labels, tl, ll, blank)
+    costs, df, dg = run_add(f, g, labels, tl, ll, blank)
+    assert np.abs(costs - ref_c).max() <= 1e-4 * max(1.0, np.abs(ref_c).max())
+    rdf, rdg = ref_gz.sum(axis=2), ref_gz.sum(axis=1)
+    assert (np.abs(df - rdf) <= 2e-4 * max(1.0, U / 32) + 5e-5 * np.abs(rdf)).all()
+    assert (np.abs(dg - rdg) <= 2e-4 * max(1.0, T / 32) + 5e-5 * np.abs(rdg)).all()
+    assert np.abs(rdf[..., blank]).max() > 0.5          # the column under test carries real mass
+    for b in range(N):
+        assert not df[b, tl[b]:].any() and not dg[b, ll[b] + 1:].any()
+
+
 def test_equals_materialised_gpu_path():
     from warprnnt_pytorch import RNNTLoss
     f, g, labels, tl, ll, blank = problem((4, 30, 12, 300), 5)

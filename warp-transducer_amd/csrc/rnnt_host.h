@@ -209,10 +209,11 @@ static void ranges_mark(int i, bool do_fwd, bool do_bwd, const char* const names
 //          2 at any size and every block takes the log-domain fallback (tests), 3 at any size,
 // tile2d = 2-D cell-tile statistics kernel for short rows under wide lattices on/off,
 // jfsum = additive joint: the correction sums of the gradient GEMMs formed inside the tiled coefficient kernel on/off,
-// jsplit = additive joint, small vocabularies: the wavefronts of a DF / DG block split the contraction instead of the columns on/off.
+// jsplit = additive joint, small vocabularies: the wavefronts of a DF / DG block split the contraction instead of the columns on/off,
+// jnocb = additive joint, one-hot DF behind the tiled coefficient kernel: blank corrections from the row sums, no CB plane on/off.
 struct Tune { int sw = 4, nta = 1, gmax = 4194304, rows = 0, tile = 1, tilekb = 52, ppt = 2;
               int jfnk = 0, jfpf = 1, jgnk = 0, jgpf = 1, blk = 1, jzs = 0, xcd = 1, ctile = 1, pskip = 1, joh = -1;
-              int lat2 = -1, xst = 0, jsamp = 1, tilemax = kTileMaxRowBytes, j16 = 7, j16pf = 1, j16nt = 4, tile2d = 1, latlin = 1, pskipb = 8192, pskipmin = 128, jfsum = 1, jsplit = 1; };
+              int lat2 = -1, xst = 0, jsamp = 1, tilemax = kTileMaxRowBytes, j16 = 7, j16pf = 1, j16nt = 4, tile2d = 1, latlin = 1, pskipb = 8192, pskipmin = 128, jfsum = 1, jsplit = 1, jnocb = 1; };
 #ifdef RNNT_DEV
 static Tune read_tune() {
     Tune t;
@@ -223,7 +224,7 @@ static Tune read_tune() {
         {"tilekb", &t.tilekb}, {"ppt", &t.ppt}, {"jfnk", &t.jfnk}, {"jfpf", &t.jfpf}, {"jgnk", &t.jgnk},
         {"jgpf", &t.jgpf}, {"blk", &t.blk}, {"jzs", &t.jzs}, {"xcd", &t.xcd}, {"ctile", &t.ctile},
         {"pskip", &t.pskip}, {"joh", &t.joh}, {"lat2", &t.lat2}, {"xst", &t.xst}, {"jsamp", &t.jsamp}, {"tilemax", &t.tilemax},
-        {"j16", &t.j16}, {"j16pf", &t.j16pf}, {"j16nt", &t.j16nt}, {"tile2d", &t.tile2d}, {"latlin", &t.latlin}, {"pskipb", &t.pskipb}, {"pskipmin", &t.pskipmin}, {"jfsum", &t.jfsum}, {"jsplit", &t.jsplit}};
+        {"j16", &t.j16}, {"j16pf", &t.j16pf}, {"j16nt", &t.j16nt}, {"tile2d", &t.tile2d}, {"latlin", &t.latlin}, {"pskipb", &t.pskipb}, {"pskipmin", &t.pskipmin}, {"jfsum", &t.jfsum}, {"jsplit", &t.jsplit}, {"jnocb", &t.jnocb}};
     // tokens are separated by ',', a token is key=value with the WHOLE key compared
     for (const char* p = e; *p;) {
         const char* end = strchr(p, ',');
@@ -357,13 +358,15 @@ template <typename C> static void launch_lattice(Plan<C>& p, bool with_beta) {
 // {sfb, sgb, sgl, farflag} -- formed inside the tiled kernel; returns false when the caller still has to run
 // joint_sums_kernel (the cell-per-thread form of small lattices leaves them to it)
 struct JointSums { float *sfb, *sgb, *sgl; int* farflag; };
+template <typename C> static bool coef_is_tiled(const Plan<C>& p) { return !(p.maxU <= 48 || !tune().ctile); }
 template <typename C> static bool launch_coef(Plan<C>& p, bool joint = false, bool onehot = false, const JointSums* sums = nullptr) {
     float* wmat = joint ? p.wmat : nullptr;
     const int Upad = joint_upad(p.maxU);
     // additive joint: W and CL planes always (the DF kernel takes its label corrections from CL); small
     // vocabularies add CB and replace the records by a plane of c
-    const int planes = onehot ? joint_planes_onehot(p.maxU) : (joint ? 2 : 1);
-    if (p.maxU <= 48 || !tune().ctile) {
+    int planes = onehot ? joint_planes_onehot(p.maxU) : (joint ? 2 : 1);
+    if (coef_is_tiled(p) && sums != nullptr && planes == 4 && tune().jnocb) planes = 5;   // (no CB plane: joint_df_kernel<..., BS> reads the row sums)
+    if (!coef_is_tiled(p)) {
         // small lattices: one thread per skewed cell, scattered record store
         const long long skew_cells = static_cast<long long>(p.maxT + p.maxU - 1) * ((p.Up + 63) / 64) * 64;   // whole 64-column segments
         for (int b0 = 0; b0 < p.N; b0 += kGridSamples) {       // (samples on gridDim.y: slices of the batch)

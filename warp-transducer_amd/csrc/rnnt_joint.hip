@@ -174,10 +174,19 @@ static rnntStatus_t run_gpu_joint(const typename Tag::store* f, const typename T
         const int NKf = pick(tn.jfnk), NKg = pick(tn.jgnk);
         // small vocabularies (one or two column groups): the four wavefronts of a block split the CONTRACTION instead of the
         // columns (joint_df_kernel, SPLIT) -- when it is long enough to be worth the reduction
+        const bool nocb = onehot && joint_planes_onehot(maxU) == 4 && coef_is_tiled(p) && tn.jfsum && tn.jnocb;
         const bool split_f = tn.jsplit && (A + 32 * NKf - 1) / (32 * NKf) <= 2 && maxU >= 64;
         const bool split_g = tn.jsplit && (A + 32 * NKg - 1) / (32 * NKg) <= 2 && maxT >= 64;
 #define RNNT_JDF_SPLIT(NN, OO)                                                                                   \
-    hipLaunchKernelGGL((joint_df_kernel<Tag, NN, true, OO, true>), dim3((A + 32 * NN - 1) / (32 * NN), tilesT, N), dim3(256), 0, \
+    hipLaunchKernelGGL((joint_df_kernel<Tag, NN, true, OO, true, false>), dim3((A + 32 * NN - 1) / (32 * NN), tilesT, N), dim3(256), 0, \
+                       p.stream, f, g, p.rowmax, p.wmat, grad_scale, labels, input_lengths, label_lengths, df, maxT,  \
+                       maxU, Upad, A, N, p.blank, sfb)
+#define RNNT_JDF_SPLIT_BS(NN)                                                                                    \
+    hipLaunchKernelGGL((joint_df_kernel<Tag, NN, true, true, true, true>), dim3((A + 32 * NN - 1) / (32 * NN), tilesT, N), dim3(256), 0, \
+                       p.stream, f, g, p.rowmax, p.wmat, grad_scale, labels, input_lengths, label_lengths, df, maxT,  \
+                       maxU, Upad, A, N, p.blank, sfb)
+#define RNNT_JDF_BS(NN)                                                                                          \
+    hipLaunchKernelGGL((joint_df_kernel<Tag, NN, true, true, false, true>), dim3((A + 128 * NN - 1) / (128 * NN), tilesT, N), dim3(256), 0, \
                        p.stream, f, g, p.rowmax, p.wmat, grad_scale, labels, input_lengths, label_lengths, df, maxT,  \
                        maxU, Upad, A, N, p.blank, sfb)
 #define RNNT_JDG_SPLIT(NN)                                                                                       \
@@ -209,6 +218,8 @@ static rnntStatus_t run_gpu_joint(const typename Tag::store* f, const typename T
             }
         }
         if (df16) { /* launched above */ }
+        else if (split_f && onehot && nocb) { if (NKf == 4) RNNT_JDF_SPLIT_BS(4); else if (NKf == 2) RNNT_JDF_SPLIT_BS(2); else RNNT_JDF_SPLIT_BS(1); }
+        else if (onehot && nocb) { if (NKf == 4) RNNT_JDF_BS(4); else if (NKf == 2) RNNT_JDF_BS(2); else RNNT_JDF_BS(1); }
         else if (split_f && onehot) { if (NKf == 4) RNNT_JDF_SPLIT(4, true); else if (NKf == 2) RNNT_JDF_SPLIT(2, true); else RNNT_JDF_SPLIT(1, true); }
         else if (split_f) { if (NKf == 4) RNNT_JDF_SPLIT(4, false); else if (NKf == 2) RNNT_JDF_SPLIT(2, false); else RNNT_JDF_SPLIT(1, false); }
         else if (onehot)  { if (NKf == 4) RNNT_JDF(4, true, true); else if (NKf == 2) RNNT_JDF(2, true, true); else RNNT_JDF(1, true, true); }
@@ -235,6 +246,8 @@ static rnntStatus_t run_gpu_joint(const typename Tag::store* f, const typename T
 #undef RNNT_JDF
 #undef RNNT_JDG
 #undef RNNT_JDF_SPLIT
+#undef RNNT_JDF_SPLIT_BS
+#undef RNNT_JDF_BS
 #undef RNNT_JDG_SPLIT
         p.check();
         hipLaunchKernelGGL((joint_far_kernel<Tag>), fixgrid, dim3(256), 0, p.stream, f, g, p.rowmax, p.rowtab, grad_scale,

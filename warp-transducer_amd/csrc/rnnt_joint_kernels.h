@@ -750,7 +750,8 @@ __device__ __forceinline__ void joint_reduce_waves(f32x16 (&acc)[NV], float* __r
 // lattice cell (the first version's fix-up kernel), which all land on the few cache lines of a short df row (c4 shape,
 // A = 50: 340 us of atomics against ~100 us of extra matrix work); above a few hundred symbols the atomics
 // are cheaper than the 3x contraction and the host keeps them.
-template <typename Tag, int NK, bool PF, bool OH, bool SPLIT = false>   // PF: operand ping-pong + epilogue values requested before the loop (more registers)
+template <typename Tag, int NK, bool PF, bool OH, bool SPLIT = false, bool BS = false>   // PF: operand ping-pong + epilogue values requested before the loop (more registers)
+                                                                       // BS (with OH): the blank corrections come from the row sums sfb, no CB operand (no CB plane exists)
 __global__ __launch_bounds__(256) void joint_df_kernel(
         const typename Tag::store* __restrict__ f, const typename Tag::store* __restrict__ g, const float* __restrict__ rowmax,
         const float* __restrict__ wmat, const float* __restrict__ scale, const int* __restrict__ labels,
@@ -815,9 +816,11 @@ __global__ __launch_bounds__(256) void joint_df_kernel(
         const float4 w4 = *reinterpret_cast<const float4*>(wrow + ub);
         s.w[0] = w4.x; s.w[1] = w4.y; s.w[2] = w4.z; s.w[3] = w4.w;
         if constexpr (OH) {                                // zero outside the sample (padding, pad columns): no masks
-            const float4 b4 = *reinterpret_cast<const float4*>(wrow + plane + ub);
+            if constexpr (!BS) {
+                const float4 b4 = *reinterpret_cast<const float4*>(wrow + plane + ub);
+                s.cb[0] = b4.x; s.cb[1] = b4.y; s.cb[2] = b4.z; s.cb[3] = b4.w;
+            }
             const float4 l4 = *reinterpret_cast<const float4*>(wrow + 2 * plane + ub);
-            s.cb[0] = b4.x; s.cb[1] = b4.y; s.cb[2] = b4.z; s.cb[3] = b4.w;
             s.cl[0] = l4.x; s.cl[1] = l4.y; s.cl[2] = l4.z; s.cl[3] = l4.w;
         }
 #pragma unroll
@@ -838,7 +841,7 @@ __global__ __launch_bounds__(256) void joint_df_kernel(
                 const int lab = s.lab[i] < 0 ? 0 : (s.lab[i] >= A ? A - 1 : s.lab[i]);
 #pragma unroll
                 for (int n = 0; n < NK; ++n) {
-                    acc2[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(s.cb[i], kc + n == blank ? 1.0f : 0.0f, acc2[n], 0, 0, 0);
+                    if constexpr (!BS) acc2[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(s.cb[i], kc + n == blank ? 1.0f : 0.0f, acc2[n], 0, 0, 0);
                     acc2[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(s.cl[i], kc + n == lab ? 1.0f : 0.0f, acc2[n], 0, 0, 0);
                 }
             }
@@ -922,14 +925,14 @@ __global__ __launch_bounds__(256) void joint_df_kernel(
     for (int r = 0; r < 16; ++r) {
         const int t = t0 + mfma_row(r, lane);
         const bool live = t < Tb;
-        float vb = 0.0f;                                                  // (not OH) the blank column's row sum
-        if constexpr (!OH)
+        float vb = 0.0f;                                                  // (not OH, or BS) the blank column's row sum
+        if constexpr (!OH || BS)
             if (live && dblank < static_cast<unsigned>(NK)) vb = sfb[static_cast<size_t>(b) * maxT + t];
 #pragma unroll
         for (int n = 0; n < NK; ++n) {
             float o = live ? joint_exp(fv[r][n], mt[r]) * acc[n][r] : 0.0f;
             if constexpr (OH) o = live ? o - acc2[n][r] : 0.0f;
-            else o -= (dblank == static_cast<unsigned>(n)) ? vb : 0.0f;
+            if constexpr (!OH || BS) o -= (dblank == static_cast<unsigned>(n)) ? vb : 0.0f;
             acc[n][r] = o;
         }
     }
@@ -1224,7 +1227,9 @@ __global__ __launch_bounds__(256) void joint_far_kernel(
     const int tend = tb0 + kJointFixT < Tb ? tb0 + kJointFixT : Tb;
     for (int t = tb0 + wave; t < tend; t += 4) {
         float c = log_zero<float>();
-        if (uin) c = joint_cell(rowtab, planes, b, t, u, maxT, maxU, Upad, N).x;
+        if (uin)                                           // (only c: with planes == 5 the CB plane holds nothing)
+            c = planes != nullptr ? reinterpret_cast<const float*>(rowtab)[(static_cast<size_t>(b) * maxT + t) * Upad + u]
+                                  : rowtab[(static_cast<size_t>(b) * maxT + t) * maxU + u].x;
         typename Tag::store* dfrow = df + (static_cast<size_t>(b) * maxT + t) * A;
         unsigned long long far = __ballot(uin && c > kJointFarC);
         while (far) {

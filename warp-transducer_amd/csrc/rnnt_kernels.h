@@ -1722,21 +1722,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void c
         if (offsets != nullptr) {                          // packed row order: the run of a time row stays contiguous
             const size_t at = static_cast<size_t>(offsets[b]) + static_cast<size_t>(t) * Ub + u;
             if (t < Tb && u < Ub && at < static_cast<size_t>(N) * maxT * maxU) rowtab[at] = o;
-        } else if (planes != 4) {
+        } else if (planes < 4) {
             rowtab[(static_cast<size_t>(b) * maxT + t) * maxU + u] = o;
             if (t >= Tb || u >= Ub) *padflag = 1;          // the batch has padded rows: the gradient kernel may skip their logits
         }
         if (wmat != nullptr) {                             // additive joint only: W = exp(c), cb, cl; row stride Upad
+            // planes: 1 W | 2 W, CL | 3 W, CB, CL | 4 W, CB, CL and the plane of c in place of the records | 5 (SUMS only) as 4 WITHOUT
+            // the CB plane: the DF kernel takes its blank corrections from the row sums formed above, nothing reads cb per cell
             const float cc = static_cast<float>(o.x);
             const size_t at = (static_cast<size_t>(b) * maxT + t) * Upad + u;
             wmat[at] = cc > kJointFarC ? 0.0f : fast_exp(cc);
-            if (planes >= 3) wmat[plane + at] = static_cast<float>(o.y);
+            if (planes == 3 || planes == 4) wmat[plane + at] = static_cast<float>(o.y);
             if (planes >= 2) wmat[2 * plane + at] = static_cast<float>(o.z);
-            if (planes == 4) reinterpret_cast<float*>(rowtab)[at] = cc;   // plane of c in place of the records
+            if (planes >= 4) reinterpret_cast<float*>(rowtab)[at] = cc;   // plane of c in place of the records
             if (u == maxU - 1)                             // the row's pad columns [maxU, Upad) are zero
                 for (int k = 1; k <= Upad - maxU; ++k)
                     for (int pl = 0; pl < 3; ++pl)
-                        if (pl == 0 || planes >= 3 || (pl == 2 && planes == 2)) wmat[pl * plane + at + k] = 0.0f;
+                        if (pl == 0 || (pl == 1 && (planes == 3 || planes == 4)) || (pl == 2 && planes >= 2)) wmat[pl * plane + at + k] = 0.0f;
         }
     }
 }

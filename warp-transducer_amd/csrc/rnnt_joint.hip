@@ -141,9 +141,14 @@ static rnntStatus_t run_gpu_joint(const typename Tag::store* f, const typename T
     mark(2);
     // small vocabularies: the df corrections ride along in the DF GEMM as one-hot operands (3x its
     // contraction) instead of one global atomic per lattice cell in the fix-up kernel
-    // (fp32 storage only: with 16-bit storage the one-hot DF kernel needs 228 + 128 registers and runs at a third of
-    // the speed -- c4 shape 0.81 vs 0.51 ms for the backward phase -- so 16-bit keeps the epilogue corrections)
-    const bool onehot = tune().joh >= 0 ? tune().joh != 0 : (A <= 256 && sizeof(S) == 4);
+    // (fp32 storage: with 16-bit storage the column-split one-hot DF kernel needs 228 + 128 registers and runs at a third of
+    // the speed -- c4 shape 0.81 vs 0.51 ms for the backward phase -- so 16-bit keeps the epilogue corrections, except:)
+    // 16-bit storage, at most two 32-column groups, long label rows: there the split-contraction DF kernel without the CB
+    // operand (SPLIT, BS below) fits 248 registers and the one-hot form wins as it does for fp32 (c4 shape, bf16: backward
+    // 0.300 -> 0.233 ms, and the coefficient kernel writes three planes instead of records + two: 0.366 -> 0.318 ms)
+    const bool onehot16 = A <= 64 && maxU >= 64 && joint_planes_onehot(maxU) == 4 && coef_is_tiled(p) && tune().jfsum &&
+                          tune().jnocb && tune().jsplit;
+    const bool onehot = tune().joh >= 0 ? tune().joh != 0 : (A <= 256 && (sizeof(S) == 4 || onehot16));
     // correction sums (fp32 side vectors in the workspace) for the epilogues of the gradient GEMMs
     float* sfb = p.side;
     float* sgb = sfb + static_cast<size_t>(N) * maxT;

@@ -507,3 +507,77 @@ def test_full_size_c3_shape(oracle, dtype):
     rdf, rdg = ref_gz.sum(axis=2), ref_gz.sum(axis=1)
     assert (np.abs(df[:K].double().cpu().numpy() - rdf) <= 2e-4 + 5e-5 * np.abs(rdf) + ulp * np.abs(rdf)).all()
     assert (np.abs(dg[:K].double().cpu().numpy() - rdg) <= 2e-4 * (T / 32) + 5e-5 * np.abs(rdg) + ulp * np.abs(rdg)).all()
+
+
+@pytest.mark.parametrize("loader", ["ext", "ctypes"])
+def test_both_bindings(monkeypatch, oracle, loader):
+    """RNNTLossAdd through the compiled extension module's C++ autograd function (csrc/binding.cpp: rnnt_loss_add) and through
+    the ctypes twin (add_network._RNNTAdd): the three reductions with a per-sample grad_output against the oracle on the
+    materialised joint, a gradient for only ONE of the two activations, a no-grad call, FastEmit, 16-bit storage, and the
+    argument errors (same exception types and texts from both)."""
+    from warprnnt_pytorch import warp_rnnt
+    from warprnnt_pytorch.add_network import RNNTLossAdd
+    if loader == "ext":
+        assert warp_rnnt.binding() == "ext", "the compiled extension module was not built"
+    else:
+        monkeypatch.setattr(warp_rnnt, "_EXT", None)
+    shape = (3, 20, 9, 40)
+    f, g, labels, tl, ll, blank = problem(shape, 11)
+    N = shape[0]
+    z = f[:, :, None, :].astype(np.float64) + g[:, None, :, :].astype(np.float64)
+    ref_c, ref_gz = oracle.rnnt_logits(z, labels, tl, ll, blank)
+    rdf, rdg = ref_gz.sum(axis=2), ref_gz.sum(axis=1)
+    dev = torch.device("cuda:0")
+    lab, ttl, tll = (torch.tensor(a, device=dev) for a in (labels, tl, ll))
+
+    def leaves(fg=True, gg=True, dtype=torch.float32):
+        return (torch.tensor(f, device=dev, dtype=dtype).requires_grad_(fg), torch.tensor(g, device=dev, dtype=dtype).requires_grad_(gg))
+
+    tf, tg = leaves()
+    per = RNNTLossAdd(blank=blank, reduction="none")(tf, tg, lab, ttl, tll)
+    assert per.shape == (N,) and per.dtype == torch.float32
+    w = torch.tensor([0.5, -2.0, 3.0], device=dev)
+    (per * w).sum().backward()
+    wn = w.cpu().numpy().astype(np.float64)
+    assert np.allclose(per.detach().cpu().numpy(), ref_c, rtol=1e-5)
+    assert np.allclose(tf.grad.cpu().numpy(), rdf * wn[:, None, None], rtol=2e-4, atol=2e-4)
+    assert np.allclose(tg.grad.cpu().numpy(), rdg * wn[:, None, None], rtol=2e-4, atol=2e-4)
+    for red, val, sc in (("sum", ref_c.sum(), 1.0), ("mean", ref_c.mean(), 1.0 / N)):
+        tf, tg = leaves()
+        loss = RNNTLossAdd(blank=blank, reduction=red)(tf, tg, lab, ttl, tll)
+        assert loss.shape == (1,) and np.allclose(loss.item(), val, rtol=1e-5)
+        loss.sum().backward()
+        assert np.allclose(tf.grad.cpu().numpy(), rdf * sc, rtol=2e-4, atol=2e-4)
+        assert np.allclose(tg.grad.cpu().numpy(), rdg * sc, rtol=2e-4, atol=2e-4)
+    tf, tg = leaves(fg=False)                           # only the prediction network trains
+    RNNTLossAdd(blank=blank, reduction="sum")(tf, tg, lab, ttl, tll).sum().backward()
+    assert tf.grad is None and np.allclose(tg.grad.cpu().numpy(), rdg, rtol=2e-4, atol=2e-4)
+    with torch.no_grad():
+        tf, tg = leaves()
+        assert np.allclose(RNNTLossAdd(blank=blank, reduction="sum")(tf, tg, lab, ttl, tll).item(), ref_c.sum(), rtol=1e-5)
+    tf, tg = leaves(dtype=torch.bfloat16)
+    loss = RNNTLossAdd(blank=blank, reduction="sum")(tf, tg, lab, ttl, tll)
+    loss.sum().backward()
+    assert loss.dtype == torch.float32 and tf.grad.dtype == torch.bfloat16 and tg.grad.dtype == torch.bfloat16
+    assert abs(loss.item() - ref_c.sum()) < 0.02 * ref_c.sum()
+    tf, tg = leaves()
+    fe = RNNTLossAdd(blank=blank, reduction="sum", fastemit_lambda=0.5)(tf, tg, lab, ttl, tll)
+    fe.sum().backward()
+    assert np.allclose(fe.item(), ref_c.sum(), rtol=1e-5)            # FastEmit changes the gradients, not the reported loss
+    assert not np.allclose(tg.grad.cpu().numpy(), rdg, rtol=2e-4, atol=2e-4)
+    tf, tg = leaves()
+    mod = RNNTLossAdd(blank=blank)
+    with pytest.raises(ValueError, match="Input length mismatch"):
+        mod(tf, tg, lab, ttl - 1, tll)
+    with pytest.raises(ValueError, match="Output length mismatch"):
+        mod(tf, tg, lab, ttl, tll - 1)
+    with pytest.raises(TypeError, match="labels must be"):
+        mod(tf, tg, lab.long(), ttl, tll)
+    with pytest.raises(ValueError, match="must be contiguous"):
+        mod(tf.transpose(1, 2).contiguous().transpose(1, 2), tg, lab, ttl, tll)
+    with pytest.raises(ValueError, match="disagree"):
+        mod(tf, tg[:, :, :-1].contiguous(), lab, ttl, tll)
+    with pytest.raises(TypeError, match="must both be"):
+        mod(tf, tg.double(), lab, ttl, tll)
+    with pytest.raises(ValueError, match="GPU only"):
+        mod(tf.detach().cpu(), tg.detach().cpu(), lab.cpu(), ttl.cpu(), tll.cpu())

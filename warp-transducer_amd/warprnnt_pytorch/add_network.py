@@ -112,11 +112,23 @@ class _RNNTAdd(Function):
         return df, dg, None, None, None, None, None, None
 
 
+_REDUCTIONS = {"none": 0, "sum": 1, "mean": 2}
+
+
 def rnnt_loss_add(trans_acts, pred_acts, labels, act_lens, label_lens, blank=0, reduction="mean",
                   fastemit_lambda=0.0):
     """RNN-T loss of the additive joint ``trans_acts[:, :, None] + pred_acts[:, None]`` without
     forming it.  Arguments as `rnnt_loss`, with the two activations instead of the joint tensor
-    (float32, bfloat16 or float16; the loss is float32, the gradients have the activations' dtype)."""
+    (float32, bfloat16 or float16; the loss is float32, the gradients have the activations' dtype).
+
+    With the compiled extension module loaded (`warp_rnnt.binding() == "ext"`) the whole loss is its C++
+    autograd function `rnnt_loss_add` (csrc/binding.cpp: the same checks, allocations and the two
+    library calls without returning to Python); `_RNNTAdd` below is the ctypes twin."""
+    from . import warp_rnnt
+    ext = getattr(warp_rnnt, "_EXT", None)
+    if ext is not None and reduction in _REDUCTIONS and isinstance(trans_acts, torch.Tensor) and trans_acts.is_cuda:
+        return ext.rnnt_loss_add(trans_acts, pred_acts, labels, act_lens, label_lens, int(blank), _REDUCTIONS[reduction],
+                                 float(fastemit_lambda), True)
     return _RNNTAdd.apply(trans_acts, pred_acts, labels, act_lens, label_lens, blank, reduction, fastemit_lambda)
 
 

@@ -189,6 +189,31 @@ void gpu_rnnt_bwd(const at::Tensor& acts, at::Tensor grads, const c10::optional<
 }
 
 // ---------------------------------------------------------------------------------------------------------- argument checks
+// T == max(lengths), U == max(label_lengths) + 1 need the VALUES: the two small vectors are copied to pinned host memory
+// behind whatever the stream holds, one synchronisation, maxima on the host (the reference reads them back with two
+// .item() calls: two reductions and two synchronisations)
+void read_max_lengths(const at::Tensor& lengths, const at::Tensor& label_lengths, int* max_t_out, int* max_l_out) {
+    const long n = lengths.numel();
+    int max_t = 0, max_l = 0;
+    if (lengths.is_cuda() && label_lengths.is_cuda() && lengths.device() == label_lengths.device()) {
+        static thread_local at::Tensor pinned;
+        if (!pinned.defined() || pinned.numel() < 2 * n)
+            pinned = at::empty({2 * n > 256 ? 2 * n : 256}, at::TensorOptions().dtype(at::kInt).pinned_memory(true));
+        const DeviceGuard guard(lengths.device());
+        const hipStream_t stream = c10::hip::getCurrentHIPStream(lengths.device().index()).stream();
+        int* h = pinned.data_ptr<int>();
+        C10_HIP_CHECK(hipMemcpyAsync(h, lengths.data_ptr<int>(), sizeof(int) * n, hipMemcpyDeviceToHost, stream));
+        C10_HIP_CHECK(hipMemcpyAsync(h + n, label_lengths.data_ptr<int>(), sizeof(int) * n, hipMemcpyDeviceToHost, stream));
+        C10_HIP_CHECK(hipStreamSynchronize(stream));
+        for (long i = 0; i < n; ++i) { max_t = h[i] > max_t || i == 0 ? h[i] : max_t; max_l = h[n + i] > max_l || i == 0 ? h[n + i] : max_l; }
+    } else {
+        max_t = lengths.max().item<int>();
+        max_l = label_lengths.max().item<int>();
+    }
+    *max_t_out = max_t;
+    *max_l_out = max_l;
+}
+
 // The reference binding's checks, in its order, with its exception types and message texts (incl. the spelling "lenghts"):
 // pytorch_binding/warprnnt_pytorch/__init__.py:103-140 (the Python twin of this function is warprnnt_pytorch/_checks.py).
 void certify_inputs(const at::Tensor& acts, const at::Tensor& labels, const at::Tensor& lengths, const at::Tensor& label_lengths,
@@ -207,26 +232,8 @@ void certify_inputs(const at::Tensor& acts, const at::Tensor& labels, const at::
     TORCH_CHECK_VALUE(lengths.dim() == 1, "lenghts must be 1D");
     TORCH_CHECK_VALUE(label_lengths.dim() == 1, "label_lenghts must be 1D");
     if (!read_lengths) return;
-    // T == max(lengths), U == max(label_lengths) + 1 need the VALUES: the two small vectors are copied to pinned host memory
-    // behind whatever the stream holds, one synchronisation, maxima on the host (the reference reads them back with two
-    // .item() calls: two reductions and two synchronisations)
-    const long n = lengths.numel();
     int max_t = 0, max_l = 0;
-    if (lengths.is_cuda() && label_lengths.is_cuda() && lengths.device() == label_lengths.device()) {
-        static thread_local at::Tensor pinned;
-        if (!pinned.defined() || pinned.numel() < 2 * n)
-            pinned = at::empty({2 * n > 256 ? 2 * n : 256}, at::TensorOptions().dtype(at::kInt).pinned_memory(true));
-        const DeviceGuard guard(lengths.device());
-        const hipStream_t stream = c10::hip::getCurrentHIPStream(lengths.device().index()).stream();
-        int* h = pinned.data_ptr<int>();
-        C10_HIP_CHECK(hipMemcpyAsync(h, lengths.data_ptr<int>(), sizeof(int) * n, hipMemcpyDeviceToHost, stream));
-        C10_HIP_CHECK(hipMemcpyAsync(h + n, label_lengths.data_ptr<int>(), sizeof(int) * n, hipMemcpyDeviceToHost, stream));
-        C10_HIP_CHECK(hipStreamSynchronize(stream));
-        for (long i = 0; i < n; ++i) { max_t = h[i] > max_t || i == 0 ? h[i] : max_t; max_l = h[n + i] > max_l || i == 0 ? h[n + i] : max_l; }
-    } else {
-        max_t = lengths.max().item<int>();
-        max_l = label_lengths.max().item<int>();
-    }
+    read_max_lengths(lengths, label_lengths, &max_t, &max_l);
     TORCH_CHECK_VALUE(acts.size(1) == max_t, "Input length mismatch");
     TORCH_CHECK_VALUE(acts.size(2) == max_l + 1, "Output length mismatch");
 }
@@ -281,6 +288,127 @@ at::Tensor rnnt_loss(const at::Tensor& acts, const at::Tensor& labels, const at:
     return RNNTFunction::apply(acts, labels, act_lens, label_lens, blank, reduction, fastemit_lambda, validate);
 }
 
+// ---------------------------------------------------------------------------------------------------------- additive joint
+// RNNTLossAdd as a C++ autograd function (the Python twin: warprnnt_pytorch/add_network.py): the loss of the joint
+// trans_acts[:, :, None] + pred_acts[:, None] without forming it (compute_rnnt_loss_add_fwd_dt / _bwd_dt; the reference's
+// add_network call shape, pytorch_binding/test/test_time.py:51-70).  Checks in the order and with the texts of add_network._certify.
+size_t workspace_bytes_add(int T, int U, int N) {
+    static std::mutex mu;
+    static std::map<std::tuple<int, int, int>, size_t> cache;
+    const auto key = std::make_tuple(T, U, N);
+    {
+        std::lock_guard<std::mutex> g(mu);
+        auto it = cache.find(key);
+        if (it != cache.end()) return it->second;
+    }
+    size_t n = 0;
+    check_status(get_workspace_size_add(T, U, N, &n), "get_workspace_size_add");
+    std::lock_guard<std::mutex> g(mu);
+    cache[key] = n;
+    return n;
+}
+
+void certify_add(const at::Tensor& f, const at::Tensor& g, const at::Tensor& labels, const at::Tensor& lengths, const at::Tensor& label_lengths,
+                 bool read_lengths) {
+    TORCH_CHECK_TYPE(labels.scalar_type() == at::kInt, "labels must be torch.int32");
+    TORCH_CHECK_TYPE(label_lengths.scalar_type() == at::kInt, "label_lengths must be torch.int32");
+    TORCH_CHECK_TYPE(lengths.scalar_type() == at::kInt, "lengths must be torch.int32");
+    TORCH_CHECK_VALUE(f.is_contiguous(), "trans_acts must be contiguous");
+    TORCH_CHECK_VALUE(g.is_contiguous(), "pred_acts must be contiguous");
+    TORCH_CHECK_VALUE(labels.is_contiguous(), "labels must be contiguous");
+    TORCH_CHECK_VALUE(lengths.is_contiguous(), "lengths must be contiguous");
+    TORCH_CHECK_VALUE(label_lengths.is_contiguous(), "label_lengths must be contiguous");
+    TORCH_CHECK_VALUE(f.dim() == 3, "trans_acts must be 3D");
+    TORCH_CHECK_VALUE(g.dim() == 3, "pred_acts must be 3D");
+    TORCH_CHECK_VALUE(labels.dim() == 2, "labels must be 2D");
+    TORCH_CHECK_VALUE(lengths.dim() == 1, "lengths must be 1D");
+    TORCH_CHECK_VALUE(label_lengths.dim() == 1, "label_lengths must be 1D");
+    TORCH_CHECK_VALUE(f.is_cuda() && g.is_cuda(), "the additive-joint loss runs on the GPU only");
+    const int code = dtype_code(f);
+    TORCH_CHECK_TYPE((code == 0 || code == 2 || code == 3) && g.scalar_type() == f.scalar_type(),
+                     "trans_acts and pred_acts must both be torch.float32, torch.bfloat16 or torch.float16");
+    TORCH_CHECK_VALUE(g.size(0) == f.size(0) && g.size(2) == f.size(2), "trans_acts (B,T,V) and pred_acts (B,U+1,V) disagree");
+    TORCH_CHECK_VALUE(lengths.size(0) == f.size(0) && label_lengths.size(0) == f.size(0), "must have a length per example.");
+    if (!read_lengths) return;
+    int max_t = 0, max_l = 0;
+    read_max_lengths(lengths, label_lengths, &max_t, &max_l);
+    TORCH_CHECK_VALUE(f.size(1) == max_t, "Input length mismatch");
+    TORCH_CHECK_VALUE(g.size(1) == max_l + 1, "Output length mismatch");
+}
+
+rnntOptions make_options_add(const at::Tensor& f, const at::Tensor& g, int blank, hipStream_t stream) {
+    rnntOptions o{};
+    o.loc = RNNT_GPU;
+    o.stream = reinterpret_cast<CUstream>(stream);
+    o.blank_label = blank;
+    o.maxT = static_cast<int>(f.size(1));
+    o.maxU = static_cast<int>(g.size(1));
+    o.batch_first = true;
+    return o;
+}
+
+struct RNNTAddFunction : public torch::autograd::Function<RNNTAddFunction> {
+    static at::Tensor forward(torch::autograd::AutogradContext* ctx, const at::Tensor& f, const at::Tensor& g, const at::Tensor& labels,
+                              const at::Tensor& act_lens, const at::Tensor& label_lens, int64_t blank, int64_t reduction,
+                              double fastemit_lambda, bool validate) {
+        certify_add(f, g, labels, act_lens, label_lens, validate);
+        const long n = f.size(0);
+        const int T = static_cast<int>(f.size(1)), U = static_cast<int>(g.size(1)), V = static_cast<int>(f.size(2));
+        const bool need_grad = f.requires_grad() || g.requires_grad();
+        const int index = f.device().index();
+        OptionalDeviceGuard guard;
+        if (at::hip::current_device() != index) guard.set_index(index);
+        const hipStream_t stream = c10::hip::getCurrentHIPStream(index).stream();
+        at::Tensor costs = at::empty({n}, f.options().dtype(at::kFloat));
+        at::Tensor ws = at::empty({static_cast<long>(workspace_bytes_add(T, U, static_cast<int>(n)))}, f.options().dtype(at::kByte));
+        const rnntOptions opt = make_options_add(f, g, static_cast<int>(blank), stream);
+        const int* lab = labels.numel() > 0 ? labels.data_ptr<int>() : reinterpret_cast<const int*>(costs.data_ptr());   // maxU == 1: never read
+        check_status(compute_rnnt_loss_add_fwd_dt(f.data_ptr(), g.data_ptr(), lab, iptr(label_lens), iptr(act_lens), V, static_cast<int>(n),
+                                                  costs.data_ptr<float>(), ws.data_ptr(), opt, dtype_code(f), need_grad ? 1 : 0,
+                                                  static_cast<float>(fastemit_lambda)),
+                     "compute_rnnt_loss_add_fwd");
+        if (need_grad) {
+            ctx->save_for_backward({f, g, labels, act_lens, label_lens, ws});
+            ctx->saved_data["blank"] = blank;
+            ctx->saved_data["mean_scale"] = reduction == 2 ? 1.0 / static_cast<double>(n) : 1.0;
+            ctx->saved_data["stream"] = static_cast<int64_t>(reinterpret_cast<long>(stream));
+        }
+        if (reduction == 1) return costs.sum(0, /*keepdim=*/true);
+        if (reduction == 2) return costs.mean(0, /*keepdim=*/true);
+        return costs;
+    }
+
+    static torch::autograd::variable_list backward(torch::autograd::AutogradContext* ctx, torch::autograd::variable_list grad_outputs) {
+        const auto saved = ctx->get_saved_variables();
+        const at::Tensor &f = saved[0], &g = saved[1], &labels = saved[2], &act_lens = saved[3], &label_lens = saved[4], &ws = saved[5];
+        const long n = f.size(0);
+        const int index = f.device().index();
+        OptionalDeviceGuard guard;
+        if (at::hip::current_device() != index) guard.set_index(index);
+        const c10::hip::HIPStream cur = c10::hip::getCurrentHIPStream(index);
+        const long fwd_stream = ctx->saved_data["stream"].toInt();
+        if (fwd_stream != 0 && reinterpret_cast<long>(cur.stream()) != fwd_stream)
+            c10::hip::HIPCachingAllocatorMasqueradingAsCUDA::recordStreamMasqueradingAsCUDA(ws.storage().data_ptr(),
+                                                                                          c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(index));
+        at::Tensor go = grad_outputs[0].reshape({-1});
+        if (go.scalar_type() != at::kFloat || go.device() != f.device()) go = go.to(f.device(), at::kFloat);
+        const at::Tensor scale = go.expand({n}) * ctx->saved_data["mean_scale"].toDouble();
+        at::Tensor df = at::empty_like(f), dg = at::empty_like(g);
+        const rnntOptions opt = make_options_add(f, g, static_cast<int>(ctx->saved_data["blank"].toInt()), cur.stream());
+        const int* lab = labels.numel() > 0 ? labels.data_ptr<int>() : reinterpret_cast<const int*>(scale.data_ptr());
+        check_status(compute_rnnt_loss_add_bwd_dt(f.data_ptr(), g.data_ptr(), df.data_ptr(), dg.data_ptr(), scale.data_ptr<float>(), lab,
+                                                  iptr(label_lens), iptr(act_lens), static_cast<int>(f.size(2)), static_cast<int>(n),
+                                                  ws.data_ptr(), opt, dtype_code(f)),
+                     "compute_rnnt_loss_add_bwd");
+        return {df, dg, at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor()};
+    }
+};
+
+at::Tensor rnnt_loss_add(const at::Tensor& trans_acts, const at::Tensor& pred_acts, const at::Tensor& labels, const at::Tensor& act_lens,
+                         const at::Tensor& label_lens, int64_t blank, int64_t reduction, double fastemit_lambda, bool validate) {
+    return RNNTAddFunction::apply(trans_acts, pred_acts, labels, act_lens, label_lens, blank, reduction, fastemit_lambda, validate);
+}
+
 }  // namespace
 
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
@@ -299,5 +427,8 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
     m.def("rnnt_loss", &rnnt_loss, "RNN-T loss of GPU tensors as a C++ autograd function (reduction: 0 none, 1 sum, 2 mean)", py::arg("acts"),
           py::arg("labels"), py::arg("act_lens"), py::arg("label_lens"), py::arg("blank") = 0, py::arg("reduction") = 2,
           py::arg("fastemit_lambda") = 0.0, py::arg("validate") = true);
+    m.def("rnnt_loss_add", &rnnt_loss_add, "RNN-T loss of the additive joint trans_acts[:, :, None] + pred_acts[:, None] as a C++ autograd function",
+          py::arg("trans_acts"), py::arg("pred_acts"), py::arg("labels"), py::arg("act_lens"), py::arg("label_lens"), py::arg("blank") = 0,
+          py::arg("reduction") = 2, py::arg("fastemit_lambda") = 0.0, py::arg("validate") = true);
     m.def("library_version", []() { return get_warprnnt_version(); });
 }

@@ -121,12 +121,16 @@ def test_peak_separation_sweep(oracle, sep):
     assert np.allclose(dg, ref_gz.sum(axis=1), rtol=1e-3, atol=1e-3)
 
 
-@pytest.mark.parametrize("shape", [(1, 6, 4, 50), (1, 6, 70, 50), (1, 5, 1, 20)])   # cell / tiled coefficient kernel, U = 1
+@pytest.mark.parametrize("shape", [(1, 6, 4, 50), (1, 6, 70, 50), (1, 5, 1, 20),    # cell / tiled coefficient kernel, U = 1
+                                   (3, 40, 70, 50), (3, 33, 20, 300), (2, 20, 70, 300)])   # ragged batches; only sample 1 has far cells; tiled + epilogue corrections
 def test_large_logit_range_is_safe(oracle, shape):
-    """Rows whose best f column and best g column differ by 100+ nats: every cell is recomputed directly."""
+    """Rows whose best f column and best g column differ by 100+ nats: every cell is recomputed directly, and the
+    gradient GEMMs leave those cells out (W = the far mark, a negative zero; joint_far_kernel adds them from the c the
+    coefficient kernel stored for exactly those cells)."""
     f, g, labels, tl, ll, blank = problem(shape, 77)
-    f[..., 3] += 120.0
-    g[..., 40 % shape[3]] += 150.0
+    far = slice(1, 2) if shape[0] > 1 else slice(None)
+    f[far, :, 3] += 120.0
+    g[far, :, 40 % shape[3]] += 150.0
     z = f[:, :, None, :].astype(np.float64) + g[:, None, :, :].astype(np.float64)
     ref_c, ref_gz = oracle.rnnt_logits(z, labels, tl, ll, blank)
     costs, df, dg = run_add(f, g, labels, tl, ll, blank)

@@ -363,9 +363,11 @@ template <typename C> static bool launch_coef(Plan<C>& p, bool joint = false, bo
     float* wmat = joint ? p.wmat : nullptr;
     const int Upad = joint_upad(p.maxU);
     // additive joint: W and CL planes always (the DF kernel takes its label corrections from CL); small
-    // vocabularies add CB and replace the records by a plane of c
+    // vocabularies add CB and drop the records (a far cell's c is kept in their memory)
     int planes = onehot ? joint_planes_onehot(p.maxU) : (joint ? 2 : 1);
-    if (coef_is_tiled(p) && sums != nullptr && planes == 4 && tune().jnocb) planes = 5;   // (no CB plane: joint_df_kernel<..., BS> reads the row sums)
+    // the tiled kernel forming the sums itself: nothing reads cb per cell (joint_df_kernel<..., BS> and the epilogue form both take
+    // the row sums) nor the records -- W and CL only, whatever the vocabulary
+    if (coef_is_tiled(p) && sums != nullptr && joint_planes_onehot(p.maxU) == 4 && tune().jnocb) planes = 5;
     if (!coef_is_tiled(p)) {
         // small lattices: one thread per skewed cell, scattered record store
         const long long skew_cells = static_cast<long long>(p.maxT + p.maxU - 1) * ((p.Up + 63) / 64) * 64;   // whole 64-column segments

@@ -154,7 +154,10 @@ static rnntStatus_t run_gpu_joint(const typename Tag::store* f, const typename T
     float* sgb = sfb + static_cast<size_t>(N) * maxT;
     float* sgl = sgb + static_cast<size_t>(N) * maxU;
     int* farflag = reinterpret_cast<int*>(sgl + static_cast<size_t>(N) * maxU);
-    const float* cplanes = onehot && joint_planes_onehot(maxU) == 4 ? p.wmat : nullptr;   // c / cb / cl as dense planes
+    // no record table (far cells: the mark in W, their c at the plane index): the one-hot planes, or W and CL alone behind the
+    // tiled coefficient kernel that forms the sums (launch_coef: planes 4 / 5)
+    const bool norec = joint_planes_onehot(maxU) == 4 && (onehot || (coef_is_tiled(p) && tune().jfsum && tune().jnocb));
+    const float* cplanes = norec ? p.wmat : nullptr;
     const dim3 fixgrid((maxU + 63) / 64, (maxT + kJointFixT - 1) / kJointFixT, N);
     if (do_fwd && training) {
         const JointSums sums{sfb, sgb, sgl, farflag};

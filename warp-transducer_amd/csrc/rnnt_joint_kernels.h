@@ -1137,7 +1137,7 @@ __device__ __forceinline__ Cell<float> joint_cell(const Cell<float>* __restrict_
     if (planes != nullptr) {
         const size_t plane = static_cast<size_t>(N) * maxT * Upad;
         const size_t at = (static_cast<size_t>(b) * maxT + t) * Upad + u;
-        rec.x = reinterpret_cast<const float*>(rowtab)[at];
+        rec.x = joint_is_far_mark(planes[at]) ? reinterpret_cast<const float*>(rowtab)[at] : 0.0f;   // (c itself is kept for far cells only)
         rec.y = planes[plane + at];
         rec.z = planes[2 * plane + at];
         rec.w = 0.0f;
@@ -1227,9 +1227,14 @@ __global__ __launch_bounds__(256) void joint_far_kernel(
     const int tend = tb0 + kJointFixT < Tb ? tb0 + kJointFixT : Tb;
     for (int t = tb0 + wave; t < tend; t += 4) {
         float c = log_zero<float>();
-        if (uin)                                           // (only c: with planes == 5 the CB plane holds nothing)
-            c = planes != nullptr ? reinterpret_cast<const float*>(rowtab)[(static_cast<size_t>(b) * maxT + t) * Upad + u]
-                                  : rowtab[(static_cast<size_t>(b) * maxT + t) * maxU + u].x;
+        if (uin) {                                         // (only c: with planes == 5 the CB plane holds nothing)
+            if (planes != nullptr) {                       // no records: the far mark in W, c stored for marked cells only
+                const size_t at = (static_cast<size_t>(b) * maxT + t) * Upad + u;
+                if (joint_is_far_mark(planes[at])) c = reinterpret_cast<const float*>(rowtab)[at];
+            } else {
+                c = rowtab[(static_cast<size_t>(b) * maxT + t) * maxU + u].x;
+            }
+        }
         typename Tag::store* dfrow = df + (static_cast<size_t>(b) * maxT + t) * A;
         unsigned long long far = __ballot(uin && c > kJointFarC);
         while (far) {

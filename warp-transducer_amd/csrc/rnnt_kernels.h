@@ -51,6 +51,12 @@ constexpr double kLn2 = 0.6931471805599453;
 // W[b][t][u] = exp(c) of the gradient GEMMs; cells with c above kJointFarC ("far" cells, whose two
 // logit rows peak at different symbols) and the padding get 0 and are handled outside the GEMMs.
 constexpr float kJointFarC = 40.0f;
+// ... and W holds this mark there: NEGATIVE zero.  As an operand of the gradient GEMMs it is a zero like any other (no
+// clamp, no mask in DF / DG), and no exp() produces it, so joint_far_kernel / joint_sums_kernel recognise a far cell by the
+// bit pattern -- with the one-hot planes (no records) only those cells' c is stored, into the record table's memory
+// at the plane index, instead of a dense plane of c that nothing else read (117 MB per step on the c4 shape).
+constexpr float kJointFarMark = -0.0f;
+__device__ __forceinline__ bool joint_is_far_mark(float w) { return __float_as_uint(w) == 0x80000000u; }
 // Row stride of those dense matrices: maxU rounded up to 8 (the GEMMs read them eight columns at a time;
 // the pad columns are kept zero).  Three planes of N*maxT*Upad floats each: W, CB (blank corrections),
 // CL (label corrections).
@@ -1469,7 +1475,7 @@ __global__ __launch_bounds__(kLinThreads) void lattice_lin_kernel(
 // formed in fp64 from the scaled fp32 lattice values and their fp64 offsets.
 constexpr int kPadded = -2;
 // One-hot df corrections (additive joint, small vocabularies): planes written by the coefficient kernels.
-// 4 = the plane of c replaces the records (it must fit their memory: ceil8(maxU) <= 4 maxU), else 3.
+// 4 = no records: a far cell's c is stored at its PLANE index in the records' memory (which must cover it: ceil8(maxU) <= 4 maxU), else 3.
 __host__ __device__ inline int joint_planes_onehot(int maxU) { return joint_upad(maxU) <= 4 * maxU ? 4 : 3; }
 
 // Everything the record of one lattice cell needs from memory.  coef_fetch() issues all of it UNCONDITIONALLY
@@ -1560,10 +1566,9 @@ __global__ __launch_bounds__(256) void coef_cell_kernel(
         const double* __restrict__ offb, const double* __restrict__ ll_fwd,
         const int* __restrict__ labels, const int* __restrict__ xlen, const int* __restrict__ ylen,
         Cell<L>* __restrict__ rowtab, int maxT, int maxU, int Up, float* __restrict__ wmat, int Upad, float fastemit,
-        int planes, const long long* __restrict__ offsets, int lw, int lsh, int b0, int N, int* __restrict__ padflag) {   // offsets: packed row order (see row_stats_kernel); b0 = first sample of this launch, N = samples of the batch   // planes: 1 = W only; 2 = W and CL (third plane); 3 = W, CB, CL (one-hot df corrections); 4 = W, CB, CL and a plane of c
-                        // that is written INTO the record table's memory (stride Upad <= 4 maxU floats) instead of
-                        // the records -- with the one-hot DF nothing reads cb / cl / label per record any more,
-                        // and 16 instead of 28 bytes leave per cell
+        int planes, const long long* __restrict__ offsets, int lw, int lsh, int b0, int N, int* __restrict__ padflag) {   // offsets: packed row order (see row_stats_kernel); b0 = first sample of this launch, N = samples of the batch   // planes: 1 = W only; 2 = W and CL (third plane); 3 = W, CB, CL (one-hot df corrections); 4 = W, CB, CL, no records; the c of a FAR cell (W = kJointFarMark) is
+                        // written INTO the record table's memory at the plane index (stride Upad <= 4 maxU floats) -- with the
+                        // one-hot DF nothing reads cb / cl / label per record any more, and 12 instead of 28 bytes leave per cell
     const int b = b0 + blockIdx.y;
     const unsigned per = gridDim.x >> 3;
     const unsigned blk = (blockIdx.x & 7u) * per + (blockIdx.x >> 3);
@@ -1593,10 +1598,10 @@ __global__ __launch_bounds__(256) void coef_cell_kernel(
     if (wmat != nullptr) {                                    // additive joint only: W = exp(c), cb, cl; row stride Upad
         const float c = static_cast<float>(o.x);
         const size_t at = (static_cast<size_t>(b) * maxT + t) * Upad + u;
-        wmat[at] = c > kJointFarC ? 0.0f : fast_exp(c);
+        wmat[at] = c > kJointFarC ? kJointFarMark : fast_exp(c);
         if (planes >= 3) wmat[plane + at] = static_cast<float>(o.y);
-            if (planes >= 2) wmat[2 * plane + at] = static_cast<float>(o.z);
-        if (planes == 4) reinterpret_cast<float*>(rowtab)[at] = c;   // plane of c in place of the records
+        if (planes >= 2) wmat[2 * plane + at] = static_cast<float>(o.z);
+        if (planes == 4 && c > kJointFarC) reinterpret_cast<float*>(rowtab)[at] = c;   // (rare) the far cell's c, in the record table's memory
         if (u == maxU - 1)                                    // the row's pad columns [maxU, Upad) are zero
             for (int k = 1; k <= Upad - maxU; ++k)
                 for (int pl = 0; pl < 3; ++pl)
@@ -1727,14 +1732,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void c
             if (t >= Tb || u >= Ub) *padflag = 1;          // the batch has padded rows: the gradient kernel may skip their logits
         }
         if (wmat != nullptr) {                             // additive joint only: W = exp(c), cb, cl; row stride Upad
-            // planes: 1 W | 2 W, CL | 3 W, CB, CL | 4 W, CB, CL and the plane of c in place of the records | 5 (SUMS only) as 4 WITHOUT
+            // planes: 1 W | 2 W, CL | 3 W, CB, CL | 4 W, CB, CL, no records (a far cell's c goes where its record would start) | 5 (SUMS only) as 4 WITHOUT
             // the CB plane: the DF kernel takes its blank corrections from the row sums formed above, nothing reads cb per cell
             const float cc = static_cast<float>(o.x);
             const size_t at = (static_cast<size_t>(b) * maxT + t) * Upad + u;
-            wmat[at] = cc > kJointFarC ? 0.0f : fast_exp(cc);
+            wmat[at] = cc > kJointFarC ? kJointFarMark : fast_exp(cc);
             if (planes == 3 || planes == 4) wmat[plane + at] = static_cast<float>(o.y);
             if (planes >= 2) wmat[2 * plane + at] = static_cast<float>(o.z);
-            if (planes >= 4) reinterpret_cast<float*>(rowtab)[at] = cc;   // plane of c in place of the records
+            if (planes >= 4 && cc > kJointFarC) reinterpret_cast<float*>(rowtab)[at] = cc;   // (rare) the far cell's c, in the record table's memory
             if (u == maxU - 1)                             // the row's pad columns [maxU, Upad) are zero
                 for (int k = 1; k <= Upad - maxU; ++k)
                     for (int pl = 0; pl < 3; ++pl)

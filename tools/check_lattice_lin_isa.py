@@ -20,12 +20,13 @@ import sys
 import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SRC = os.path.join(ROOT, "warp-transducer_amd", "csrc", "rnnt_gpu.hip")
+# both translation units instantiate the kernel (launch_lattice lives in rnnt_host.h): two code objects, two copies to check
+SRCS = [os.path.join(ROOT, "warp-transducer_amd", "csrc", name) for name in ("rnnt_gpu.hip", "rnnt_joint.hip")]
 PFD, KW = 8, 4                                   # lattice_lin_body: chunks in flight, rows per operand wavefront and chunk
 VMEM = re.compile(r"^(buffer|global|flat|scratch)_(load|store|atomic)")
 
 
-def device_asm(path=None):
+def device_asm(path=None, SRC=SRCS[0]):
     if path:
         return open(path).read()
     with tempfile.TemporaryDirectory() as tmp:
@@ -109,11 +110,14 @@ def check(asm):
 
 
 if __name__ == "__main__":
-    probs = check(device_asm(sys.argv[1] if len(sys.argv) > 1 else None))
+    if len(sys.argv) > 1:
+        probs = check(device_asm(sys.argv[1]))
+    else:
+        probs = [os.path.basename(src) + ": " + p for src in SRCS for p in check(device_asm(None, src))]
     if probs:
         print("lattice_lin_kernel: the hand-counted vmcnt of the operand role is NOT safe with this build:")
         for p in probs:
             print("  *", p)
         sys.exit(1)
     print("lattice_lin_kernel: operand role holds exactly its hand-written vector-memory instructions "
-          "(%d requests in flight, %d per refill); no scratch, no spills" % (PFD * KW, KW))
+          "(%d requests in flight, %d per refill); no scratch, no spills (both translation units)" % (PFD * KW, KW))

@@ -25,7 +25,7 @@ __all__ = ["rnnt_loss_add", "RNNTLossAdd"]
 _DT = {torch.float32: _lib.DT_F32, torch.bfloat16: _lib.DT_BF16, torch.float16: _lib.DT_F16}
 
 
-def _certify(trans_acts, pred_acts, labels, act_lens, label_lens):
+def _certify(trans_acts, pred_acts, labels, act_lens, label_lens, read_lengths=True):
     check_type(labels, torch.int32, "labels")
     check_type(label_lens, torch.int32, "label_lengths")
     check_type(act_lens, torch.int32, "lengths")
@@ -46,6 +46,8 @@ def _certify(trans_acts, pred_acts, labels, act_lens, label_lens):
         raise ValueError("trans_acts (B,T,V) and pred_acts (B,U+1,V) disagree")
     if act_lens.shape[0] != B or label_lens.shape[0] != B:
         raise ValueError("must have a length per example.")
+    if not read_lengths:
+        return
     if T != torch.max(act_lens):
         raise ValueError("Input length mismatch")
     if pred_acts.shape[1] != torch.max(label_lens) + 1:
@@ -58,8 +60,8 @@ class _RNNTAdd(Function):
     pass over d(trans_acts) / d(pred_acts), as in `warprnnt_pytorch._RNNT`."""
 
     @staticmethod
-    def forward(ctx, trans_acts, pred_acts, labels, act_lens, label_lens, blank, reduction, fastemit_lambda=0.0):
-        _certify(trans_acts, pred_acts, labels, act_lens, label_lens)
+    def forward(ctx, trans_acts, pred_acts, labels, act_lens, label_lens, blank, reduction, fastemit_lambda=0.0, validate=True):
+        _certify(trans_acts, pred_acts, labels, act_lens, label_lens, validate)
         lib = _lib.lib()
         B, T, V = trans_acts.shape
         U = pred_acts.shape[1]
@@ -109,34 +111,39 @@ class _RNNTAdd(Function):
                                                   _DT[trans_acts.dtype])
             _lib.check(st, "compute_rnnt_loss_add_bwd")
             ctx.workspace.record_stream(torch.cuda.current_stream(dev))
-        return df, dg, None, None, None, None, None, None
+        return df, dg, None, None, None, None, None, None, None
 
 
 _REDUCTIONS = {"none": 0, "sum": 1, "mean": 2}
 
 
 def rnnt_loss_add(trans_acts, pred_acts, labels, act_lens, label_lens, blank=0, reduction="mean",
-                  fastemit_lambda=0.0):
+                  fastemit_lambda=0.0, validate=True):
     """RNN-T loss of the additive joint ``trans_acts[:, :, None] + pred_acts[:, None]`` without
     forming it.  Arguments as `rnnt_loss`, with the two activations instead of the joint tensor
     (float32, bfloat16 or float16; the loss is float32, the gradients have the activations' dtype).
 
     With the compiled extension module loaded (`warp_rnnt.binding() == "ext"`) the whole loss is its C++
     autograd function `rnnt_loss_add` (csrc/binding.cpp: the same checks, allocations and the two
-    library calls without returning to Python); `_RNNTAdd` below is the ctypes twin."""
+    library calls without returning to Python); `_RNNTAdd` below is the ctypes twin.
+
+    validate=False (as in `rnnt_loss`) skips the two checks that need the VALUES of the lengths (T == max(act_lens),
+    U == max(label_lens) + 1: a device-to-host read and a synchronisation per call); without them the call only
+    enqueues -- forward AND backward can then be captured in a HIP graph with the rest of a training step
+    (tests/test_gpu_graph_step.py)."""
     from . import warp_rnnt
     ext = getattr(warp_rnnt, "_EXT", None)
     if ext is not None and reduction in _REDUCTIONS and isinstance(trans_acts, torch.Tensor) and trans_acts.is_cuda:
         return ext.rnnt_loss_add(trans_acts, pred_acts, labels, act_lens, label_lens, int(blank), _REDUCTIONS[reduction],
-                                 float(fastemit_lambda), True)
-    return _RNNTAdd.apply(trans_acts, pred_acts, labels, act_lens, label_lens, blank, reduction, fastemit_lambda)
+                                 float(fastemit_lambda), bool(validate))
+    return _RNNTAdd.apply(trans_acts, pred_acts, labels, act_lens, label_lens, blank, reduction, fastemit_lambda, validate)
 
 
 class RNNTLossAdd(Module):
-    def __init__(self, blank=0, reduction="mean", fastemit_lambda=0.0):
+    def __init__(self, blank=0, reduction="mean", fastemit_lambda=0.0, validate=True):
         super().__init__()
-        self.blank, self.reduction, self.fastemit_lambda = blank, reduction, fastemit_lambda
+        self.blank, self.reduction, self.fastemit_lambda, self.validate = blank, reduction, fastemit_lambda, validate
 
     def forward(self, trans_acts, pred_acts, labels, act_lens, label_lens):
         return rnnt_loss_add(trans_acts, pred_acts, labels, act_lens, label_lens, self.blank, self.reduction,
-                             self.fastemit_lambda)
+                             self.fastemit_lambda, self.validate)

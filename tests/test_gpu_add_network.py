@@ -13,6 +13,8 @@ SHAPES = [  # N, T, U, A
     (2, 40, 16, 64), (1, 1, 1, 9), (2, 5, 1, 33), (2, 1, 6, 31), (3, 65, 33, 100),
     (2, 40, 35, 2048), (1, 34, 5, 5000), (2, 31, 70, 1030),   # vocabulary split over 8 / 4 wavefronts of a tile
     (2, 65, 34, 56), (2, 40, 70, 57), (3, 33, 33, 2), (2, 64, 64, 50),   # either side of the small-vocabulary Z kernel's limit
+    (2, 600, 5, 300), (1, 520, 3, 129),    # long utterances: DG splits the contraction over t for any vocabulary (T >= 512)
+    (2, 30, 70, 128), (2, 20, 66, 256),    # DF columns per lane follow the vocabulary (A = 128: one, A = 256: two)
 ]
 
 
@@ -327,7 +329,8 @@ def test_validation_errors():
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("shape", [(3, 20, 9, 40), (2, 33, 21, 257), (2, 40, 35, 2048), (2, 9, 300, 7), (1, 34, 5, 5000),
-                                   (2, 40, 70, 57), (2, 65, 34, 56), (1, 1, 1, 9), (2, 31, 70, 1030), (3, 65, 33, 100)])
+                                   (2, 40, 70, 57), (2, 65, 34, 56), (1, 1, 1, 9), (2, 31, 70, 1030), (3, 65, 33, 100),
+                                   (2, 600, 5, 300), (2, 30, 70, 128), (2, 20, 66, 256)])   # split DG at long T; DF columns per lane by vocabulary
 def test_sixteen_bit_activations(oracle, dtype, shape):
     """bfloat16 / float16 STORAGE of both activations and both gradients (compute_rnnt_loss_add_fwd_dt / _bwd_dt: the
     kernels read and write the 16-bit tensors directly and compute in fp32): the loss against the oracle on the

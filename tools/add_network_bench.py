@@ -18,7 +18,8 @@ for p in (ROOT, os.path.join(ROOT, "warp-transducer_amd")):
 import torch
 from warprnnt_pytorch import _lib, warp_rnnt
 
-SHAPES = {"c2": (16, 150, 41, 28), "c3": (128, 150, 21, 5000), "c4": (64, 1500, 301, 50), "c5f32": (128, 200, 41, 1024)}
+SHAPES = {"c2": (16, 150, 41, 28), "c3": (128, 150, 21, 5000), "c4": (64, 1500, 301, 50), "c5f32": (128, 200, 41, 1024),
+          "long128": (32, 1500, 301, 128), "long256": (32, 1500, 301, 256), "long1024": (16, 1500, 301, 1024)}   # long utterances, mid-size vocabularies
 dev = torch.device("cuda:0")
 lib = _lib.lib()
 HALF = torch.bfloat16 if "--bf16" in sys.argv else (torch.float16 if "--fp16" in sys.argv else None)

@@ -179,12 +179,26 @@ static rnntStatus_t run_gpu_joint(const typename Tag::store* f, const typename T
                         : (A % 2 == 0 && (all4 & (2 * sizeof(S) - 1)) == 0 && A >= 48) ? 2 : 1;
         const Tune& tn = tune();
         auto pick = [&](int want) { int nk = want > 0 ? want : NKmax; while (nk > NKmax) nk >>= 1; return nk; };
-        const int NKf = pick(tn.jfnk), NKg = pick(tn.jgnk);
+        int NKf = pick(tn.jfnk);
+        const int NKg = pick(tn.jgnk);
+        auto groups = [&](int nk) { return (A + 32 * nk - 1) / (32 * nk); };   // 32 NK-column groups of the vocabulary
+        if (tn.jfnk <= 0) {
+            // DF, columns per lane: at most 64 symbols and long label rows -> ONE group of 64 columns whose contraction the
+            // block's wavefronts split (below); otherwise the widest NK that still gives each of the block's four wavefronts
+            // columns to work on (a block spans 128 NK columns: at A = 256, NK = 4 leaves two of them idle -- long utterances,
+            // fp32: 353 us against 194 with NK = 2; 16-bit storage halves the register budget per column once more: NK = 1
+            // 198 us against 245)
+            if (A <= 64 && maxU >= 64) NKf = NKf < 2 ? NKf : 2;
+            else while (NKf > 1 && 128 * NKf * (sizeof(S) == 2 ? 2 : 1) > A) NKf >>= 1;
+        }
         // small vocabularies (one or two column groups): the four wavefronts of a block split the CONTRACTION instead of the
         // columns (joint_df_kernel, SPLIT) -- when it is long enough to be worth the reduction
         const bool nocb = onehot && joint_planes_onehot(maxU) == 4 && coef_is_tiled(p) && tn.jfsum && tn.jnocb;
-        const bool split_f = tn.jsplit && (A + 32 * NKf - 1) / (32 * NKf) <= 2 && maxU >= 64;
-        const bool split_g = tn.jsplit && (A + 32 * NKg - 1) / (32 * NKg) <= 2 && maxT >= 64;
+        // (DF: never with four columns per lane -- that instantiation needs more than 512 registers; jsplit = 2: dev, any vocabulary)
+        const bool split_f = tn.jsplit && NKf <= 2 && maxU >= 64 && (groups(NKf) <= 2 || tn.jsplit >= 2);
+        // DG: also whenever the contraction over t is LONG, whatever the vocabulary -- the block count of the column-split form does
+        // not grow with T (N=16, T=1500, U=301, A=1024: 320 blocks, 276 us; split 192 us), at T = 150 / 200 the split form loses 5-10 %
+        const bool split_g = tn.jsplit && maxT >= 64 && (groups(NKg) <= 2 || maxT >= 512 || tn.jsplit >= 2);
 #define RNNT_JDF_SPLIT(NN, OO)                                                                                   \
     hipLaunchKernelGGL((joint_df_kernel<Tag, NN, true, OO, true, false>), dim3((A + 32 * NN - 1) / (32 * NN), tilesT, N), dim3(256), 0, \
                        p.stream, f, g, p.rowmax, p.wmat, grad_scale, labels, input_lengths, label_lengths, df, maxT,  \
@@ -226,10 +240,10 @@ static rnntStatus_t run_gpu_joint(const typename Tag::store* f, const typename T
             }
         }
         if (df16) { /* launched above */ }
-        else if (split_f && onehot && nocb) { if (NKf == 4) RNNT_JDF_SPLIT_BS(4); else if (NKf == 2) RNNT_JDF_SPLIT_BS(2); else RNNT_JDF_SPLIT_BS(1); }
+        else if (split_f && onehot && nocb) { if (NKf == 2) RNNT_JDF_SPLIT_BS(2); else RNNT_JDF_SPLIT_BS(1); }
         else if (onehot && nocb) { if (NKf == 4) RNNT_JDF_BS(4); else if (NKf == 2) RNNT_JDF_BS(2); else RNNT_JDF_BS(1); }
-        else if (split_f && onehot) { if (NKf == 4) RNNT_JDF_SPLIT(4, true); else if (NKf == 2) RNNT_JDF_SPLIT(2, true); else RNNT_JDF_SPLIT(1, true); }
-        else if (split_f) { if (NKf == 4) RNNT_JDF_SPLIT(4, false); else if (NKf == 2) RNNT_JDF_SPLIT(2, false); else RNNT_JDF_SPLIT(1, false); }
+        else if (split_f && onehot) { if (NKf == 2) RNNT_JDF_SPLIT(2, true); else RNNT_JDF_SPLIT(1, true); }
+        else if (split_f) { if (NKf == 2) RNNT_JDF_SPLIT(2, false); else RNNT_JDF_SPLIT(1, false); }
         else if (onehot)  { if (NKf == 4) RNNT_JDF(4, true, true); else if (NKf == 2) RNNT_JDF(2, true, true); else RNNT_JDF(1, true, true); }
         else if (pf_f) { if (NKf == 4) RNNT_JDF(4, true, false); else if (NKf == 2) RNNT_JDF(2, true, false); else RNNT_JDF(1, true, false); }
         else              { if (NKf == 4) RNNT_JDF(4, false, false); else if (NKf == 2) RNNT_JDF(2, false, false); else RNNT_JDF(1, false, false); }

@@ -207,13 +207,13 @@ static void ranges_mark(int i, bool do_fwd, bool do_bwd, const char* const names
 // j16 = bf16 storage on the bf16 matrix cores (rnnt_joint16_kernels.h), bit 0 DG, bit 1 DF, bit 2 Z; j16pf = operand ping-pong there, j16nt = columns per lane of its DF / DG (8 | 4),
 // latlin = linear-domain lattice kernel (chain + helper wavefronts) for one-wavefront fp32 lattices: 0 off, 1 up to one block per CU,
 //          2 at any size and every block takes the log-domain fallback (tests), 3 at any size,
-// tile2d = 2-D cell-tile statistics kernel for short rows under wide lattices on/off,
+// tile2d = 2-D cell-tile statistics kernel for short rows under wide lattices: 0 off, 1 = 8 x 32 cells per block, 2 = 16 x 16 (default),
 // jfsum = additive joint: the correction sums of the gradient GEMMs formed inside the tiled coefficient kernel on/off,
 // jsplit = additive joint, small vocabularies: the wavefronts of a DF / DG block split the contraction instead of the columns on/off,
 // jnocb = additive joint, one-hot DF behind the tiled coefficient kernel: blank corrections from the row sums, no CB plane on/off.
 struct Tune { int sw = 4, nta = 1, gmax = 4194304, rows = 0, tile = 1, tilekb = 52, ppt = 2;
               int jfnk = 0, jfpf = 1, jgnk = 0, jgpf = 1, blk = 1, jzs = 0, xcd = 1, ctile = 1, pskip = 1, joh = -1;
-              int lat2 = -1, xst = 0, jsamp = 1, tilemax = kTileMaxRowBytes, j16 = 7, j16pf = 1, j16nt = 4, tile2d = 1, latlin = 1, pskipb = 8192, pskipmin = 128, jfsum = 1, jsplit = 1, jnocb = 1; };
+              int lat2 = -1, xst = 0, jsamp = 1, tilemax = kTileMaxRowBytes, j16 = 7, j16pf = 1, j16nt = 4, tile2d = 2, latlin = 1, pskipb = 8192, pskipmin = 128, jfsum = 1, jsplit = 1, jnocb = 1; };
 #ifdef RNNT_DEV
 static Tune read_tune() {
     Tune t;
@@ -238,7 +238,11 @@ static Tune read_tune() {
     return t;
 }
 static const Tune& tune() {
-    static const Tune t = read_tune();     // function-local static: initialised once, thread-safe
+    // RNNT_TUNE_LIVE set: RNNT_TUNE is read again on EVERY call, so one process can alternate variants on the same buffers
+    // (some kernels' times depend on where the process's memory landed: tools/c4_align_probe.py).  Dev build, one thread.
+    static const bool live = getenv("RNNT_TUNE_LIVE") != nullptr;
+    static Tune t = read_tune();           // function-local static: initialised once, thread-safe
+    if (live) t = read_tune();
     return t;
 }
 #else

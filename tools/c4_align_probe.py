@@ -51,6 +51,14 @@ if os.environ.get("RNNT_TUNE_LIVE"):       # dev library: alternate kernel varia
             m = run(0, 0)
             print("%-16s statistics %.4f  lattice %.4f  coefficients %.4f  gradient %.4f  (ms)" % (v, m[0], m[1], m[2], m[3]))
     sys.exit(0)
+if os.environ.get("PROBE_FAR"):            # large relative shifts of the workspace (64 MB ... 1 GB) against the activations
+    BIG = 1 << 30
+    wbig = torch.empty(wsb + BIG + PAD, dtype=torch.uint8, device=dev)
+    wraw = wbig
+    for woff in [0, 1 << 26, 1 << 27, 3 << 26, 1 << 28, 5 << 26, 1 << 29, (1 << 29) + (1 << 26), 7 << 27, 1 << 30, 0]:
+        m = run(0, woff)
+        print("ws +%-11d statistics %.4f  lattice %.4f  coefficients %.4f  gradient %.4f  (ms)" % (woff, m[0], m[1], m[2], m[3]))
+    sys.exit(0)
 for aoff, woff in [(0, 0), (0, 256), (0, 4096), (0, 65536), (0, 1 << 20), (0, (2 << 20) + 256), (16, 0), (4096, 0), (65536, 0), (1 << 20, 0),
                    ((1 << 20) + 4096, 4096), (0, 0)]:
     m = run(aoff, woff)

@@ -123,9 +123,9 @@ static rnntStatus_t run_gpu_joint(const typename Tag::store* f, const typename T
             p.check();
             if (small)
                 hipLaunchKernelGGL((joint_z_small_kernel<Tag>), dim3(((tiles + 3) / 4 + 7) / 8 * 8, N), dim3(256),
-                                   4 * kJointZSmallSlice * sizeof(float), p.stream, f, g, p.rowmax, labels,
+                                   4 * joint_z_small_slice(A) * sizeof(float), p.stream, f, g, p.rowmax, labels,
                                    input_lengths, label_lengths, p.lp2, p.logz, maxT, maxU, p.Up, A, p.blank, tilesU,
-                                   tiles, N, p.poison);
+                                   tiles, N, p.poison, joint_z_small_slice(A));
             else
                 RNNT_JZ_ALL(false, no_gate);
         }

@@ -512,15 +512,22 @@ constexpr int kJointZSmallA = 56;
 constexpr int kJointZSmallIt = kJointZSmallA / 2;          // flat loads per lane and operand (32 rows * A / 64)
 constexpr int kJointZOutPad = 34;                          // row stride of the turned tile (diagonal reads hit distinct banks)
 constexpr int kJointZSmallOp = 32 * (kJointZSmallA + 1);   // floats per operand
-constexpr int kJointZSmallSlice = 2 * kJointZSmallOp + 64; // per wavefront (>= 3 * 32 * kJointZOutPad); 4 slices < 64 KB
+constexpr int kJointZSmallSlice = 2 * kJointZSmallOp + 64; // per wavefront at the LARGEST vocabulary; 4 slices < 64 KB
 static_assert(kJointZSmallSlice >= 3 * 32 * kJointZOutPad && 4 * kJointZSmallSlice * 4 <= 65536, "LDS budget");
+// The slice for THIS vocabulary: both raw operands at row stride A | 1 plus the spare words, and never less than the turned
+// output tile.  Sized at run time because the block count per CU hangs on it: 4 x 59 KB allows two blocks, at A <= 50 the
+// 4 x 13.3 KB of the real rows allow THREE (the kernel needs 148 registers: three wavefronts per SIMD fit).
+__host__ __device__ inline int joint_z_small_slice(int A) {
+    const int need = 2 * 32 * (A | 1) + 64, out = 3 * 32 * kJointZOutPad;
+    return ((need > out ? need : out) + 3) & ~3;
+}
 
 template <typename Tag>
 __global__ __launch_bounds__(256) void joint_z_small_kernel(
         const typename Tag::store* __restrict__ f, const typename Tag::store* __restrict__ g, const float* __restrict__ rowmax,
         const int* __restrict__ labels, const int* __restrict__ xlen, const int* __restrict__ ylen,
         LogPair<float>* __restrict__ lp2, float* __restrict__ logz, int maxT, int maxU, int Up, int A,
-        int blank, int tilesU, int tiles, int N, int* __restrict__ poison) {
+        int blank, int tilesU, int tiles, int N, int* __restrict__ poison, int slice) {   // slice: joint_z_small_slice(A) floats of LDS per wavefront
     extern __shared__ float4 zsmall4[];
     constexpr int IT = kJointZSmallIt;
     const int AS = A | 1;                                  // LDS row stride
@@ -539,9 +546,9 @@ __global__ __launch_bounds__(256) void joint_z_small_kernel(
     const float* mf = rowmax + static_cast<size_t>(b) * maxT;
     const float* mg = rowmax + static_cast<size_t>(N) * maxT + static_cast<size_t>(b) * maxU;
     const float* sentinel = rowmax + static_cast<size_t>(N) * (maxT + maxU);      // +inf: exp(x - inf) = 0
-    float* fs = reinterpret_cast<float*>(zsmall4) + wave * kJointZSmallSlice;     // [32][AS] raw f
-    float* gs = fs + kJointZSmallOp;                                              // [32][AS] raw g
-    float* spare = gs + kJointZSmallOp;
+    float* fs = reinterpret_cast<float*>(zsmall4) + wave * slice;                 // [32][AS] raw f
+    float* gs = fs + 32 * AS;                                                     // [32][AS] raw g
+    float* spare = gs + 32 * AS;
 
     // ---- every global load of the tile is requested here, before anything waits
     const int nf = (Tb - t0 < 32 ? Tb - t0 : 32) * A, ng = (Ub - u0 < 32 ? Ub - u0 : 32) * A;   // valid flat elements

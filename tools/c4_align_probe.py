@@ -10,25 +10,31 @@ from warprnnt_pytorch import _lib
 lib = _lib.lib()
 dev = torch.device("cuda:0")
 N, T, U, A = 64, 1500, 301, 50
+DT, ES, TDT = 0, 4, torch.float32                      # PROBE_SHAPE=N,T,U,A[,bf16]: another workload (default: c4, fp32)
+if os.environ.get("PROBE_SHAPE"):
+    parts = os.environ["PROBE_SHAPE"].split(",")
+    N, T, U, A = (int(x) for x in parts[:4])
+    if len(parts) > 4 and parts[4] == "bf16":
+        DT, ES, TDT = 2, 2, torch.bfloat16
 E = N * T * U * A
 PAD = 8 << 20
-raw = torch.empty(E * 4 + 2 * PAD, dtype=torch.uint8, device=dev)
-graw = torch.empty(E * 4 + 2 * PAD, dtype=torch.uint8, device=dev)
+raw = torch.empty(E * ES + 2 * PAD, dtype=torch.uint8, device=dev)
+graw = torch.empty(E * ES + 2 * PAD, dtype=torch.uint8, device=dev)
 lab = torch.randint(1, A, (N, U - 1), device=dev, dtype=torch.int32)
 tl = torch.full((N,), T, dtype=torch.int32, device=dev)
 ll = torch.full((N,), U - 1, dtype=torch.int32, device=dev)
 costs = torch.empty(N, device=dev)
-wsb = _lib.workspace_bytes(T, U, N, True, 4)
+wsb = _lib.workspace_bytes(T, U, N, True, ES)
 wraw = torch.empty(wsb + 2 * PAD, dtype=torch.uint8, device=dev)
 print("base addresses: acts %#x grads %#x ws %#x" % (raw.data_ptr(), graw.data_ptr(), wraw.data_ptr()))
-src = torch.rand(E // 8, device=dev)
+src = torch.rand(E // 8, device=dev).to(TDT)
 stream = torch.cuda.current_stream().cuda_stream
 
 def run(aoff, woff, reps=6):
-    a = raw[aoff:aoff + E * 4].view(torch.float32)
+    a = raw[aoff:aoff + E * ES].view(TDT)
     for i in range(8):
         a[i * (E // 8):(i + 1) * (E // 8)].copy_(src)
-    g = graw[aoff:aoff + E * 4].view(torch.float32)
+    g = graw[aoff:aoff + E * ES].view(TDT)
     ws = wraw[woff:woff + wsb]
     opt = _lib.rnntOptions(loc=1, num_threads=0, stream=stream, blank_label=0, maxT=T, maxU=U, batch_first=True)
     lib.rnnt_profile_reset(); lib.rnnt_profile_enable(1)
@@ -36,7 +42,7 @@ def run(aoff, woff, reps=6):
         if i == 2:
             torch.cuda.synchronize(); lib.rnnt_profile_collect(); lib.rnnt_profile_reset()
         st = lib.compute_rnnt_loss_async(a.data_ptr(), g.data_ptr(), lab.data_ptr(), ll.data_ptr(), tl.data_ptr(), A, N,
-                                         costs.data_ptr(), None, ws.data_ptr(), opt, 0)
+                                         costs.data_ptr(), None, ws.data_ptr(), opt, DT)
         assert st == 0
         torch.cuda.synchronize(); lib.rnnt_profile_collect()
     ms = (ctypes.c_double * 5)()

@@ -145,7 +145,7 @@ static rnntStatus_t run_gpu_joint(const typename Tag::store* f, const typename T
     // the speed -- c4 shape 0.81 vs 0.51 ms for the backward phase -- so 16-bit keeps the epilogue corrections, except:)
     // 16-bit storage, at most two 32-column groups, long label rows: there the split-contraction DF kernel without the CB
     // operand (SPLIT, BS below) fits 248 registers and the one-hot form wins as it does for fp32 (c4 shape, bf16: backward
-    // 0.300 -> 0.233 ms, and the coefficient kernel writes three planes instead of records + two: 0.366 -> 0.318 ms)
+    // 0.300 -> 0.233 ms, and the coefficient kernel writes W and CL only instead of records + two planes: 0.366 -> 0.27 ms)
     const bool onehot16 = A <= 64 && maxU >= 64 && joint_planes_onehot(maxU) == 4 && coef_is_tiled(p) && tune().jfsum &&
                           tune().jnocb && tune().jsplit;
     const bool onehot = tune().joh >= 0 ? tune().joh != 0 : (A <= 256 && (sizeof(S) == 4 || onehot16));

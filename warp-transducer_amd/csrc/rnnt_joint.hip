@@ -63,7 +63,8 @@ static rnntStatus_t run_gpu_joint(const typename Tag::store* f, const typename T
     if (do_fwd) {   // row maxima, then the partition-function GEMM with the log-prob epilogue
         const long long rows = static_cast<long long>(N) * (maxT + maxU);
         const bool per_block = static_cast<size_t>(A) * sizeof(S) >= 12288;       // long rows: a block per row
-        const dim3 rgrid(static_cast<unsigned>(per_block ? rows : (rows + 3) / 4));
+        const bool per_lanes = A <= 64;                                            // short rows: eight lanes per row
+        const dim3 rgrid(static_cast<unsigned>(per_block ? rows : per_lanes ? (rows + 31) / 32 : (rows + 3) / 4));
         // vocabulary slices per tile: few tiles and a long contraction -> split it over 4 or 8 wavefronts
         const long long all_tiles = static_cast<long long>(N) * tiles;
         const int nchunk = (A + 31) / 32;
@@ -87,6 +88,7 @@ static rnntStatus_t run_gpu_joint(const typename Tag::store* f, const typename T
 #define RNNT_JMAX_ALL(SIDE, GATE)                                                                               \
         do {                                                                                                    \
             if (per_block) { if (vec) RNNT_JMAX(true, 4, SIDE, GATE); else RNNT_JMAX(false, 4, SIDE, GATE); }   \
+            else if (per_lanes) RNNT_JMAX(false, 0, SIDE, GATE);                                                \
             else { if (vec) RNNT_JMAX(true, 1, SIDE, GATE); else RNNT_JMAX(false, 1, SIDE, GATE); }             \
         } while (0)
 #define RNNT_JZ(SS, VV, SAMP, GATE)                                                                              \

@@ -57,9 +57,9 @@ __device__ __forceinline__ float joint_exp(float x, float m2) {
 // ------------------------------------------------------------------------------------------
 // Row maxima, stored TIMES log2(e).  rowmax[0, N*maxT) = mf, rowmax[N*maxT, N*(maxT+maxU)) = mg,
 // rowmax[N*(maxT+maxU)] = +inf (sentinel).
-// WPR wavefronts share a row (1: wavefront per row; 4: the whole block, for rows >= 12 KB, so that the
+// WPR wavefronts share a row (0: eight LANES per row, rows of at most 64 symbols; 1: wavefront per row; 4: the whole block, for rows >= 12 KB, so that the
 // rows in flight form one contiguous window -- see row_stats_block_kernel); rows of the padding
-// (t >= T_b, u > U_b) are skipped.  grid = ceil(rows * WPR / 4), block = 256.
+// (t >= T_b, u > U_b) are skipped.  grid = ceil(rows * WPR / 4) (WPR = 0: ceil(rows / 32)), block = 256.
 template <typename Tag, bool VEC, int WPR>
 __global__ __launch_bounds__(256) void joint_rowmax_kernel(
         const typename Tag::store* __restrict__ f, const typename Tag::store* __restrict__ g, const int* __restrict__ xlen,
@@ -69,7 +69,7 @@ __global__ __launch_bounds__(256) void joint_rowmax_kernel(
     // second, exact pass of the sampled-reference forward (joint_z_kernel, SAMPLED): only if a row tripped the guard
     if (gate != nullptr && *gate != seq) return;
     // the correction sums of joint_sums_kernel (N*(maxT + 2 maxU) floats + N flags) start at zero: the grid has at
-    // least 64 threads per row of f and g, more than that many words
+    // least 8 threads per row of f and g, more than that many words
     {
         const unsigned long long gid = static_cast<unsigned long long>(blockIdx.x) * 256 + threadIdx.x;
         if (side != nullptr && gid < nside) side[gid] = 0.0f;
@@ -77,7 +77,34 @@ __global__ __launch_bounds__(256) void joint_rowmax_kernel(
     // one extra entry after the maxima holds +inf: operand loads of the gradient GEMMs point masked
     // rows at it, which makes their exp() exactly 0 without a select on loaded data
     if (blockIdx.x == 0 && threadIdx.x == 0) rowmax[static_cast<size_t>(N) * (maxT + maxU)] = -neg_inf<float>();
-    constexpr int TPR = 64 * WPR;                          // threads per row
+    if constexpr (WPR == 0) {
+        // short rows (A <= 64): EIGHT lanes per row, eight rows per wavefront -- with a wavefront per row the c4 shape of the
+        // additive joint (115 264 rows of 50 symbols) was a launch of 115 264 wavefronts with one load each, 27 us
+        const long long row = static_cast<long long>(blockIdx.x) * 32 + (threadIdx.x >> 3);
+        const long long rows_f = static_cast<long long>(N) * maxT;
+        const int sub = threadIdx.x & 7;
+        bool live = row < rows_f + static_cast<long long>(N) * maxU;
+        const typename Tag::store* p = f;
+        if (live) {
+            if (row < rows_f) {
+                const int b = static_cast<int>(row / maxT);
+                live = static_cast<int>(row - static_cast<long long>(b) * maxT) < xlen[b];
+                p = f + row * A;
+            } else {
+                const long long r = row - rows_f;
+                const int b = static_cast<int>(r / maxU);
+                live = static_cast<int>(r - static_cast<long long>(b) * maxU) <= ylen[b];
+                p = g + r * A;
+            }
+        }
+        float m = neg_inf<float>();
+        if (live)
+            for (int i = sub; i < A; i += 8) m = fmaxf(m, load1<Tag>(p + i));
+        m = fmaxf(m, __shfl_xor(m, 1)); m = fmaxf(m, __shfl_xor(m, 2)); m = fmaxf(m, __shfl_xor(m, 4));
+        if (live && sub == 0) rowmax[row] = fmaxf(m, kJointMinMax) * static_cast<float>(kLog2e);
+        return;
+    }
+    constexpr int TPR = 64 * (WPR > 0 ? WPR : 1);          // threads per row
     const int wave = threadIdx.x >> 6;
     const long long row = WPR == 4 ? static_cast<long long>(blockIdx.x)
                                    : static_cast<long long>(blockIdx.x) * 4 + wave;

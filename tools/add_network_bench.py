@@ -62,6 +62,21 @@ for name in [a for a in sys.argv[1:] if not a.startswith("--")] or ["c3"]:
         warp_rnnt.gpu_rnnt_async(joint, labels, tl, ll, costs, grads, 0, workspace=ws)
         return grads.sum(2), grads.sum(1)
 
+    if os.environ.get("RNNT_TUNE_LIVE") and os.environ.get("VARIANTS"):
+        # dev library: alternate RNNT_TUNE variants INSIDE this process on the same buffers (VARIANTS="a=1;b=2,c=3;...")
+        for rep in range(2):
+            for v in os.environ["VARIANTS"].split(";"):
+                os.environ["RNNT_TUNE"] = v
+                for _ in range(3):
+                    fused()
+                torch.cuda.synchronize()
+                lib.rnnt_profile_reset(); lib.rnnt_profile_enable(1)
+                for _ in range(10):
+                    fused(); torch.cuda.synchronize(); lib.rnnt_profile_collect()
+                lib.rnnt_profile_enable(0)
+                st = (C.c_double * 5)(); n = lib.rnnt_profile_read(st, 5)
+                print("%s %-22s stages stats/lattice/coef/grad/span %s" % (name, v, [round(st[i] / max(n, 1), 4) for i in range(5)]))
+        continue
     out = {}
     for label, fn in (("fused", fused),) + (() if FUSED_ONLY else (("materialised", materialised),)):
         for _ in range(3):

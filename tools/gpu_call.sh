@@ -12,6 +12,8 @@ python bench.py > gpurun_out/${TAG}_bench_default.json 2> gpurun_out/${TAG}_benc
 timeout 1500 tools/gpu_profile.sh "$TAG" "c3 c4 c5 c2" pmc > gpurun_out/profile.log 2>&1
 # additive joint: fp32 / bf16 / fp16 storage, kernel traces of the c3 shape; RNNTLoss through autograd
 { python tools/add_network_bench.py c3 c5f32 c4 c2; python tools/add_network_bench.py --bf16 c3 c5f32; python tools/add_network_bench.py --fp16 c3 c5f32; } 2>&1 | grep -v amdgpu.ids > gpurun_out/${TAG}_add_network_bench.log
+{ python tools/add_network_bench.py --fused-only long128 long256 long1024; python tools/add_network_bench.py --bf16 c4 long128 long256 long1024; } 2>&1 | grep -v amdgpu.ids > gpurun_out/${TAG}_add_network_long.log
+python tools/add_network_fuzz.py 300 11 2>&1 | tail -1 > gpurun_out/${TAG}_add_network_fuzz.log
 python tools/autograd_bench.py c2 c3 c5 2>&1 | grep -v amdgpu.ids > gpurun_out/${TAG}_autograd_bench.log
 { python tools/binding_ab.py 1; python tools/binding_ab.py 0; } 2>&1 | grep validate > gpurun_out/${TAG}_binding_ab.log
 ( cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/profj && rocprofv3 --kernel-trace --stats -d /tmp/profj -o trace -- python $OLDPWD/tools/add_network_bench.py --bf16 c3 > /dev/null 2>&1; db=$(find /tmp/profj -name "*.db" | head -1); [ -n "$db" ] && python $OLDPWD/tools/rocpd_summary.py "$db" "$TAG additive joint, bf16 storage, c3 shape: rocprofv3 --kernel-trace --stats -- python tools/add_network_bench.py --bf16 c3" > $OLDPWD/gpurun_out/${TAG}_add_bf16_c3_kernel_trace.md )

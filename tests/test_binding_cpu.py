@@ -78,3 +78,26 @@ def test_extension_module_surface():
     assert np.abs(grads.numpy() - G.OPTIONS_LOGPROB_GRADS).max() < 1e-4
     assert warp_rnnt.cpu_rnnt(lp.half(), None, None, None, None, None, 0, 1) == -1   # unsupported dtype
     assert hasattr(warp_rnnt, "gpu_rnnt")
+
+
+def test_compiled_module_exports_and_additive_joint_checks():
+    """The compiled extension module carries the reference's two functions, the two-phase pair and both losses as C++ autograd
+    functions; the additive-joint loss refuses host tensors and wrong dtypes with the same exception types from the Python
+    checks (the C++ twin of these checks runs on the GPU box: tests/test_gpu_add_network.py::test_both_bindings)."""
+    import pytest
+    ext = getattr(warp_rnnt, "_EXT", None)
+    assert ext is not None, "the compiled extension module was not built (python warp-transducer_amd/warprnnt_pytorch/build_ext.py)"
+    for name in ("cpu_rnnt", "gpu_rnnt", "gpu_rnnt_fwd", "gpu_rnnt_bwd", "certify_inputs", "rnnt_loss", "rnnt_loss_add", "library_version"):
+        assert hasattr(ext, name), name
+    assert ext.library_version() == 1
+    from warprnnt_pytorch.add_network import RNNTLossAdd
+    f, g = torch.zeros(1, 4, 5), torch.zeros(1, 3, 5)
+    lab, tl, ll = torch.IntTensor([[1, 2]]), torch.IntTensor([4]), torch.IntTensor([2])
+    with pytest.raises(ValueError, match="GPU only"):
+        RNNTLossAdd()(f, g, lab, tl, ll)
+    with pytest.raises(ValueError, match="GPU only"):
+        RNNTLossAdd(validate=False)(f, g, lab, tl, ll)
+    with pytest.raises(TypeError, match="labels must be"):
+        RNNTLossAdd()(f, g, lab.long(), tl, ll)
+    with pytest.raises(ValueError, match="must be 3D"):
+        RNNTLossAdd()(f[0], g, lab, tl, ll)

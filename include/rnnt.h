@@ -435,9 +435,9 @@ rnntStatus_t compute_rnnt_loss_add_bwd(const float* const trans_acts,
  * computes in fp32 -- element-wise work and accumulation in fp32; with 16-bit storage, rows of whole 16-byte packets and 512
  * symbols or more the three contractions run on the bf16 matrix cores with every operand split into a bf16 hi + lo pair,
  * ~2^-17 relative per product, otherwise on the fp32 ones --; costs and grad_scale stay float).  Same workspace query, same
- * conventions.  One caveat of 16-bit GRADIENT storage: the rare "far" cells (rows of trans_acts and pred_acts peaking more than
- * 40 nats apart -- not reached by ordinary logits) are added to the stored gradients one cell at a time, each addition rounded
- * to the storage type; a gradient element that collects hundreds of them can be off by ~1 % (fp32 storage: exact path).  */
+ * conventions.  (The rare "far" cells -- rows of trans_acts and pred_acts peaking more than 40 nats apart, not reached by ordinary
+ * logits -- are summed in fp32 per row segment before they are added to a stored 16-bit gradient: at most ceil(maxU / 64) resp.
+ * ceil(maxT / 64) rounded additions per element.)  */
 rnntStatus_t compute_rnnt_loss_add_fwd_dt(const void* trans_acts,
                                           const void* pred_acts,
                                           const int* const flat_labels,

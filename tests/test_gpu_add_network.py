@@ -414,6 +414,36 @@ def _bf16_case(oracle, f, g, labels, tl, ll, blank, weights=None, dtype=torch.bf
     return tf.grad, tg.grad
 
 
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_sixteen_bit_far_cells_accumulate_in_fp32(oracle, dtype):
+    """16-bit gradient storage, HUNDREDS of far cells per gradient element (rows peaking 70-90 nats apart on a 520 x 300 lattice;
+    tools/add_network_fuzz.py seed 11 case 262): added one cell at a time, every addition rounded to fp16, a dg element came out
+    1.7354 for 1.7591.  joint_far16_kernel sums a row segment's far cells in fp32 first: within a few storage quanta now."""
+    from warprnnt_pytorch.add_network import RNNTLossAdd
+    rng = np.random.default_rng(262)
+    N, T, U, A, blank = 1, 520, 300, 3, 1
+    dev = torch.device("cuda:0")
+    f = torch.tensor(rng.standard_normal((N, T, A)) * 1.5, dtype=dtype, device=dev)
+    g = torch.tensor(rng.standard_normal((N, U, A)) * 1.5, dtype=dtype, device=dev)
+    f[0, ::3, 0] += 70.0
+    g[0, ::2, 2] += 90.0
+    labels = rng.integers(0, A, size=(N, U - 1))
+    labels[labels == blank] = (blank + 1) % A
+    tl, ll = np.array([T], np.int32), np.array([U - 1], np.int32)
+    z = f.double().cpu().numpy()[:, :, None, :] + g.double().cpu().numpy()[:, None, :, :]
+    ref_c, ref_gz = oracle.rnnt_logits(z, labels.astype(np.int32), tl, ll, blank)
+    rdf, rdg = ref_gz.sum(axis=2), ref_gz.sum(axis=1)
+    fa, ga = f.clone().requires_grad_(True), g.clone().requires_grad_(True)
+    loss = RNNTLossAdd(blank=blank, reduction="sum")(fa, ga, torch.tensor(labels.astype(np.int32), device=dev),
+                                                     torch.tensor(tl, device=dev), torch.tensor(ll, device=dev))
+    loss.sum().backward()
+    assert abs(loss.item() - ref_c.sum()) <= 1e-4 * abs(ref_c.sum())
+    quantum = 2.0 ** -10 if dtype == torch.float16 else 2.0 ** -7          # relative spacing of the storage type
+    for got, ref in ((fa.grad, rdf), (ga.grad, rdg)):
+        err = np.abs(got.double().cpu().numpy() - ref)
+        assert (err <= 6 * quantum * np.maximum(np.abs(ref), 1.0) + 3e-3 * np.maximum(np.abs(ref), 1.0)).all()
+
+
 @pytest.mark.parametrize("shape", [
     (2, 33, 21, 512),      # smallest vocabulary of the bf16 matrix-core kernels; second contraction step half masked
     (3, 17, 9, 520),       # a partial last column block (520 = 4 x 128 + 8), T and U below one step

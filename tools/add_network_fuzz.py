@@ -52,7 +52,7 @@ for case in range(cases):
     def excess(a, b, cells):       # tests/test_gpu_add_network.py: |err| <= 2e-4 max(1, cells / 32) + 5e-5 |ref|  (x 3: per-sample weights up to 2, and the bound is what the fp32 materialised path itself just meets)
         a = a.double()
         bound = 3.0 * (2e-4 * max(1.0, cells / 32) + 5e-5 * b.abs()) + quant * b.abs().clamp_min(1.0)
-        if far and quant: bound = bound + 3e-2 * b.abs().clamp_min(1.0)   # far cells are ADDED to 16-bit gradients one by one (compare-and-swap): each add rounds to the storage type
+        if far and quant: bound = bound + 4 * quant * b.abs().clamp_min(1.0)   # far cells reach a 16-bit gradient in up to ceil(U / 64) / ceil(T / 64) rounded additions
         if far: bound = bound + 2e-3 * b.abs().clamp_min(1.0)   # logits of magnitude 100+: their fp32 rounding alone (the materialised fp32 path shows the same)
         return float(((a - b).abs() / bound).max())
     edf, edg = excess(fa.grad, fm.grad, U), excess(ga.grad, gm.grad, T)

@@ -274,8 +274,16 @@ static rnntStatus_t run_gpu_joint(const typename Tag::store* f, const typename T
 #undef RNNT_JDF_BS
 #undef RNNT_JDG_SPLIT
         p.check();
-        hipLaunchKernelGGL((joint_far_kernel<Tag>), fixgrid, dim3(256), 0, p.stream, f, g, p.rowmax, p.rowtab, grad_scale,
-                           input_lengths, label_lengths, farflag, df, dg, maxT, maxU, A, N, cplanes, Upad);
+        if constexpr (sizeof(S) == 4) {
+            hipLaunchKernelGGL((joint_far_kernel<Tag>), fixgrid, dim3(256), 0, p.stream, f, g, p.rowmax, p.rowtab, grad_scale,
+                               input_lengths, label_lengths, farflag, df, dg, maxT, maxU, A, N, cplanes, Upad);
+        } else {
+            // 16-bit gradients: the far cells of a row segment are summed in fp32 before the stored element is touched (joint_far16_kernel)
+            const int longer = maxT > maxU ? maxT : maxU;
+            const dim3 fargrid((longer + 63) / 64, (maxT + kJointFixT - 1) / kJointFixT + (maxU + kJointFixT - 1) / kJointFixT, N);
+            hipLaunchKernelGGL((joint_far16_kernel<Tag>), fargrid, dim3(256), 0, p.stream, f, g, p.rowmax, p.rowtab, grad_scale,
+                               input_lengths, label_lengths, farflag, df, dg, maxT, maxU, A, N, cplanes, Upad);
+        }
         p.check();
     }
     mark(4);

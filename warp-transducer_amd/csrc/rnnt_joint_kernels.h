@@ -1288,4 +1288,72 @@ __global__ __launch_bounds__(256) void joint_far_kernel(
     }
 }
 
+// 16-bit GRADIENT storage: every joint_atomic_add above rounds to the storage type, and joint_far_kernel adds one CELL at a time --
+// a gradient element that collects hundreds of far cells drifted by ~1 % (fp16, T = 520: 1.7354 for 1.7591; tools/add_network_fuzz.py).
+// Here the far cells of a whole row segment are summed in fp32 registers first and the stored element is touched ONCE per block:
+// phase 0 (blockIdx.y < rows_f): a block owns 64 label rows (lanes) x kJointFixT time rows and adds  sum_u exp(f + g + c)  to df;
+// phase 1: the transposed tiling, 64 time rows (lanes) x kJointFixT label rows, adds  sum_t  to dg.  At most ceil(U / 64) resp.
+// ceil(T / 64) rounded additions per element instead of U resp. T.  grid = (ceil(max(maxT, maxU) / 64),
+// ceil(maxT / kJointFixT) + ceil(maxU / kJointFixT), N), block = 256; a sample without far cells costs one flag read per block.
+template <typename Tag>
+__global__ __launch_bounds__(256) void joint_far16_kernel(
+        const typename Tag::store* __restrict__ f, const typename Tag::store* __restrict__ g, const float* __restrict__ rowmax,
+        const Cell<float>* __restrict__ rowtab, const float* __restrict__ scale, const int* __restrict__ xlen,
+        const int* __restrict__ ylen, const int* __restrict__ farflag, typename Tag::store* __restrict__ df,
+        typename Tag::store* __restrict__ dg,
+        int maxT, int maxU, int A, int N, const float* __restrict__ planes, int Upad) {
+    const int b = blockIdx.z;
+    if (farflag[b] == 0) return;
+    const int lane = threadIdx.x & 63, wave = uniform(threadIdx.x >> 6);
+    const int rows_f = (maxT + kJointFixT - 1) / kJointFixT;
+    const bool for_dg = static_cast<int>(blockIdx.y) >= rows_f;                 // block-uniform
+    const int Tb = clamp_len(xlen[b], maxT), Ub = clamp_len(ylen[b] + 1, maxU);
+    const int Lb = for_dg ? Tb : Ub, Rb = for_dg ? Ub : Tb;                      // lanes run along L, the block's rows along R
+    const int lb0 = blockIdx.x * 64, rb0 = (static_cast<int>(blockIdx.y) - (for_dg ? rows_f : 0)) * kJointFixT;
+    if (rb0 >= Rb || lb0 >= Lb) return;
+    const int l = lb0 + lane;
+    const bool lin = l < Lb;
+    const float* mf = rowmax + static_cast<size_t>(b) * maxT;
+    const float* mg = rowmax + static_cast<size_t>(N) * maxT + static_cast<size_t>(b) * maxU;
+    const float sc = scale != nullptr ? scale[b] : 1.0f;
+    const int rend = rb0 + kJointFixT < Rb ? rb0 + kJointFixT : Rb;
+    using ST = typename Tag::store;
+    const ST* fb = f + static_cast<size_t>(b) * maxT * A;
+    const ST* gb = g + static_cast<size_t>(b) * maxU * A;
+    for (int r = rb0 + wave; r < rend; r += 4) {
+        const int t = for_dg ? l : r, u = for_dg ? r : l;
+        float c = log_zero<float>();
+        if (lin) {
+            if (planes != nullptr) {                       // no records: the far mark in W, c stored for marked cells only
+                const size_t at = (static_cast<size_t>(b) * maxT + t) * Upad + u;
+                if (joint_is_far_mark(planes[at])) c = reinterpret_cast<const float*>(rowtab)[at];
+            } else {
+                c = rowtab[(static_cast<size_t>(b) * maxT + t) * maxU + u].x;
+            }
+        }
+        const unsigned long long far = __ballot(lin && c > kJointFarC);
+        if (far == 0) continue;                            // (wave-uniform)
+        const ST* own = for_dg ? gb + static_cast<size_t>(r) * A : fb + static_cast<size_t>(r) * A;   // the output row's own activations
+        const ST* others = for_dg ? fb : gb;
+        const float* mo = for_dg ? mf : mg;
+        const float m_own = for_dg ? mg[r] : mf[r];
+        ST* out = (for_dg ? dg + (static_cast<size_t>(b) * maxU + r) * A : df + (static_cast<size_t>(b) * maxT + r) * A);
+        for (int k0 = 0; k0 < A; k0 += 64) {               // (wave-uniform trip count: lane_get below needs every lane there)
+            const int k = k0 + lane;
+            const bool kin = k < A;
+            const float xo = kin ? load1<Tag>(own + k) : 0.0f;
+            float acc = 0.0f;
+            unsigned long long mask = far;
+            while (mask) {
+                const int src = __ffsll(static_cast<long long>(mask)) - 1;
+                mask &= mask - 1;
+                const int ll = lb0 + src;
+                const float shift = lane_get(c, src) - (m_own + mo[ll]) * static_cast<float>(kLn2);
+                if (kin) acc += fast_exp(xo + load1<Tag>(others + static_cast<size_t>(ll) * A + k) + shift);
+            }
+            if (kin) joint_atomic_add<Tag>(out + k, acc * sc);
+        }
+    }
+}
+
 }  // namespace rnnt

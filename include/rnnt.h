@@ -92,7 +92,9 @@ typedef struct rnntOptions rnntOptions;
  * its in-lattice rows NaN, as the reference's arithmetic does (include/detail/reduce.h:85,103 -> gpu_rnnt_kernel.h:5-9 ->
  * rnnt_helper.h:16-24); its padded rows stay zero, the other samples of the batch are not affected, and the status is
  * RNNT_STATUS_SUCCESS (a NaN loss is a result, as in the reference).  Values in PADDED rows are never read.  Single -inf
- * logits are ordinary (probability zero). */
+ * logits are ordinary (probability zero) -- unless they leave a sample NO alignment of non-zero probability (a label it must
+ * emit, or the blank, masked wherever it could be emitted): that sample's cost is +inf and its in-lattice gradients are NaN,
+ * which is where the reference's arithmetic ends too (ll = -inf; exp(alpha + beta - ll) = exp(-inf + inf)). */
 rnntStatus_t compute_rnnt_loss(const float* const activations,
                                float* gradients,
                                const int* const flat_labels,

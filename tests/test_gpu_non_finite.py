@@ -208,3 +208,66 @@ def test_additive_joint(shape, bad):
                 and np.allclose(dg1[keep], dg0[keep], rtol=rt, atol=rt * 0.1)
             assert np.isfinite(df1[keep]).all() and np.isfinite(dg1[keep]).all()
             assert np.isnan(df1[1, :tl[1]]).any() and np.isnan(dg1[1, :ll[1] + 1]).any()
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# No alignment with non-zero probability: a REQUIRED label masked with -inf wherever it could be emitted.  The reference's
+# arithmetic ends on ll = -inf: cost +inf, every in-lattice gradient exp(-inf + inf) = NaN (rnnt_helper.h:16-24,
+# gpu_rnnt_kernel.h:161-174; the oracle restates exactly that).  The lattice kernels work with a finite "log zero" sentinel, so
+# the sweep ends on ~ -1e30 instead -- which used to come out as a finite cost of 6.9e29 with finite gradients.
+@pytest.mark.parametrize("case", [(3, 6, 5, 8, torch.float32), (2, 40, 70, 20, torch.float32), (3, 9, 4, 1024, torch.float32),
+                                  (2, 30, 300, 12, torch.float32), (3, 6, 5, 8, torch.float64), (3, 12, 7, 64, torch.bfloat16)],
+                         ids=["one-wavefront", "three-wavefront", "long-rows", "two-column-lanes", "fp64", "bf16"])
+def test_impossible_alignment_is_an_infinite_cost(oracle, case):
+    N, T, U, A, dtype = case
+    acts, labels, tl, ll = problem((N, T, U, A), T * U + A)
+    victim = 1
+    u = int(ll[victim]) // 2                                # a label the victim must emit (u < its label length)
+    assert u < int(ll[victim])
+    x_clean = torch.tensor(acts, device=DEV).to(dtype)
+    x_bad = x_clean.clone()
+    x_bad[victim, :, u, int(labels[victim, u])] = -float("inf")   # ... and cannot, at any time step
+    ref_c, ref_g = oracle.rnnt_logits(x_bad.double().cpu().numpy(), labels, tl, ll)
+    Tb, Ub = int(tl[victim]), int(ll[victim]) + 1
+    assert np.isposinf(ref_c[victim]) and np.isnan(ref_g[victim, :Tb, :Ub]).all()
+    c0, g0 = gpu_call(x_clean, labels, tl, ll)
+    c1, g1 = gpu_call(x_bad, labels, tl, ll)
+    assert np.isposinf(c1[victim]), c1
+    assert np.isnan(g1[victim, :Tb, :Ub]).all()
+    assert not g1[victim, Tb:].any() and not g1[victim, :, Ub:].any()          # padding: zeros
+    others = np.arange(N) != victim
+    assert np.array_equal(c1[others], c0[others]) and np.array_equal(g1[others], g0[others])
+    assert np.isfinite(c1[others]).all()
+    c2, _ = gpu_call(x_bad, labels, tl, ll, want_grad=False)                   # score only
+    assert np.isposinf(c2[victim]) and np.array_equal(c2[others], c0[others])
+
+
+def test_impossible_alignment_additive_joint_and_packed(oracle):
+    from warprnnt_pytorch.add_network import RNNTLossAdd
+    from warprnnt_pytorch.packed import RNNTLossPacked, pack_joint
+    rng = np.random.default_rng(5)
+    N, T, U, A, blank = 2, 12, 70, 20, 0
+    dev = torch.device("cuda:0")
+    f = rng.standard_normal((N, T, A)).astype(np.float32)
+    g = rng.standard_normal((N, U, A)).astype(np.float32)
+    labels = rng.integers(1, A, size=(N, U - 1)).astype(np.int32)
+    tl, ll = np.array([T, T - 3], np.int32), np.array([U - 1, U - 5], np.int32)
+    g[0, 30, labels[0, 30]] = -np.inf                       # sample 0 can never emit its label 30
+    lab, ttl, tll = (torch.tensor(a, device=dev) for a in (labels, tl, ll))
+    tf, tg = torch.tensor(f, device=dev, requires_grad=True), torch.tensor(g, device=dev, requires_grad=True)
+    loss = RNNTLossAdd(blank=blank, reduction="none")(tf, tg, lab, ttl, tll)
+    loss.sum().backward()
+    c = loss.detach().cpu().numpy()
+    assert np.isposinf(c[0]) and np.isfinite(c[1])
+    assert torch.isnan(tf.grad[0]).all() and torch.isfinite(tf.grad[1]).all() and torch.isfinite(tg.grad[1]).all()
+    z = f[:, :, None, :].astype(np.float64) + g[:, None, :, :].astype(np.float64)
+    ref_c, _ = oracle.rnnt_logits(z, labels, tl, ll, blank)
+    assert np.isposinf(ref_c[0]) and abs(c[1] - ref_c[1]) <= 1e-4 * abs(ref_c[1])
+    joint = torch.tensor(z.astype(np.float32), device=dev)
+    xp = pack_joint(joint, ttl, tll).contiguous().requires_grad_(True)
+    lp = RNNTLossPacked(blank=blank, reduction="none")(xp, lab, ttl, tll)
+    lp.sum().backward()
+    cp = lp.detach().cpu().numpy()
+    assert np.isposinf(cp[0]) and abs(cp[1] - ref_c[1]) <= 1e-4 * abs(ref_c[1])
+    n0 = int(tl[0]) * (int(ll[0]) + 1)
+    assert torch.isnan(xp.grad[:n0]).all() and torch.isfinite(xp.grad[n0:]).all()

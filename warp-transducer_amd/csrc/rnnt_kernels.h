@@ -1059,8 +1059,13 @@ __device__ __forceinline__ void lattice_body(
                 poison[b] = 0;
                 if (hint_is_poison(hint, logz, sample0, Up, Tb, Ub)) ll2 = __builtin_nan("");
             }
-            ll_fwd[b] = ll2;                                  // base 2, for the coefficient kernel
-            costs_dev[b] = bad_len ? cost_invalid<L>() : static_cast<L>(-ll2 * kLn2);
+            // NO alignment has non-zero probability (a required label or blank masked with -inf everywhere it could be emitted):
+            // the sweep ends on the finite "log zero" sentinel.  The reference's arithmetic ends on -inf there -- cost +inf, and
+            // exp(alpha + beta - ll) = exp(-inf + inf) = NaN for every in-lattice gradient (rnnt_helper.h:16-24,
+            // gpu_rnnt_kernel.h:161-174); same here: +inf cost, and the NaN in ll_fwd reaches the gradients through the coefficients
+            const bool impossible = ll2 < 0.5 * static_cast<double>(log_zero<L>());
+            ll_fwd[b] = impossible ? __builtin_nan("") : ll2; // base 2, for the coefficient kernel
+            costs_dev[b] = bad_len ? cost_invalid<L>() : impossible ? -neg_inf<L>() : static_cast<L>(-ll2 * kLn2);
         }
     } else {
         // ------------------------------- beta -------------------------------
@@ -1435,8 +1440,9 @@ __device__ __forceinline__ void lattice_lin_body(
                     poison[b] = 0;
                     if (hint_is_poison(hint, logz, sample0, Up, Tb, Ub)) ll2 = __builtin_nan("");
                 }
-                ll_fwd[b] = ll2;
-                costs_dev[b] = bad_len ? cost_invalid<float>() : static_cast<float>(-ll2 * kLn2);
+                const bool impossible = ll2 < 0.5 * static_cast<double>(log_zero<float>());   // (see lattice_body; a zero probability takes the fallback anyway)
+                ll_fwd[b] = impossible ? __builtin_nan("") : ll2;
+                costs_dev[b] = bad_len ? cost_invalid<float>() : impossible ? -neg_inf<float>() : static_cast<float>(-ll2 * kLn2);
             } else {
                 ll_bwd[b] = (nsteps > 0 ? log2(fin) + Eo : static_cast<double>(x_last)) * kLn2;
             }

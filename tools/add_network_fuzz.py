@@ -30,6 +30,11 @@ for case in range(cases):
     if far:                                            # rows peaking far apart: direct branches, far cells
         f[int(rng.integers(0, N)), ::3, int(rng.integers(0, A))] += 70.0
         g[int(rng.integers(0, N)), ::2, int(rng.integers(0, A))] += 90.0
+    if rng.random() < 0.12 and A > 2:                  # masked symbols: -inf in f (all u of a time step) or g (all t of a label row)
+        f[torch.rand(f.shape, device=dev) < 0.04] = -float("inf")
+        g[torch.rand(g.shape, device=dev) < 0.04] = -float("inf")
+        f[..., blank] = torch.nan_to_num(f[..., blank], neginf=0.0)     # the blank stays possible
+        g[..., blank] = torch.nan_to_num(g[..., blank], neginf=0.0)
     labels = rng.integers(0, A, size=(N, max(U - 1, 0)))
     if A > 1:
         labels[labels == blank] = (blank + 1) % A
@@ -47,7 +52,15 @@ for case in range(cases):
     joint = (fm.unsqueeze(2) + gm.unsqueeze(1)).contiguous()
     lm = RNNTLoss(blank=blank, reduction="none")(joint, lab, ttl, tll)
     (lm * w.double()).sum().backward()
-    ec = float(((la.detach().double() - lm.detach()).abs() / lm.detach().abs().clamp_min(1.0)).max())
+    fin = torch.isfinite(lm.detach())
+    same = bool((torch.isfinite(la.detach()) == fin).all())
+    ec = float(((la.detach().double() - lm.detach()).abs() / lm.detach().abs().clamp_min(1.0))[fin].max()) if fin.any() else 0.0
+    if not same:
+        print("MISMATCH case %d: finite / infinite costs differ: %s vs %s" % (case, la.detach().cpu().numpy(), lm.detach().cpu().numpy())); sys.exit(1)
+    if not fin.all():                                  # (samples without an alignment: +inf on both sides, NaN gradients; compare the others)
+        keep = fin.view(-1, 1, 1)
+        for t_ in (fa.grad, ga.grad, fm.grad, gm.grad):
+            t_.masked_fill_(~keep.expand_as(t_), 0.0)
     quant = 0.0 if dtype == torch.float32 else (8e-3 if dtype == torch.bfloat16 else 1e-3)    # storage quantum of 16-bit gradients (relative)
     def excess(a, b, cells):       # tests/test_gpu_add_network.py: |err| <= 2e-4 max(1, cells / 32) + 5e-5 |ref|  (x 3: per-sample weights up to 2, and the bound is what the fp32 materialised path itself just meets)
         a = a.double()
@@ -56,7 +69,7 @@ for case in range(cases):
         if far: bound = bound + 2e-3 * b.abs().clamp_min(1.0)   # logits of magnitude 100+: their fp32 rounding alone (the materialised fp32 path shows the same)
         return float(((a - b).abs() / bound).max())
     edf, edg = excess(fa.grad, fm.grad, U), excess(ga.grad, gm.grad, T)
-    bad = not (ec <= 2e-4 and edf <= 1.0 and edg <= 1.0) or not torch.isfinite(la).all()
+    bad = not (ec <= 2e-4 and edf <= 1.0 and edg <= 1.0)
     worst["cost"] = max(worst["cost"], ec)
     if dtype == torch.float32:
         worst["df"] = max(worst["df"], edf); worst["dg"] = max(worst["dg"], edg)
@@ -66,7 +79,7 @@ for case in range(cases):
         l3 = RNNTLoss(blank=blank, reduction="none")((f3.unsqueeze(2) + g3.unsqueeze(1)).contiguous(), lab, ttl, tll)
         (l3 * w).sum().backward()
         mdf, mdg = excess(f3.grad, fm.grad, U), excess(g3.grad, gm.grad, T)
-        if ec <= 2e-4 and torch.isfinite(la).all() and edf <= 1.5 * mdf + 0.5 and edg <= 1.5 * mdg + 0.5:
+        if ec <= 2e-4 and edf <= 1.5 * mdf + 0.5 and edg <= 1.5 * mdg + 0.5:
             floor += 1                                 # long lattices / logits of magnitude 100+: both fp32 paths sit at the same distance
             continue
         print("far=%s; fp32 materialised path: df %.2f dg %.2f of the bound" % (far, mdf, mdg))

@@ -190,3 +190,25 @@ def test_non_finite_log_probs_propagate_as_in_the_reference(oracle, bad):
         fc, _ = oracle.ref_rnnt_logprobs(x, labels, tl, ll)
         assert np.array_equal(np.isnan(fc), np.isnan(c))
         assert np.allclose(fc[~np.isnan(fc)], c[~np.isnan(c)], rtol=1e-10)
+
+
+def test_impossible_alignment_is_an_infinite_cost_on_the_cpu_too(oracle):
+    """A label the sample must emit, closed (-inf) at every time step: no alignment is left.  The reference's arithmetic ends on
+    ll = -inf -> cost +inf (the GPU location matches it since round 4: tests/test_gpu_non_finite.py); RNNT_CPU, the oracle and
+    the reference's own library agree, the other samples are untouched."""
+    rng = np.random.default_rng(8)
+    N, T, U, A = 3, 6, 4, 7
+    lp = oracle.log_softmax(rng.standard_normal((N, T, U, A)))
+    labels = rng.integers(1, A, size=(N, U - 1)).astype(np.int32)
+    tl, ll = [T, T - 1, T], [U - 1, U - 2, U - 1]
+    c0, g0 = cpu_loss(lp, labels, tl, ll)
+    x = lp.copy()
+    x[1, :, 0, labels[1, 0]] = -np.inf                    # sample 1 can never emit its first label
+    c, g = cpu_loss(x, labels, tl, ll)
+    assert np.isposinf(c[1])
+    assert np.array_equal(c[[0, 2]], c0[[0, 2]]) and np.array_equal(g[[0, 2]], g0[[0, 2]])
+    rc, _ = oracle.rnnt_logprobs(x, labels, tl, ll)
+    assert np.isposinf(rc[1]) and np.allclose(rc[[0, 2]], c[[0, 2]], rtol=1e-6)
+    if oracle.have_ref():
+        fc, _ = oracle.ref_rnnt_logprobs(x, labels, tl, ll)
+        assert np.isposinf(fc[1])

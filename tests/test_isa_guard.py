@@ -40,3 +40,15 @@ def test_guard_trips_on_a_planted_instruction(device_asm):
     bad = list(lines)
     del bad[req]
     assert guard.check("\n".join(bad))
+
+
+def test_no_kernel_uses_scratch_or_spills_vector_registers(device_asm):
+    """Every kernel of BOTH translation units: no private segment, no spilled VGPR (tools/check_kernel_resources.py).  Scratch
+    does not change results -- no parity test would notice -- and it cost the split-contraction DF kernel 40 % (EXPERIMENTS 11)."""
+    guard, asm = device_asm
+    import check_kernel_resources as res
+    assert len(res.kernels(asm)) > 50 and res.check(asm) == []
+    joint = guard.device_asm(None, guard.SRCS[1])
+    assert len(res.kernels(joint)) > 100 and res.check(joint) == []
+    assert guard.check(joint) == []                      # the second copy of lattice_lin_kernel (the joint translation unit's)
+    assert res.check(joint.replace(".private_segment_fixed_size: 0", ".private_segment_fixed_size: 64", 1)) != []   # the check can fail

@@ -17,7 +17,12 @@ def device_asm():
     if shutil.which("hipcc") is None:
         pytest.skip("needs hipcc")
     import check_lattice_lin_isa as guard
-    return guard, guard.device_asm()
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(2) as pool:                       # both translation units at once (hipcc, ~35 s and ~75 s)
+        jobs = [pool.submit(guard.device_asm, None, src) for src in guard.SRCS]
+        asms = [j.result() for j in jobs]
+    guard.joint_asm = asms[1]
+    return guard, asms[0]
 
 
 def test_operand_role_holds_only_its_own_memory_instructions(device_asm):
@@ -48,7 +53,7 @@ def test_no_kernel_uses_scratch_or_spills_vector_registers(device_asm):
     guard, asm = device_asm
     import check_kernel_resources as res
     assert len(res.kernels(asm)) > 50 and res.check(asm) == []
-    joint = guard.device_asm(None, guard.SRCS[1])
+    joint = guard.joint_asm
     assert len(res.kernels(joint)) > 100 and res.check(joint) == []
     assert guard.check(joint) == []                      # the second copy of lattice_lin_kernel (the joint translation unit's)
     assert res.check(joint.replace(".private_segment_fixed_size: 0", ".private_segment_fixed_size: 64", 1)) != []   # the check can fail

@@ -94,7 +94,14 @@ typedef struct rnntOptions rnntOptions;
  * RNNT_STATUS_SUCCESS (a NaN loss is a result, as in the reference).  Values in PADDED rows are never read.  Single -inf
  * logits are ordinary (probability zero) -- unless they leave a sample NO alignment of non-zero probability (a label it must
  * emit, or the blank, masked wherever it could be emitted): that sample's cost is +inf and its in-lattice gradients are NaN,
- * which is where the reference's arithmetic ends too (ll = -inf; exp(alpha + beta - ll) = exp(-inf + inf)). */
+ * which is where the reference's arithmetic ends too (ll = -inf; exp(alpha + beta - ll) = exp(-inf + inf)).
+ * A LABEL EQUAL TO THE BLANK SYMBOL is legal and each location keeps its reference's answer -- they differ:
+ *   RNNT_GPU (every entry point, packed and additive-joint included): both the blank and the label correction are
+ *     subtracted from the blank column of such a cell (reference include/detail/gpu_rnnt_kernel.h:161-174: independent
+ *     `if`s) -- the true derivative; pinned against fp64 autograd by tests/test_gpu_label_equals_blank.py;
+ *   RNNT_CPU: the label term is ASSIGNED after the blank term and overwrites it (reference include/detail/cpu_rnnt.h:253-267);
+ *     kept as is -- it is what a caller of the reference's CPU location gets (tests/test_cpu_location.py).
+ * The costs agree in both. */
 rnntStatus_t compute_rnnt_loss(const float* const activations,
                                float* gradients,
                                const int* const flat_labels,

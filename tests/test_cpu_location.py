@@ -212,3 +212,26 @@ def test_impossible_alignment_is_an_infinite_cost_on_the_cpu_too(oracle):
     if oracle.have_ref():
         fc, _ = oracle.ref_rnnt_logprobs(x, labels, tl, ll)
         assert np.isposinf(fc[1])
+
+
+def test_label_equal_to_blank_keeps_the_cpu_references_assignment(oracle):
+    """A label that equals the blank: the reference's CPU location ASSIGNS the label term after the blank term
+    (cpu_rnnt.h:253-267: the second write overwrites the first), its GPU location subtracts both
+    (gpu_rnnt_kernel.h:161-174).  RNNT_CPU here keeps the CPU contract, assignment and all (include/rnnt.h says so);
+    the GPU location is pinned by tests/test_gpu_label_equals_blank.py against fp64 autograd."""
+    import torch
+    from warprnnt_pytorch import warp_rnnt
+    shape = (2, 9, 5, 7)
+    rng = np.random.default_rng(2)
+    blank = 3
+    labels = rng.integers(0, 7, size=(2, 4)).astype(np.int32)
+    labels[:, ::2] = blank
+    tl, ll = np.array([9, 6], np.int32), np.array([4, 3], np.int32)
+    lp = torch.log_softmax(torch.tensor(rng.standard_normal(shape), dtype=torch.float32), -1)
+    costs, grads = torch.zeros(2), torch.zeros(shape)
+    assert warp_rnnt.cpu_rnnt(lp, torch.tensor(labels), torch.tensor(tl), torch.tensor(ll), costs, grads, blank, 0) == 0
+    ref_c, ref_g = oracle.rnnt_logprobs(lp.numpy(), labels, tl, ll, blank, True)
+    assert np.allclose(costs.numpy(), ref_c, rtol=1e-5) and np.abs(grads.numpy() - ref_g).max() < 1e-5
+    if oracle.have_ref():
+        rc, rg = oracle.ref_rnnt_logprobs(lp.numpy(), labels, tl, ll, blank, True, 1)
+        assert np.allclose(costs.numpy(), rc, rtol=1e-5) and np.abs(grads.numpy() - rg).max() < 1e-5

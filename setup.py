@@ -15,6 +15,7 @@ import subprocess
 
 from setuptools import setup
 from setuptools.command.build_py import build_py
+from setuptools.command.develop import develop
 from setuptools.dist import Distribution
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -52,6 +53,18 @@ class build_native(build_py):
         be.build(force=True, lib_dir=lib_out, out_dir=pkg_out)
 
 
+class develop_native(develop):
+    """`pip install -e .` / `setup.py develop`: the package runs from the source tree, so the native pair is built IN the
+    tree (what __graft_entry__.build() does) -- an editable install without it would silently fall back to the ctypes
+    loader, or find no library at all."""
+
+    def run(self):
+        if not os.environ.get("WARP_RNNT_PATH"):
+            subprocess.run(["make", "-j3", "-C", os.path.join(ROOT, "warp-transducer_amd"), "lib/libwarprnnt.so"], check=True)
+        subprocess.run([os.sys.executable, os.path.join(PKG_SRC, "build_ext.py")], check=True)
+        super().run()
+
+
 setup(
     name="warprnnt_pytorch",
     version="0.4.0",
@@ -59,7 +72,7 @@ setup(
     packages=["warprnnt_pytorch"],
     package_dir={"warprnnt_pytorch": os.path.relpath(PKG_SRC, ROOT)},
     python_requires=">=3.8",
-    cmdclass={"build_py": build_native},
+    cmdclass={"build_py": build_native, "develop": develop_native},
     distclass=BinaryDistribution,
     zip_safe=False,
 )

@@ -866,3 +866,39 @@ def test_padding_flag_follows_the_batch(oracle, dtype, A):
     warp_rnnt.gpu_rnnt_bwd(x, grads2, scale, ws2, 0)
     torch.cuda.synchronize()
     assert torch.equal(dcosts, dcosts2) and torch.equal(grads, grads2)
+
+
+@pytest.mark.parametrize("loader", ["ext", "ctypes"])
+def test_binding_rejects_host_side_arguments_and_short_workspaces(monkeypatch, loader):
+    """labels / lengths on the host next to device activations used to be a GPU fault, and a caller-owned
+    workspace was passed on unchecked (its layout is private and grew by the per-sample `poison` array).  Both are
+    exceptions now, in the compiled module and in the ctypes loader, in the one-call and the two-phase entries and in the
+    additive joint."""
+    from warprnnt_pytorch import RNNTLoss, _lib, warp_rnnt
+    from warprnnt_pytorch.add_network import RNNTLossAdd
+    if loader == "ctypes":
+        monkeypatch.setattr(warp_rnnt, "_EXT", None)
+    dev = torch.device("cuda:0")
+    N, T, U, A = 2, 5, 3, 8
+    x = torch.randn(N, T, U, A, device=dev)
+    lab = torch.ones(N, U - 1, dtype=torch.int32, device=dev)
+    tl = torch.full((N,), T, dtype=torch.int32, device=dev)
+    ll = torch.full((N,), U - 1, dtype=torch.int32, device=dev)
+    for bad in ((lab.cpu(), tl, ll), (lab, tl.cpu(), ll), (lab, tl, ll.cpu())):
+        with pytest.raises(ValueError, match="must be on the device"):
+            RNNTLoss()(x, *bad)
+        with pytest.raises(ValueError, match="must be on the device"):
+            warp_rnnt.gpu_rnnt(x, *[bad[0], bad[1], bad[2]], torch.zeros(N), torch.empty_like(x), 0, 0)
+        with pytest.raises(ValueError, match="must be on the device"):
+            RNNTLossAdd()(torch.randn(N, T, A, device=dev), torch.randn(N, U, A, device=dev), *bad)
+    need = _lib.workspace_bytes(T, U, N, True, 4)
+    costs, grads = torch.zeros(N), torch.empty_like(x)
+    with pytest.raises(ValueError, match="workspace"):
+        warp_rnnt.gpu_rnnt(x, lab, tl, ll, costs, grads, 0, 0, workspace=torch.empty(need - 1, dtype=torch.uint8, device=dev))
+    with pytest.raises(ValueError, match="workspace"):
+        warp_rnnt.gpu_rnnt(x, lab, tl, ll, costs, grads, 0, 0, workspace=torch.empty(need, dtype=torch.uint8))
+    ws = warp_rnnt.gpu_rnnt_fwd(x, lab, tl, ll, torch.zeros(N, device=dev), 0, True)
+    with pytest.raises(ValueError, match="workspace"):
+        warp_rnnt.gpu_rnnt_bwd(x, grads, None, ws[:need // 2], 0)
+    assert warp_rnnt.gpu_rnnt(x, lab, tl, ll, costs, grads, 0, 0, workspace=torch.empty(need, dtype=torch.uint8, device=dev)) == 0
+    torch.cuda.synchronize()

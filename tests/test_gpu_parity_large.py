@@ -313,7 +313,10 @@ def test_wide_lattice_sweep(oracle):
 
 
 @pytest.mark.parametrize("case", [((5, 790, 12, 33), torch.float32), ((4, 700, 90, 20), torch.float32), ((3, 400, 400, 9), torch.float32),
-                                  ((6, 800, 20, 1024), torch.bfloat16), ((2, 780, 5, 7), torch.float64)],
+                                  ((6, 800, 20, 1024), torch.bfloat16), ((2, 780, 5, 7), torch.float64),
+                                  # 2N > compute units: the one-stream schedule takes the log-domain lattice, and so must the halves
+                                  # (each of which alone would fit the linear-domain chain's one-block-per-CU rule); odd sample size
+                                  ((300, 790, 12, 6), torch.float32), ((5, 771, 3, 3), torch.float32)],
                          ids=lambda c: "x".join(map(str, c[0])) + "-" + str(c[1]).split(".")[-1])
 def test_two_half_schedule_on_a_second_stream(oracle, case):
     """rnnt_set_aux_stream: on long lattices the batch is split in two and the lattice kernel of one half runs on the caller's second
@@ -381,3 +384,64 @@ def test_two_half_schedule_on_a_second_stream(oracle, case):
     rc, rg = oracle.rnnt_logits(acts[pick].double().cpu().numpy(), labels[pick].cpu().numpy(), tl[pick], ll[pick])
     assert np.abs(got["full"][0][pick] - rc).max() <= 1e-4 * np.abs(rc).max()
     assert np.abs(got["full"][1][pick] - rg).max() <= (1e-3 if dtype != torch.bfloat16 else 4e-3)
+
+
+def test_aux_stream_can_be_replaced_and_released():
+    """rnnt_set_aux_stream again with another stream, and with NULL: the fork / join events are dropped and made again for
+    the next call (they used to be created once per thread, on whichever device was current, and never
+    destroyed); results stay the one-stream schedule's bits throughout."""
+    from warprnnt_pytorch import warp_rnnt
+    dev = torch.device("cuda:0")
+    N, T, U, A = 4, 800, 9, 16
+    rng = np.random.default_rng(5)
+    acts = torch.tensor(rng.standard_normal((N, T, U, A)).astype(np.float32), device=dev)
+    labels = torch.tensor(rng.integers(1, A, size=(N, U - 1)).astype(np.int32), device=dev)
+    tl = torch.full((N,), T, dtype=torch.int32, device=dev); ll = torch.full((N,), U - 1, dtype=torch.int32, device=dev)
+
+    def run():
+        costs = torch.zeros(N, device=dev); grads = torch.empty_like(acts)
+        warp_rnnt.gpu_rnnt_async(acts, labels, tl, ll, costs, grads, 0)
+        torch.cuda.synchronize()
+        return costs.cpu().numpy(), grads.cpu().numpy()
+
+    warp_rnnt.set_aux_stream(None)
+    ref = run()
+    try:
+        for _ in range(3):
+            side = torch.cuda.Stream(dev)
+            warp_rnnt.set_aux_stream(side)
+            for _ in range(2):
+                got = run()
+                assert np.array_equal(got[0], ref[0]) and np.array_equal(got[1], ref[1])
+            warp_rnnt.set_aux_stream(None)
+            got = run()
+            assert np.array_equal(got[0], ref[0]) and np.array_equal(got[1], ref[1])
+    finally:
+        warp_rnnt.set_aux_stream(None)
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs")
+def test_aux_stream_follows_the_thread_to_another_device():
+    """A thread that hands over a stream of ANOTHER GPU after having used the schedule on the first: the events are made
+    again on the device of the call."""
+    from warprnnt_pytorch import warp_rnnt
+    N, T, U, A = 4, 800, 9, 16
+    rng = np.random.default_rng(6)
+    x = rng.standard_normal((N, T, U, A)).astype(np.float32)
+    lab = rng.integers(1, A, size=(N, U - 1)).astype(np.int32)
+    outs = []
+    try:
+        for d in (0, 1, 0):
+            dev = torch.device("cuda", d)
+            with torch.cuda.device(dev):
+                acts = torch.tensor(x, device=dev); labels = torch.tensor(lab, device=dev)
+                tl = torch.full((N,), T, dtype=torch.int32, device=dev); ll = torch.full((N,), U - 1, dtype=torch.int32, device=dev)
+                warp_rnnt.set_aux_stream(torch.cuda.Stream(dev))
+                costs = torch.zeros(N, device=dev); grads = torch.empty_like(acts)
+                warp_rnnt.gpu_rnnt_async(acts, labels, tl, ll, costs, grads, 0)
+                torch.cuda.synchronize(dev)
+                outs.append((costs.cpu().numpy(), grads.cpu().numpy()))
+    finally:
+        warp_rnnt.set_aux_stream(None)
+    for o in outs[1:]:
+        assert np.array_equal(o[0], outs[0][0]) and np.array_equal(o[1], outs[0][1])

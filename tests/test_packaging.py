@@ -54,6 +54,26 @@ def test_pip_install_into_a_clean_venv(tmp_path):
     assert run.returncode == 0 and "installed-ok 1" in run.stdout, run.stdout[-2000:] + run.stderr[-4000:]
 
 
+def test_sdist_carries_the_native_sources(tmp_path):
+    """An sdist must be buildable: the HIP / C++ sources, the public header, the Makefile and the extension module's source
+    travel with it (MANIFEST.in)."""
+    import tarfile
+    work = tmp_path / "src"
+    shutil.copytree(ROOT, work, ignore=shutil.ignore_patterns(".git", "gpurun_out", "profiles", "build", "*.o", "*.so", "__pycache__", "_ref",
+                                                             ".pytest_cache", "*.egg-info", "dev", "oracle", "tests", "tools"))
+    out = subprocess.run([sys.executable, "setup.py", "-q", "sdist", "-d", str(tmp_path / "dist")], cwd=str(work), capture_output=True,
+                         text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    (tarball,) = list((tmp_path / "dist").glob("*.tar.gz"))
+    names = {n.split("/", 1)[1] for n in tarfile.open(tarball).getnames() if "/" in n}
+    for need in ("include/rnnt.h", "warp-transducer_amd/Makefile", "warp-transducer_amd/exports.map", "warp-transducer_amd/csrc/rnnt_gpu.hip",
+                 "warp-transducer_amd/csrc/rnnt_joint.hip", "warp-transducer_amd/csrc/rnnt_kernels.h", "warp-transducer_amd/csrc/rnnt_cpu.cpp",
+                 "warp-transducer_amd/warprnnt_pytorch/csrc/binding.cpp", "warp-transducer_amd/warprnnt_pytorch/build_ext.py",
+                 "warp-transducer_amd/warprnnt_pytorch/__init__.py", "setup.py", "pyproject.toml"):
+        assert need in names, (need, sorted(names)[:40])
+    assert not any(n.endswith((".so", ".o")) for n in names)
+
+
 def test_cmake_build_matches_the_makefile_build(tmp_path):
     """cmake -B b && cmake --build b: libwarprnnt.so with exactly the export list of include/rnnt.h (= the Makefile build's),
     the two C-ABI consumers, and an install tree another CMake project finds with find_package(warprnnt)."""

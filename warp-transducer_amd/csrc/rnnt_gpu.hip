@@ -27,6 +27,18 @@ Profile g_prof;
 std::mutex g_prof_mu;
 Ranges g_ranges;
 
+// Short rows under a wide lattice take the 2-D cell-tile statistics kernel -- when the tensor allows its covering packets
+// (first and last byte on 16-byte boundaries).  The one rule of the dispatch that looks at the batch size: a half of the
+// two-half schedule is told the whole batch's answer (Plan::stats_tile2d) instead of asking for itself.
+template <typename Tag>
+static bool stats_is_tile2d(const Plan<typename Tag::comp>& p, const typename Tag::store* acts) {
+    const size_t row_bytes = static_cast<size_t>(p.A) * sizeof(typename Tag::store);
+    if (!tune().tile2d || p.offsets != nullptr || row_bytes % 8 != 0 || row_bytes > 208 || p.maxU < 64) return false;
+    if (p.stats_tile2d >= 0) return p.stats_tile2d == 1;
+    return (reinterpret_cast<uintptr_t>(acts) & 15u) == 0 &&
+           (static_cast<unsigned long long>(p.N) * p.cells_per_sample * row_bytes) % 16 == 0;
+}
+
 // Stage 1 (materialised path): log-softmax statistics of every (b,t,u) row.
 template <typename Tag>
 static void launch_row_stats(Plan<typename Tag::comp>& p, const typename Tag::store* acts, int vec_ok) {
@@ -36,8 +48,7 @@ static void launch_row_stats(Plan<typename Tag::comp>& p, const typename Tag::st
     // short rows under a wide lattice (c4): 2-D cell tiles, results stored along the anti-diagonals
     // (the kernel loads the aligned 16-byte packets that COVER a piece of rows: with the tensor's first and last byte on
     // 16-byte boundaries no packet reaches outside it, whatever phase the pieces inside have)
-    if (tn.tile2d && p.offsets == nullptr && row_bytes % 8 == 0 && (reinterpret_cast<uintptr_t>(acts) & 15u) == 0 &&
-        (static_cast<unsigned long long>(p.N) * p.cells_per_sample * row_bytes) % 16 == 0 && row_bytes <= 208 && p.maxU >= 64) {
+    if (stats_is_tile2d<Tag>(p, acts)) {
         // tile shape: 16 x 16 (128-byte runs along the anti-diagonals, pieces of 16 rows; the default: 1.053 against 1.089 ms on c4,
         // alternating inside one process, tools/c4_align_probe.py) | 8 x 32 (64-byte runs, pieces of 32 rows)
         const bool sq = tn.tile2d == 2;
@@ -288,17 +299,34 @@ constexpr int kOverlapMinDiagonals = 768;
 struct AuxStream {
     hipStream_t stream = nullptr;
     hipEvent_t ev[4];
-    bool ready = false;
+    int made = 0;                               // events of ev[] that exist ...
+    int device = -1;                            // ... and the device they belong to (HIP events are bound to their device)
 };
 static thread_local AuxStream t_aux;            // per calling thread, like options.stream is per call
 
+static void aux_drop_events() {
+    for (int i = 0; i < t_aux.made; ++i) (void)hipEventDestroy(t_aux.ev[i]);
+    (void)hipGetLastError();
+    t_aux.made = 0; t_aux.device = -1;
+}
+
+// The fork / join events of the calling thread, on the CURRENT device: a thread that moves to another GPU (the stream it
+// hands over "must belong to the device of the call") gets events of that GPU -- the old ones are destroyed, not leaked.
+// false: no auxiliary stream, or the events cannot be made -> the caller runs the one-stream schedule (nothing has
+// been launched yet, so a failure here can never leave half a fork behind).
 static bool aux_prepare() {
     if (t_aux.stream == nullptr) return false;
-    if (!t_aux.ready) {
-        for (auto& e : t_aux.ev)
-            if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); return false; }
-        t_aux.ready = true;
-    }
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return false; }
+    if (t_aux.made == 4 && t_aux.device == dev) return true;
+    aux_drop_events();
+    for (; t_aux.made < 4; ++t_aux.made)
+        if (hipEventCreateWithFlags(&t_aux.ev[t_aux.made], hipEventDisableTiming) != hipSuccess) {
+            (void)hipGetLastError();
+            aux_drop_events();
+            return false;
+        }
+    t_aux.device = dev;
     return true;
 }
 
@@ -388,9 +416,23 @@ static rnntStatus_t run_gpu(const typename Tag::store* acts, typename Tag::store
 
     // (one-call training entries only: measured slower for the forward half of a two-phase pair -- its second lattice has only
     //  the first half's coefficient kernel to hide behind -- and not measured for score-only calls)
-    const bool overlap = do_fwd && do_bwd && N >= 2 && p.offsets == nullptr && p.maxT + p.maxU - 1 >= kOverlapMinDiagonals &&
-                         t_aux.stream != p.stream && aux_prepare();
+    bool overlap = do_fwd && do_bwd && N >= 2 && p.offsets == nullptr && p.maxT + p.maxU - 1 >= kOverlapMinDiagonals &&
+                   t_aux.stream != p.stream;
+    // Where to cut: the second half's tensors must start on a 16-byte boundary like the whole batch's do, or its kernels would
+    // take other forms (row-form gradient kernel, no 2-D statistics tiles) and the "same bits" promise would not hold -- the
+    // sample count nearest N/2 whose slab is a whole number of 16-byte packets (none within 8 of N/2: no split)
+    int n0 = N / 2;
+    if (overlap) {
+        const unsigned long long per_sample = static_cast<unsigned long long>(p.cells_per_sample) * A * sizeof(S);
+        n0 = 0;
+        for (int d = 0; d <= 8 && n0 == 0; ++d)
+            for (int c : {N / 2 - d, N / 2 + d})
+                if (c >= 1 && c < N && (per_sample * static_cast<unsigned long long>(c)) % 16 == 0) { n0 = c; break; }
+        overlap = n0 != 0;
+    }
+    overlap = overlap && aux_prepare();          // (last: it may create events)
     if (!overlap) {
+        if (prof) g_prof.split = false;           // (a two-half call whose events were never collected must not label this one)
         mark(0);
         if (do_fwd) launch_row_stats<Tag>(p, acts, vec_ok);
         mark(1);
@@ -402,33 +444,39 @@ static rnntStatus_t run_gpu(const typename Tag::store* acts, typename Tag::store
         mark(4);
     } else {
         // the two-half schedule (see AuxStream above)
-        const int n0 = N / 2;
         Plan<C> half[2] = {sub_plan(p, 0, n0), sub_plan(p, n0, N - n0)};
+        // kernel forms that depend on the batch size are chosen ONCE, for the whole batch: the halves run the
+        // kernels the one-stream schedule would have run
+        half[0].lat_form = half[1].lat_form = lattice_is_linear(p, training) ? 1 : 0;
+        half[0].stats_tile2d = half[1].stats_tile2d = stats_is_tile2d<Tag>(p, acts) ? 1 : 0;   // (the cut keeps both halves on 16-byte boundaries)
         const size_t slab = static_cast<size_t>(n0) * p.cells_per_sample * A;          // elements of acts / grads in front of the second half
         const S* acts_h[2] = {acts, acts + slab};
         S* grads_h[2] = {grads, grads != nullptr ? grads + slab : nullptr};
         const C* scale_h[2] = {grad_scale, grad_scale != nullptr ? grad_scale + n0 : nullptr};
         hipStream_t aux = t_aux.stream;
+        bool forked[2] = {false, false};
         auto pev = [&](hipEvent_t e, hipStream_t st) { if (prof) (void)hipEventRecord(e, st); };
         if (ranges) (void)g_ranges.push("warprnnt:two_half_schedule");
         for (int h = 0; h < 2; ++h) {
             pev(g_prof.hev[h][0], p.stream);
             launch_row_stats<Tag>(half[h], acts_h[h], vec_ok);
             pev(g_prof.hev[h][1], p.stream);
-            if (hipEventRecord(t_aux.ev[2 * h], p.stream) != hipSuccess || hipStreamWaitEvent(aux, t_aux.ev[2 * h], 0) != hipSuccess)
-                half[h].failed = true;
+            // the fork.  If it cannot be made (an event of another device, a stream that is gone), this half's lattice simply
+            // stays on the caller's stream -- the one-stream order, nothing left dangling on the auxiliary stream
+            forked[h] = hipEventRecord(t_aux.ev[2 * h], p.stream) == hipSuccess && hipStreamWaitEvent(aux, t_aux.ev[2 * h], 0) == hipSuccess;
+            if (!forked[h]) (void)hipGetLastError();
             // (the lattice kernel zeroes the batch's "has padding" word when it starts: only the first half's may -- the
             //  second runs beside the first half's coefficient kernel, which sets it -- so it gets a word of its own to clear)
             Plan<C> lat = half[h];
-            lat.stream = aux;
+            lat.stream = forked[h] ? aux : p.stream;
             if (h == 1) lat.padflag = p.padflag + 1;
-            pev(g_prof.lev[h][0], aux);
+            pev(g_prof.lev[h][0], lat.stream);
             launch_lattice(lat, training);
-            pev(g_prof.lev[h][1], aux);
-            if (lat.failed || hipEventRecord(t_aux.ev[2 * h + 1], aux) != hipSuccess) half[h].failed = true;
+            pev(g_prof.lev[h][1], lat.stream);
+            if (lat.failed || (forked[h] && hipEventRecord(t_aux.ev[2 * h + 1], aux) != hipSuccess)) half[h].failed = true;
         }
         for (int h = 0; h < 2; ++h) {
-            if (hipStreamWaitEvent(p.stream, t_aux.ev[2 * h + 1], 0) != hipSuccess) half[h].failed = true;   // the join
+            if (forked[h] && hipStreamWaitEvent(p.stream, t_aux.ev[2 * h + 1], 0) != hipSuccess) half[h].failed = true;   // the join
             pev(g_prof.hev[h][2], p.stream);
             if (training) launch_coef(half[h]);
             pev(g_prof.hev[h][3], p.stream);
@@ -473,7 +521,13 @@ int get_warprnnt_extension_version(void) { return 3; }
 
 const char* rnntGetStatusString(rnntStatus_t status) {
     // Same strings as the reference (src/rnnt_entrypoint.cpp:18-35) so log scrapers keep working.
-    switch (status) {
+    // A caller (a C program, ctypes) can hand over ANY int; loading a value outside the enumerators' range through the enum
+    // type is undefined behaviour in C++ (found by the UBSan run of `make asan`: tests/test_sanitizers.py), so the bits are
+    // read as the int they are.
+    int code = 0;
+    static_assert(sizeof(code) == sizeof(status), "rnntStatus_t is int-sized");
+    std::memcpy(&code, &status, sizeof(code));
+    switch (code) {
         case RNNT_STATUS_SUCCESS: return "no error";
         case RNNT_STATUS_MEMOPS_FAILED: return "cuda memcpy or memset failed";
         case RNNT_STATUS_INVALID_VALUE: return "invalid value";
@@ -507,10 +561,10 @@ rnntStatus_t compute_rnnt_loss(const float* const activations, float* gradients,
     if (bad_args(activations, flat_labels, label_lengths, input_lengths, costs, workspace, alphabet_size,
                  minibatch, options))
         return RNNT_STATUS_INVALID_VALUE;
-    if (options.loc == RNNT_CPU)
+    if (loc_of(options) == RNNT_CPU)
         return cpu_rnnt_f32(activations, gradients, flat_labels, label_lengths, input_lengths, alphabet_size,
                             minibatch, costs, workspace, options);
-    if (options.loc == RNNT_GPU)
+    if (loc_of(options) == RNNT_GPU)
         return run_gpu<F32>(activations, gradients, flat_labels, label_lengths, input_lengths, alphabet_size,
                             minibatch, costs, nullptr, nullptr, workspace, options);
     return RNNT_STATUS_INVALID_VALUE;
@@ -523,10 +577,10 @@ rnntStatus_t compute_rnnt_loss_fp64(const double* const activations, double* gra
     if (bad_args(activations, flat_labels, label_lengths, input_lengths, costs, workspace, alphabet_size,
                  minibatch, options))
         return RNNT_STATUS_INVALID_VALUE;
-    if (options.loc == RNNT_CPU)
+    if (loc_of(options) == RNNT_CPU)
         return cpu_rnnt_f64(activations, gradients, flat_labels, label_lengths, input_lengths, alphabet_size,
                             minibatch, costs, workspace, options);
-    if (options.loc == RNNT_GPU)
+    if (loc_of(options) == RNNT_GPU)
         return run_gpu<F64>(activations, gradients, flat_labels, label_lengths, input_lengths, alphabet_size,
                             minibatch, costs, nullptr, nullptr, workspace, options);
     return RNNT_STATUS_INVALID_VALUE;
@@ -537,7 +591,7 @@ rnntStatus_t compute_rnnt_loss_bf16(const uint16_t* const activations, uint16_t*
                                     const int* const input_lengths, int alphabet_size, int minibatch,
                                     float* costs, void* workspace, rnntOptions options) {
     if (bad_args(activations, flat_labels, label_lengths, input_lengths, costs, workspace, alphabet_size,
-                 minibatch, options) || options.loc != RNNT_GPU)
+                 minibatch, options) || loc_of(options) != RNNT_GPU)
         return RNNT_STATUS_INVALID_VALUE;
     return run_gpu<BF16>(activations, gradients, flat_labels, label_lengths, input_lengths, alphabet_size,
                          minibatch, costs, nullptr, nullptr, workspace, options);
@@ -548,7 +602,7 @@ rnntStatus_t compute_rnnt_loss_fp16(const uint16_t* const activations, uint16_t*
                                     const int* const input_lengths, int alphabet_size, int minibatch,
                                     float* costs, void* workspace, rnntOptions options) {
     if (bad_args(activations, flat_labels, label_lengths, input_lengths, costs, workspace, alphabet_size,
-                 minibatch, options) || options.loc != RNNT_GPU)
+                 minibatch, options) || loc_of(options) != RNNT_GPU)
         return RNNT_STATUS_INVALID_VALUE;
     return run_gpu<F16>(activations, gradients, flat_labels, label_lengths, input_lengths, alphabet_size,
                         minibatch, costs, nullptr, nullptr, workspace, options);
@@ -586,7 +640,7 @@ rnntStatus_t compute_rnnt_loss_async(const void* activations, void* gradients, c
                                      const void* grad_scale_device, void* workspace, rnntOptions options,
                                      int dtype_code) {
     if (bad_args(activations, flat_labels, label_lengths, input_lengths, costs_device, workspace,
-                 alphabet_size, minibatch, options) || options.loc != RNNT_GPU)
+                 alphabet_size, minibatch, options) || loc_of(options) != RNNT_GPU)
         return RNNT_STATUS_INVALID_VALUE;
     return run_async(activations, gradients, flat_labels, label_lengths, input_lengths, alphabet_size, minibatch,
                      costs_device, grad_scale_device, workspace, options, dtype_code, 3, -1);
@@ -670,7 +724,7 @@ rnntStatus_t compute_rnnt_loss_sharded(const void* activations, void* gradients,
                                        const void* grad_scale_device, double* loss_sum_count_device, void* rccl_comm,
                                        void* workspace, rnntOptions options, int dtype_code) {
     // (argument errors every rank of a job makes alike return before anything is enqueued)
-    if (loss_sum_count_device == nullptr || options.loc != RNNT_GPU) return RNNT_STATUS_INVALID_VALUE;
+    if (loss_sum_count_device == nullptr || loc_of(options) != RNNT_GPU) return RNNT_STATUS_INVALID_VALUE;
     Rccl::AllReduce all_reduce = nullptr;
     if (rccl_comm != nullptr && (all_reduce = rccl_all_reduce()) == nullptr) return RNNT_STATUS_EXECUTION_FAILED;   // no (unambiguous) RCCL in this process
     hipStream_t stream = reinterpret_cast<hipStream_t>(options.stream);
@@ -708,7 +762,7 @@ rnntStatus_t compute_rnnt_loss_fwd(const void* activations, const int* const fla
                                    int alphabet_size, int minibatch, void* costs_device, void* workspace,
                                    rnntOptions options, int dtype_code, int prepare_backward) {
     if (bad_args(activations, flat_labels, label_lengths, input_lengths, costs_device, workspace,
-                 alphabet_size, minibatch, options) || options.loc != RNNT_GPU)
+                 alphabet_size, minibatch, options) || loc_of(options) != RNNT_GPU)
         return RNNT_STATUS_INVALID_VALUE;
     return run_async(activations, nullptr, flat_labels, label_lengths, input_lengths, alphabet_size, minibatch,
                      costs_device, nullptr, workspace, options, dtype_code, 1, prepare_backward ? 1 : 0);
@@ -718,7 +772,7 @@ rnntStatus_t compute_rnnt_loss_bwd(const void* activations, void* gradients, con
                                    int alphabet_size, int minibatch, void* workspace, rnntOptions options,
                                    int dtype_code) {
     if (activations == nullptr || gradients == nullptr || workspace == nullptr || alphabet_size <= 0 ||
-        minibatch <= 0 || options.maxT <= 0 || options.maxU <= 0 || options.loc != RNNT_GPU)
+        minibatch <= 0 || options.maxT <= 0 || options.maxU <= 0 || loc_of(options) != RNNT_GPU)
         return RNNT_STATUS_INVALID_VALUE;
     return run_async(activations, gradients, nullptr, nullptr, nullptr, alphabet_size, minibatch, nullptr,
                      grad_scale_device, workspace, options, dtype_code, 2, 1);
@@ -726,7 +780,7 @@ rnntStatus_t compute_rnnt_loss_bwd(const void* activations, void* gradients, con
 
 rnntStatus_t compute_rnnt_loss_likelihoods(const void* workspace, int minibatch, rnntOptions options, int dtype_code,
                                            double* ll_forward_host, double* ll_backward_host) {
-    if (workspace == nullptr || minibatch <= 0 || options.maxT <= 0 || options.maxU <= 0 || options.loc != RNNT_GPU ||
+    if (workspace == nullptr || minibatch <= 0 || options.maxT <= 0 || options.maxU <= 0 || loc_of(options) != RNNT_GPU ||
         ll_forward_host == nullptr || ll_backward_host == nullptr || dtype_code < 0 || dtype_code > 3)
         return RNNT_STATUS_INVALID_VALUE;
     const Layout lay = make_layout(options.maxT, options.maxU, minibatch, dtype_code == 1 ? 8 : 4, false);
@@ -747,7 +801,7 @@ rnntStatus_t compute_rnnt_loss_fastemit(const void* activations, void* gradients
                                         const void* grad_scale_device, void* workspace, rnntOptions options,
                                         int dtype_code, float fastemit_lambda) {
     if (bad_args(activations, flat_labels, label_lengths, input_lengths, costs_device, workspace,
-                 alphabet_size, minibatch, options) || options.loc != RNNT_GPU)
+                 alphabet_size, minibatch, options) || loc_of(options) != RNNT_GPU)
         return RNNT_STATUS_INVALID_VALUE;
     return run_async(activations, gradients, flat_labels, label_lengths, input_lengths, alphabet_size, minibatch,
                      costs_device, grad_scale_device, workspace, options, dtype_code, 3, -1, fastemit_lambda);
@@ -759,7 +813,7 @@ rnntStatus_t compute_rnnt_loss_fwd_fastemit(const void* activations, const int* 
                                             rnntOptions options, int dtype_code, int prepare_backward,
                                             float fastemit_lambda) {
     if (bad_args(activations, flat_labels, label_lengths, input_lengths, costs_device, workspace,
-                 alphabet_size, minibatch, options) || options.loc != RNNT_GPU)
+                 alphabet_size, minibatch, options) || loc_of(options) != RNNT_GPU)
         return RNNT_STATUS_INVALID_VALUE;
     return run_async(activations, nullptr, flat_labels, label_lengths, input_lengths, alphabet_size, minibatch,
                      costs_device, nullptr, workspace, options, dtype_code, 1, prepare_backward != 0 ? 1 : 0,
@@ -774,7 +828,7 @@ rnntStatus_t compute_rnnt_loss_packed(const void* activations, void* gradients, 
     if (bad_args(activations, flat_labels, label_lengths, input_lengths, costs_device, workspace,
                  alphabet_size, minibatch, options) || row_offsets == nullptr)
         return RNNT_STATUS_INVALID_VALUE;
-    if (options.loc == RNNT_CPU) {
+    if (loc_of(options) == RNNT_CPU) {
         // the reference's CPU contract on the packed rows: every array on the host (row_offsets and costs too),
         // log-probabilities in, sparse log-prob gradients out (rnnt_cpu.cpp); fp32 / fp64, no scale, no FastEmit
         if (dtype_code > 1 || dtype_code < 0 || grad_scale_device != nullptr || fastemit_lambda != 0.0f ||
@@ -783,7 +837,7 @@ rnntStatus_t compute_rnnt_loss_packed(const void* activations, void* gradients, 
         return cpu_rnnt_packed(activations, gradients, flat_labels, label_lengths, input_lengths, row_offsets,
                                alphabet_size, minibatch, costs_device, workspace, options, dtype_code == 1);
     }
-    if (options.loc != RNNT_GPU) return RNNT_STATUS_INVALID_VALUE;
+    if (loc_of(options) != RNNT_GPU) return RNNT_STATUS_INVALID_VALUE;
     return run_async(activations, gradients, flat_labels, label_lengths, input_lengths, alphabet_size, minibatch,
                      costs_device, grad_scale_device, workspace, options, dtype_code, 3, -1, fastemit_lambda,
                      row_offsets, total_rows);
@@ -796,7 +850,7 @@ rnntStatus_t compute_rnnt_loss_packed_fwd(const void* activations, const int* co
                                           rnntOptions options, int dtype_code, int prepare_backward,
                                           float fastemit_lambda) {
     if (bad_args(activations, flat_labels, label_lengths, input_lengths, costs_device, workspace,
-                 alphabet_size, minibatch, options) || row_offsets == nullptr || options.loc != RNNT_GPU)
+                 alphabet_size, minibatch, options) || row_offsets == nullptr || loc_of(options) != RNNT_GPU)
         return RNNT_STATUS_INVALID_VALUE;
     return run_async(activations, nullptr, flat_labels, label_lengths, input_lengths, alphabet_size, minibatch,
                      costs_device, nullptr, workspace, options, dtype_code, 1, prepare_backward != 0 ? 1 : 0,
@@ -808,13 +862,16 @@ rnntStatus_t compute_rnnt_loss_packed_bwd(const void* activations, void* gradien
                                           int alphabet_size, int minibatch, void* workspace, rnntOptions options,
                                           int dtype_code) {
     if (activations == nullptr || gradients == nullptr || row_offsets == nullptr || workspace == nullptr ||
-        alphabet_size <= 0 || minibatch <= 0 || options.maxT <= 0 || options.maxU <= 0 || options.loc != RNNT_GPU)
+        alphabet_size <= 0 || minibatch <= 0 || options.maxT <= 0 || options.maxU <= 0 || loc_of(options) != RNNT_GPU)
         return RNNT_STATUS_INVALID_VALUE;
     return run_async(activations, gradients, nullptr, nullptr, nullptr, alphabet_size, minibatch, nullptr,
                      grad_scale_device, workspace, options, dtype_code, 2, 1, 0.0f, row_offsets, total_rows);
 }
 
-void rnnt_set_aux_stream(CUstream stream) { t_aux.stream = reinterpret_cast<hipStream_t>(stream); }
+void rnnt_set_aux_stream(CUstream stream) {
+    t_aux.stream = reinterpret_cast<hipStream_t>(stream);
+    aux_drop_events();          // the next call makes them again on ITS device (a stream of another GPU, NULL = release)
+}
 
 int rnnt_host_staging(int mode) {
     const int before = stage_enabled() ? 1 : 0;

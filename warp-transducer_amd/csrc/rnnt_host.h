@@ -267,6 +267,9 @@ template <typename C> struct Plan {
     size_t side_bytes = 0;
     int lat_cols = 1;              // lattice columns per lane (1 | 2), its wavefronts per block ...
     int lat_w = 1, lat_sh = 6;     // ... and the column -> wavefront shift (coefficient kernels)
+    int lat_form = -1;             // lattice kernel form: -1 by the rule of launch_lattice, 0 log-domain, 1 linear-domain chain (a half of the
+                                   // two-half schedule takes the WHOLE batch's choice: same kernels, same bits)
+    int stats_tile2d = -1;         // 2-D tile statistics kernel: -1 by the rule of stats_is_tile2d, 0 no, 1 yes (halves again)
     float fastemit = 0.0f;         // FastEmit lambda (extension entries only)
     const long long* offsets = nullptr;        // packed layout: cumulative row offsets (device, N+1 entries) ...
     unsigned long long packed_rows = 0;        // ... and the total number of rows (host)
@@ -332,6 +335,13 @@ static inline int device_cus() {
     return n;
 }
 
+// The linear-domain chain kernel (one-wavefront fp32 lattices, at most one block per compute unit) or the log-domain one?
+template <typename C> static bool lattice_is_linear(const Plan<C>& p, bool with_beta) {
+    if (p.Up > 64 || sizeof(C) != 4 || !tune().latlin) return false;
+    if (p.lat_form >= 0) return p.lat_form == 1;
+    return tune().latlin >= 2 || p.N * (with_beta ? 2 : 1) <= device_cus();
+}
+
 // Stage 2: alpha (and, for gradients, beta) recursion; writes the costs.
 template <typename C> static void launch_lattice(Plan<C>& p, bool with_beta) {
     const int dirs = with_beta ? 2 : 1;
@@ -343,7 +353,7 @@ template <typename C> static void launch_lattice(Plan<C>& p, bool with_beta) {
     // (range guard + log-domain fallback inside).  Its eight wavefronts per (sample, direction) buy latency with idle
     // SIMDs; past one block per CU there are none and the one-wavefront kernel is the faster again (N=128 T=200 U=41:
     // 13.6 us against 17.2; N=192: 18.9 against 17.4; N=1024: 57 against 37).
-    if (p.Up <= 64 && sizeof(C) == 4 && tune().latlin && (tune().latlin >= 2 || p.N * dirs <= device_cus())) {
+    if (lattice_is_linear(p, with_beta)) {
         if constexpr (sizeof(C) == 4)
             hipLaunchKernelGGL((lattice_lin_kernel<0>), dim3(p.N * dirs), dim3(kLinThreads), 0, p.stream, p.lp2, p.alpha, p.beta, p.offa, p.offb,
                                p.llf, p.llb, p.costs_dev, p.input_lengths, p.label_lengths, p.maxT, p.maxU, p.Up, dirs,
@@ -404,6 +414,16 @@ template <typename C> static bool launch_coef(Plan<C>& p, bool joint = false, bo
     }
     p.check();
     return false;
+}
+
+// options.loc as the int a caller really passed: a C program or ctypes can put ANY value there, and loading one outside the
+// enumerators' range through the enum type is undefined behaviour in C++ (UBSan, `make asan`); every entry point answers an
+// unknown location with RNNT_STATUS_INVALID_VALUE, as the reference does (src/rnnt_entrypoint.cpp:90-92).
+static inline int loc_of(const rnntOptions& o) {
+    int v = 0;
+    static_assert(sizeof(v) == sizeof(o.loc), "rnntComputeLocation is int-sized");
+    std::memcpy(&v, &o.loc, sizeof(v));
+    return v;
 }
 
 static bool bad_args(const void* acts, const int* labels, const int* label_lengths,

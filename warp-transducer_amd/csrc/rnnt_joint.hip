@@ -304,7 +304,7 @@ rnntStatus_t compute_rnnt_loss_add(const float* const trans_acts, const float* c
                                    int alphabet_size, int minibatch, float* costs_device, void* workspace,
                                    rnntOptions options) {
     if (bad_args(trans_acts, flat_labels, label_lengths, input_lengths, costs_device, workspace, alphabet_size,
-                 minibatch, options) || pred_acts == nullptr || options.loc != RNNT_GPU)
+                 minibatch, options) || pred_acts == nullptr || loc_of(options) != RNNT_GPU)
         return RNNT_STATUS_INVALID_VALUE;
     if ((trans_grads == nullptr) != (pred_grads == nullptr)) return RNNT_STATUS_INVALID_VALUE;
     const bool training = trans_grads != nullptr;
@@ -319,7 +319,7 @@ rnntStatus_t compute_rnnt_loss_add_fwd(const float* const trans_acts, const floa
                                        float* costs_device, void* workspace, rnntOptions options,
                                        int prepare_backward) {
     if (bad_args(trans_acts, flat_labels, label_lengths, input_lengths, costs_device, workspace, alphabet_size,
-                 minibatch, options) || pred_acts == nullptr || options.loc != RNNT_GPU)
+                 minibatch, options) || pred_acts == nullptr || loc_of(options) != RNNT_GPU)
         return RNNT_STATUS_INVALID_VALUE;
     return run_gpu_joint<F32>(trans_acts, pred_acts, nullptr, nullptr, flat_labels, label_lengths, input_lengths,
                          alphabet_size, minibatch, costs_device, nullptr, workspace, options, 1,
@@ -332,7 +332,7 @@ rnntStatus_t compute_rnnt_loss_add_fwd_fastemit(const float* const trans_acts, c
                                                 float* costs_device, void* workspace, rnntOptions options,
                                                 int prepare_backward, float fastemit_lambda) {
     if (bad_args(trans_acts, flat_labels, label_lengths, input_lengths, costs_device, workspace, alphabet_size,
-                 minibatch, options) || pred_acts == nullptr || options.loc != RNNT_GPU)
+                 minibatch, options) || pred_acts == nullptr || loc_of(options) != RNNT_GPU)
         return RNNT_STATUS_INVALID_VALUE;
     return run_gpu_joint<F32>(trans_acts, pred_acts, nullptr, nullptr, flat_labels, label_lengths, input_lengths,
                          alphabet_size, minibatch, costs_device, nullptr, workspace, options, 1,
@@ -346,7 +346,7 @@ rnntStatus_t compute_rnnt_loss_add_bwd(const float* const trans_acts, const floa
                                        void* workspace, rnntOptions options) {
     if (trans_acts == nullptr || pred_acts == nullptr || trans_grads == nullptr || pred_grads == nullptr ||
         flat_labels == nullptr || label_lengths == nullptr || input_lengths == nullptr || workspace == nullptr ||
-        alphabet_size <= 0 || minibatch <= 0 || options.maxT <= 0 || options.maxU <= 0 || options.loc != RNNT_GPU)
+        alphabet_size <= 0 || minibatch <= 0 || options.maxT <= 0 || options.maxU <= 0 || loc_of(options) != RNNT_GPU)
         return RNNT_STATUS_INVALID_VALUE;
     return run_gpu_joint<F32>(trans_acts, pred_acts, trans_grads, pred_grads, flat_labels, label_lengths,
                          input_lengths, alphabet_size, minibatch, nullptr, grad_scale_device, workspace, options, 2,
@@ -360,7 +360,7 @@ rnntStatus_t compute_rnnt_loss_add_fwd_dt(const void* trans_acts, const void* pr
                                           rnntOptions options, int dtype_code, int prepare_backward,
                                           float fastemit_lambda) {
     if (bad_args(trans_acts, flat_labels, label_lengths, input_lengths, costs_device, workspace, alphabet_size,
-                 minibatch, options) || pred_acts == nullptr || options.loc != RNNT_GPU)
+                 minibatch, options) || pred_acts == nullptr || loc_of(options) != RNNT_GPU)
         return RNNT_STATUS_INVALID_VALUE;
     const bool pb = prepare_backward != 0;
     switch (dtype_code) {
@@ -384,7 +384,7 @@ rnntStatus_t compute_rnnt_loss_add_bwd_dt(const void* trans_acts, const void* pr
                                           void* workspace, rnntOptions options, int dtype_code) {
     if (trans_acts == nullptr || pred_acts == nullptr || trans_grads == nullptr || pred_grads == nullptr ||
         flat_labels == nullptr || label_lengths == nullptr || input_lengths == nullptr || workspace == nullptr ||
-        alphabet_size <= 0 || minibatch <= 0 || options.maxT <= 0 || options.maxU <= 0 || options.loc != RNNT_GPU)
+        alphabet_size <= 0 || minibatch <= 0 || options.maxT <= 0 || options.maxU <= 0 || loc_of(options) != RNNT_GPU)
         return RNNT_STATUS_INVALID_VALUE;
     switch (dtype_code) {
         case 0: return run_gpu_joint<F32>(static_cast<const float*>(trans_acts), static_cast<const float*>(pred_acts),

@@ -19,6 +19,7 @@ from torch.autograd import Function
 from torch.nn import Module
 
 from . import _lib, check_contiguous, check_dim, check_type
+from ._checks import check_gpu_arguments
 
 __all__ = ["rnnt_loss_add", "RNNTLossAdd"]
 
@@ -46,6 +47,9 @@ def _certify(trans_acts, pred_acts, labels, act_lens, label_lens, read_lengths=T
         raise ValueError("trans_acts (B,T,V) and pred_acts (B,U+1,V) disagree")
     if act_lens.shape[0] != B or label_lens.shape[0] != B:
         raise ValueError("must have a length per example.")
+    if pred_acts.device != trans_acts.device:
+        raise ValueError("pred_acts must be on the device of trans_acts")
+    check_gpu_arguments(trans_acts, labels, act_lens, label_lens)
     if not read_lengths:
         return
     if T != torch.max(act_lens):

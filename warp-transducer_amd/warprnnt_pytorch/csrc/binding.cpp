@@ -46,6 +46,24 @@ int dtype_code(const at::Tensor& t) {              // include/rnnt.h: 0 fp32, 1 
 
 size_t elem_size_for_workspace(int code) { return code == 1 ? 8 : (code == 0 ? 4 : 2); }
 
+// The GPU location dereferences labels and both length vectors ON THE DEVICE of the activations: a host tensor (or one of
+// another GPU) there is a GPU fault, not an exception -- unless it is caught here.
+void check_on_device_of(const at::Tensor& acts, const at::Tensor& t, const char* name) {
+    TORCH_CHECK_VALUE(t.is_cuda() && t.device() == acts.device(), name, " must be on the device of the activations (", acts.device(),
+                      "), got ", t.device());
+}
+void check_gpu_arguments(const at::Tensor& acts, const at::Tensor& labels, const at::Tensor& lengths, const at::Tensor& label_lengths) {
+    if (labels.numel() > 0) check_on_device_of(acts, labels, "labels");
+    check_on_device_of(acts, lengths, "lengths");
+    check_on_device_of(acts, label_lengths, "label_lengths");
+}
+// A caller-owned workspace: on the device of the activations and at least as large as get_workspace_size says TODAY (the
+// layout is private and has grown between versions: a size cached from an older library must not be silently overrun).
+void check_workspace(const at::Tensor& acts, const at::Tensor& ws, size_t need) {
+    TORCH_CHECK_VALUE(ws.is_cuda() && ws.device() == acts.device(), "workspace must be on the device of the activations");
+    TORCH_CHECK_VALUE(ws.is_contiguous() && ws.nbytes() >= need, "workspace of ", ws.nbytes(), " bytes, get_workspace_size asks for ", need);
+}
+
 void check_status(rnntStatus_t st, const char* what) {
     if (st != RNNT_STATUS_SUCCESS)
         throw std::runtime_error(std::string(what) + " failed: " + rnntGetStatusString(st) + " (status " + std::to_string(static_cast<int>(st)) + ")");
@@ -123,9 +141,10 @@ int gpu_rnnt(const at::Tensor& acts, const at::Tensor& labels, const at::Tensor&
     }
     const DeviceGuard guard(acts.device());
     const hipStream_t stream = c10::hip::getCurrentHIPStream(acts.device().index()).stream();
-    at::Tensor ws = workspace.has_value() ? *workspace
-                                          : at::empty({static_cast<long>(workspace_bytes(T, U, N, true, elem_size_for_workspace(code)))},
-                                                      acts.options().dtype(at::kByte));
+    check_gpu_arguments(acts, labels, input_lengths, label_lengths);
+    const size_t need = workspace_bytes(T, U, N, true, elem_size_for_workspace(code));
+    if (workspace.has_value()) check_workspace(acts, *workspace, need);
+    at::Tensor ws = workspace.has_value() ? *workspace : at::empty({static_cast<long>(need)}, acts.options().dtype(at::kByte));
     const rnntOptions opt = make_options(RNNT_GPU, acts, blank_label, num_threads, stream);
     void* g = grads.numel() > 0 ? grads.data_ptr() : nullptr;
     rnntStatus_t st;
@@ -152,6 +171,7 @@ at::Tensor gpu_rnnt_fwd(const at::Tensor& acts, const at::Tensor& labels, const 
               A = static_cast<int>(acts.size(3));
     const int code = dtype_code(acts);
     TORCH_CHECK_TYPE(code >= 0, "rnnt_loss: unsupported dtype ", c10::toString(acts.scalar_type()), " for the GPU location");
+    check_gpu_arguments(acts, labels, input_lengths, label_lengths);
     const int index = acts.device().index();
     OptionalDeviceGuard guard;                  // (entered only when the tensors do not live on the current device)
     if (at::hip::current_device() != index) guard.set_index(index);
@@ -176,6 +196,7 @@ void gpu_rnnt_bwd(const at::Tensor& acts, at::Tensor grads, const c10::optional<
                   int blank_label, long fwd_stream) {
     const int N = static_cast<int>(acts.size(0)), A = static_cast<int>(acts.size(3));
     const int code = dtype_code(acts);
+    check_workspace(acts, workspace, workspace_bytes(static_cast<int>(acts.size(1)), static_cast<int>(acts.size(2)), N, true, elem_size_for_workspace(code)));
     const int index = acts.device().index();
     OptionalDeviceGuard guard;
     if (at::hip::current_device() != index) guard.set_index(index);
@@ -352,6 +373,8 @@ struct RNNTAddFunction : public torch::autograd::Function<RNNTAddFunction> {
                               const at::Tensor& act_lens, const at::Tensor& label_lens, int64_t blank, int64_t reduction,
                               double fastemit_lambda, bool validate) {
         certify_add(f, g, labels, act_lens, label_lens, validate);
+        check_on_device_of(f, g, "pred_acts");
+        check_gpu_arguments(f, labels, act_lens, label_lens);
         const long n = f.size(0);
         const int T = static_cast<int>(f.size(1)), U = static_cast<int>(g.size(1)), V = static_cast<int>(f.size(2));
         const bool need_grad = f.requires_grad() || g.requires_grad();

@@ -17,6 +17,7 @@ import os as _os
 import torch
 
 from . import _lib
+from ._checks import check_gpu_arguments
 
 # The compiled module (csrc/binding.cpp, built in tree by build_ext.py / setup.py) is the default binding, as in the
 # reference (a pybind11 extension, pytorch_binding/src/binding.cpp:157-162); the ctypes route below is the fallback when it
@@ -108,6 +109,7 @@ def gpu_rnnt(acts, labels, input_lengths, label_lengths, costs, grads, blank_lab
         print("warp_rnnt.gpu_rnnt: unsupported data type %s" % acts.dtype, file=sys.stderr)
         return -1
     fn, esz = table[acts.dtype]
+    check_gpu_arguments(acts, labels, input_lengths, label_lengths, workspace, _lib.workspace_bytes(T, U, N, True, esz))
     with torch.cuda.device(acts.device):
         ws = workspace if workspace is not None else torch.empty(_lib.workspace_bytes(T, U, N, True, esz),
                                                                  dtype=torch.uint8, device=acts.device)
@@ -129,6 +131,7 @@ def gpu_rnnt_async(acts, labels, input_lengths, label_lengths, costs_device, gra
     N, T, U, A = acts.shape
     code = {torch.float32: (_lib.DT_F32, 4), torch.float64: (_lib.DT_F64, 8),
             torch.bfloat16: (_lib.DT_BF16, 2), torch.float16: (_lib.DT_F16, 2)}[acts.dtype]
+    check_gpu_arguments(acts, labels, input_lengths, label_lengths, workspace, _lib.workspace_bytes(T, U, N, True, code[1]))
     with torch.cuda.device(acts.device):
         if workspace is None:
             workspace = torch.empty(_lib.workspace_bytes(T, U, N, True, code[1]), dtype=torch.uint8,
@@ -212,6 +215,7 @@ def gpu_rnnt_fwd(acts, labels, input_lengths, label_lengths, costs_device, blank
     if dt is None:
         raise TypeError("rnnt_loss: unsupported dtype %s for the GPU location" % acts.dtype)
     code, esz = dt
+    check_gpu_arguments(acts, labels, input_lengths, label_lengths)
     index = acts.device.index
     with _on_device(index):
         ws = torch.empty(_workspace_bytes_cached(T, U, N, esz), dtype=torch.uint8, device=acts.device)
@@ -244,7 +248,8 @@ def gpu_rnnt_bwd(acts, grads, grad_scale, workspace, blank_label):
         return 0
     lib = _lib.lib()
     N, T, U, A = acts.shape
-    code, _ = _DT[acts.dtype]
+    code, esz = _DT[acts.dtype]
+    check_gpu_arguments(acts, acts, acts, acts, workspace, _workspace_bytes_cached(T, U, N, esz))     # (only the workspace is an argument here)
     index = acts.device.index
     with _on_device(index):
         stream = _raw_stream(index)

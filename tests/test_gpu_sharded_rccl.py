@@ -361,3 +361,60 @@ def test_native_sharded_entry_over_two_rccl_ranks():
     for rank, costs, pair in got:
         assert pair[1] == 6 and abs(pair[0] - total) <= 1e-9 * abs(total)
         assert np.array_equal(costs, ref_c[:4].cpu().numpy() if rank == 0 else ref_c[4:].cpu().numpy())
+
+
+def _duplicate_device_worker(rank, world, uid_bytes, q):
+    """The body of _native_worker up to the communicator, with BOTH ranks on device 0."""
+    for p in (ROOT, os.path.join(ROOT, "warp-transducer_amd")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    acts, labels, tl, ll = _batch(dev)                               # the shard this rank would have run
+    rccl = _rccl()
+    uid = _NcclUniqueId()
+    C.memmove(C.byref(uid), uid_bytes, 128)
+    comm = C.c_void_p()
+    rc = rccl.ncclCommInitRank(C.byref(comm), world, uid, rank)
+    if rc == 0:                                                      # (an RCCL that accepts it: run the real thing, then)
+        sl = slice(0, 4) if rank == 0 else slice(4, 6)
+        costs, grads, pair = _sharded_call(acts[sl].contiguous(), labels[sl].contiguous(), tl[sl].contiguous(), ll[sl].contiguous(), comm)
+        q.put((rank, rc, pair.cpu().numpy()))
+        rccl.ncclCommDestroy(comm)
+    else:
+        q.put((rank, rc, None))
+
+
+def test_two_native_ranks_on_one_device_reach_rccl_and_are_refused():
+    """What a ONE-GPU box can execute of the two-rank native path: both processes go through the
+    whole bootstrap -- unique id carried between the processes, device selection, ncclCommInitRank with world = 2 -- on device
+    0, where RCCL must answer with its duplicate-GPU refusal (ncclInvalidUsage = 5) on both ranks rather than hang or crash.
+    (If an RCCL build ever accepts two ranks on one device, the sharded call itself runs and must give the global pair.)"""
+    import queue as queue_mod
+    import torch.multiprocessing as mp
+    rccl = _rccl()
+    uid = _NcclUniqueId()
+    assert rccl.ncclGetUniqueId(C.byref(uid)) == 0
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    uid_bytes = C.string_at(C.addressof(uid), 128)
+    procs = [ctx.Process(target=_duplicate_device_worker, args=(r, 2, uid_bytes, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = []
+    try:
+        for _ in procs:
+            got.append(q.get(timeout=150))
+    except queue_mod.Empty:
+        pass
+    for p in procs:
+        p.join(timeout=30)
+        if p.is_alive():
+            p.terminate()
+    assert len(got) == 2, "a rank never came back from ncclCommInitRank (world 2 on one device)"
+    codes = sorted(rc for _, rc, _ in got)
+    if codes == [0, 0]:
+        assert all(pair[1] == 6 for _, _, pair in got)
+    else:
+        assert all(rc != 0 for rc in codes), codes                  # refused on BOTH ranks (5 = ncclInvalidUsage: duplicate GPU)

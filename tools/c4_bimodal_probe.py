@@ -119,8 +119,65 @@ def run():
             print(json.dumps({"placement": "FAILED", "error": repr(e)}), flush=True)
 
 
+def matrix():
+    """WHICH allocation carries the state?  Three activation buffers and three workspaces, allocated behind fillers of
+    different sizes (different physical pages), all kept alive; every combination is measured.  With the development library
+    (WARP_RNNT_PATH=.../lib/dev, RNNT_TUNE_LIVE=1) each combination is measured with every tile order of the statistics
+    kernel (RNNT_TUNE=t2ord=0|1|2) -- same buffers, same process, alternating."""
+    import torch
+    from warprnnt_pytorch import _lib
+    lib = _lib.lib()
+    dev = torch.device("cuda:0")
+    N, T, U, A = 64, 1500, 301, 50
+    E = N * T * U * A
+    lab = torch.randint(1, A, (N, U - 1), device=dev, dtype=torch.int32)
+    tl = torch.full((N,), T, dtype=torch.int32, device=dev)
+    ll = torch.full((N,), U - 1, dtype=torch.int32, device=dev)
+    costs = torch.empty(N, device=dev)
+    wsb = _lib.workspace_bytes(T, U, N, True, 4)
+    stream = torch.cuda.current_stream().cuda_stream
+    opt = _lib.rnntOptions(loc=1, num_threads=0, stream=stream, blank_label=0, maxT=T, maxU=U, batch_first=True)
+    src = torch.rand(E // 64, device=dev)
+    acts, wss, keep = [], [], []
+    for gb in (0, 7, 33):                                          # fillers stay allocated: the next buffers come from other pages
+        if gb:
+            keep.append(torch.empty(gb << 30, dtype=torch.uint8, device=dev))
+        a = torch.empty(E, device=dev)
+        for i in range(64):
+            a.view(-1)[i * (E // 64):(i + 1) * (E // 64)].copy_(src)
+        acts.append(a)
+        wss.append(torch.empty(wsb, dtype=torch.uint8, device=dev))
+    grads = torch.empty(E, device=dev)
+    live = bool(os.environ.get("RNNT_TUNE_LIVE"))
+    variants = ["t2ord=0", "t2ord=1", "t2ord=2"] if live else [""]
+    for rnd in range(2):
+        for ia, a in enumerate(acts):
+            for iw, w in enumerate(wss):
+                rec = {"round": rnd, "acts": ia, "ws": iw, "acts_ptr": hex(a.data_ptr()), "ws_ptr": hex(w.data_ptr())}
+                for v in variants:
+                    if live:
+                        os.environ["RNNT_TUNE"] = v
+                    lib.rnnt_profile_reset(); lib.rnnt_profile_enable(1)
+                    for i in range(4):
+                        if i == 1:
+                            torch.cuda.synchronize(); lib.rnnt_profile_collect(); lib.rnnt_profile_reset()
+                        st = lib.compute_rnnt_loss_async(a.data_ptr(), grads.data_ptr(), lab.data_ptr(), ll.data_ptr(), tl.data_ptr(), A, N,
+                                                         costs.data_ptr(), None, w.data_ptr(), opt, 0)
+                        assert st == 0
+                        torch.cuda.synchronize(); lib.rnnt_profile_collect()
+                    ms = (C.c_double * 5)()
+                    calls = lib.rnnt_profile_read(ms, 5)
+                    lib.rnnt_profile_enable(0)
+                    rec["stats_ms " + v] = round(ms[0] / calls, 4)
+                    rec["grad_ms " + v] = round(ms[3] / calls, 4)
+                rec["loss0"] = float(costs[0])
+                print(json.dumps(rec), flush=True)
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 2 and sys.argv[1] == "table":
         table(sys.argv[2:])
+    elif len(sys.argv) > 1 and sys.argv[1] == "matrix":
+        matrix()
     else:
         run()

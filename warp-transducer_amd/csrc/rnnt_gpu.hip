@@ -56,8 +56,11 @@ static void launch_row_stats(Plan<typename Tag::comp>& p, const typename Tag::st
         const int tilesT = (p.maxT + TT - 1) / TT, tilesU = (p.maxU + TU - 1) / TU;
         const unsigned long long ntile = static_cast<unsigned long long>(p.N) * tilesT * tilesU;
         const int piece = (static_cast<int>(TU * row_bytes) + 15 + 15) / 16 * 16;      // covering packets of a piece at any phase
-        if (ntile < (1ull << 31)) {
-            const unsigned xgrid = static_cast<unsigned>((ntile + 7) / 8 * 8);
+        if (ntile < (1ull << 30)) {
+            const int order = tn.t2ord;
+            const unsigned long long pts = static_cast<unsigned long long>(tilesT) * tilesU;
+            const unsigned xgrid = order == 2 ? static_cast<unsigned>(static_cast<unsigned long long>(p.N) * 8 * ((pts + 7) / 8))
+                                              : static_cast<unsigned>((ntile + 7) / 8 * 8);
             // (the 256 results overlay the tile: TT rows of TU + 1 {pair, log Z} records of the lattice type)
             const size_t lds2 = static_cast<size_t>(TT) * piece > 8192 ? static_cast<size_t>(TT) * piece : 8192;
 #ifdef RNNT_DEV
@@ -68,7 +71,7 @@ static void launch_row_stats(Plan<typename Tag::comp>& p, const typename Tag::st
 #define RNNT_TILE2D(T1, U1)                                                                                       \
     hipLaunchKernelGGL((row_stats_tile2d_kernel<Tag, T1, U1>), dim3(xgrid), dim3(256), lds2, p.stream, acts, p.labels, \
                        p.input_lengths, p.label_lengths, p.lp2, p.logz, p.maxT, p.maxU, p.Up, p.A, p.blank, p.N, tilesT, \
-                       tilesU, piece, RNNT_TILE2D_POISON)
+                       tilesU, piece, RNNT_TILE2D_POISON, order)
             if (sq) RNNT_TILE2D(16, 16); else RNNT_TILE2D(8, 32);
 #undef RNNT_TILE2D
 #undef RNNT_TILE2D_POISON

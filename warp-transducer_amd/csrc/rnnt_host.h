@@ -210,10 +210,11 @@ static void ranges_mark(int i, bool do_fwd, bool do_bwd, const char* const names
 // tile2d = 2-D cell-tile statistics kernel for short rows under wide lattices: 0 off, 1 = 8 x 32 cells per block, 2 = 16 x 16 (default),
 // jfsum = additive joint: the correction sums of the gradient GEMMs formed inside the tiled coefficient kernel on/off,
 // jsplit = additive joint, small vocabularies: the wavefronts of a DF / DG block split the contraction instead of the columns on/off,
-// jnocb = additive joint, one-hot DF behind the tiled coefficient kernel: blank corrections from the row sums, no CB plane on/off.
+// jnocb = additive joint, one-hot DF behind the tiled coefficient kernel: blank corrections from the row sums, no CB plane on/off,
+// t2ord = tile order of the 2-D statistics kernel: 0 an eighth of the batch per XCD, 1 plain, 2 an eighth of each sample per XCD.
 struct Tune { int sw = 4, nta = 1, gmax = 4194304, rows = 0, tile = 1, tilekb = 52, ppt = 2;
               int jfnk = 0, jfpf = 1, jgnk = 0, jgpf = 1, blk = 1, jzs = 0, xcd = 1, ctile = 1, pskip = 1, joh = -1;
-              int lat2 = -1, xst = 0, jsamp = 1, tilemax = kTileMaxRowBytes, j16 = 7, j16pf = 1, j16nt = 4, tile2d = 2, latlin = 1, pskipb = 8192, pskipmin = 128, jfsum = 1, jsplit = 1, jnocb = 1; };
+              int lat2 = -1, xst = 0, jsamp = 1, tilemax = kTileMaxRowBytes, j16 = 7, j16pf = 1, j16nt = 4, tile2d = 2, latlin = 1, pskipb = 8192, pskipmin = 128, jfsum = 1, jsplit = 1, jnocb = 1, t2ord = 2; };
 #ifdef RNNT_DEV
 static Tune read_tune() {
     Tune t;
@@ -224,7 +225,7 @@ static Tune read_tune() {
         {"tilekb", &t.tilekb}, {"ppt", &t.ppt}, {"jfnk", &t.jfnk}, {"jfpf", &t.jfpf}, {"jgnk", &t.jgnk},
         {"jgpf", &t.jgpf}, {"blk", &t.blk}, {"jzs", &t.jzs}, {"xcd", &t.xcd}, {"ctile", &t.ctile},
         {"pskip", &t.pskip}, {"joh", &t.joh}, {"lat2", &t.lat2}, {"xst", &t.xst}, {"jsamp", &t.jsamp}, {"tilemax", &t.tilemax},
-        {"j16", &t.j16}, {"j16pf", &t.j16pf}, {"j16nt", &t.j16nt}, {"tile2d", &t.tile2d}, {"latlin", &t.latlin}, {"pskipb", &t.pskipb}, {"pskipmin", &t.pskipmin}, {"jfsum", &t.jfsum}, {"jsplit", &t.jsplit}, {"jnocb", &t.jnocb}};
+        {"j16", &t.j16}, {"j16pf", &t.j16pf}, {"j16nt", &t.j16nt}, {"tile2d", &t.tile2d}, {"latlin", &t.latlin}, {"pskipb", &t.pskipb}, {"pskipmin", &t.pskipmin}, {"jfsum", &t.jfsum}, {"jsplit", &t.jsplit}, {"jnocb", &t.jnocb}, {"t2ord", &t.t2ord}};
     // tokens are separated by ',', a token is key=value with the WHOLE key compared
     for (const char* p = e; *p;) {
         const char* end = strchr(p, ',');

@@ -659,7 +659,8 @@ __global__ __launch_bounds__(256) void row_stats_tile2d_kernel(
         const typename Tag::store* __restrict__ acts, const int* __restrict__ labels,
         const int* __restrict__ xlen, const int* __restrict__ ylen,
         LogPair<typename Tag::comp>* __restrict__ lp2, typename Tag::comp* __restrict__ logz,
-        int maxT, int maxU, int Up, int A, int blank, int N, int tilesT, int tilesU, int piece_bytes, int* __restrict__ poison) {
+        int maxT, int maxU, int Up, int A, int blank, int N, int tilesT, int tilesU, int piece_bytes, int* __restrict__ poison,
+        int order) {                 // tile order, see below
     using S = typename Tag::store;
     using C = typename Tag::comp;
     static_assert(TT * TU == 256, "one lane per row");
@@ -669,9 +670,23 @@ __global__ __launch_bounds__(256) void row_stats_tile2d_kernel(
     // (the results overlay the tile once every lane has finished reading it: 3 KB less LDS, three blocks per CU at c4's size)
     LogPair<C> (*out_lp)[TU + 1] = reinterpret_cast<LogPair<C> (*)[TU + 1]>(tile2_raw);
     C (*out_lz)[TU + 1] = reinterpret_cast<C (*)[TU + 1]>(reinterpret_cast<char*>(tile2_raw) + sizeof(LogPair<C>) * TT * (TU + 1));
+    // Tile order (workgroup i runs on XCD i % 8): 0 = every XCD owns one contiguous eighth of the BATCH's tiles (eight windows,
+    // hundreds of MB apart); 1 = plain (the eight XCDs share one moving window); 2 = every XCD owns one contiguous eighth of
+    // each SAMPLE's tiles (grid = N * 8 * ceil(tiles per sample / 8)).
     const unsigned ntile = static_cast<unsigned>(N) * tilesT * tilesU;
-    const unsigned per = (ntile + 7u) >> 3;
-    const unsigned tile_id = (blockIdx.x & 7u) * per + (blockIdx.x >> 3);
+    unsigned tile_id;
+    if (order == 1) {
+        tile_id = blockIdx.x;
+    } else if (order == 2) {
+        const unsigned pts = static_cast<unsigned>(tilesT) * tilesU, per2 = (pts + 7u) >> 3;
+        const unsigned bs = blockIdx.x / (8u * per2), r = blockIdx.x - bs * 8u * per2;
+        const unsigned within = (r & 7u) * per2 + (r >> 3);
+        if (within >= pts) return;
+        tile_id = bs * pts + within;
+    } else {
+        const unsigned per = (ntile + 7u) >> 3;
+        tile_id = (blockIdx.x & 7u) * per + (blockIdx.x >> 3);
+    }
     if (tile_id >= ntile) return;                              // grid is rounded up to a multiple of 8
     const int tu = static_cast<int>(tile_id % tilesU), tt = static_cast<int>((tile_id / tilesU) % tilesT);
     const int b = static_cast<int>(tile_id / (static_cast<unsigned>(tilesU) * tilesT));

@@ -1,7 +1,9 @@
 """warprnnt_tensorflow -- the reference's TensorFlow API (tensorflow_binding/warprnnt_tensorflow/__init__.py:9-47)
 over this library: ``rnnt_loss(acts, labels, input_lengths, label_lengths, blank_label=0)`` with the gradient
-registered for the "WarpRNNT" op.  Needs tensorflow-rocm and kernels.so built by ../build.sh; GPU only (the op has
-no CPU kernel: the GPU location of the library never falls back to the host)."""
+registered for the "WarpRNNT" op.  Needs tensorflow-rocm and kernels.so built by ../build.sh.  Device placement decides the
+contract, as in the reference (tensorflow_binding/tests/test_warprnnt_op.py:20): on the GPU `acts` are raw logits and the gradient
+is the dense d/d(logits); the CPU kernel takes LOG-PROBABILITIES (apply tf.nn.log_softmax first, the chain rule then gives the same
+dense gradient) -- the GPU location of the library itself never falls back to the host."""
 import os
 
 import tensorflow as tf

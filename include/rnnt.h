@@ -276,6 +276,24 @@ rnntStatus_t compute_rnnt_loss_likelihoods(const void* workspace,
                                            double* ll_forward_host,
                                            double* ll_backward_host);
 
+/* Debug aid -- the counterpart of the reference's -DDEBUG_KERNEL dumps of the alpha / beta tables
+ * (include/detail/gpu_rnnt.h:136-156,175-191; CPU: include/detail/cpu_rnnt.h:197-207,238-248), as a call instead of a build
+ * flag.  Writes the forward and backward variables of ONE sample of a workspace that a gradient-computing materialised-path call
+ * (same maxT / maxU / minibatch / dtype_code) has filled into two DEVICE arrays of maxT * maxU doubles each: natural (t, u) order,
+ * natural logs, alpha(t,u) = log P(y_1..u emitted by time t), beta(t,u) as in include/detail/gpu_rnnt_kernel.h:79-113
+ * (beta(0,0) = log P(y|x)); cells outside the sample's T_b x U_b lattice are NaN.  The workspace's private layout (diagonal-skewed,
+ * base-2, re-centred per chunk with fp64 offsets) is undone here so that no caller has to know it.  input_lengths /
+ * label_lengths: the device arrays of the call.  Enqueue only (one small kernel on options.stream), nothing allocated. */
+rnntStatus_t compute_rnnt_loss_lattice_dump(const void* workspace,
+                                            const int* const label_lengths,
+                                            const int* const input_lengths,
+                                            int minibatch,
+                                            int sample,
+                                            rnntOptions options,
+                                            int dtype_code,
+                                            double* alpha_device,
+                                            double* beta_device);
+
 /* FastEmit regularisation (Yu et al., "FastEmit", ICASSP 2021, in the form NVIDIA
  * NeMo's RNN-T loss uses): the gradient of every LABEL transition's log-probability is scaled by
  * (1 + fastemit_lambda), which pushes the model to emit earlier; the returned costs are the plain

@@ -798,6 +798,32 @@ rnntStatus_t compute_rnnt_loss_likelihoods(const void* workspace, int minibatch,
     return RNNT_STATUS_SUCCESS;
 }
 
+rnntStatus_t compute_rnnt_loss_lattice_dump(const void* workspace, const int* const label_lengths, const int* const input_lengths,
+                                            int minibatch, int sample, rnntOptions options, int dtype_code, double* alpha_device,
+                                            double* beta_device) {
+    if (workspace == nullptr || label_lengths == nullptr || input_lengths == nullptr || alpha_device == nullptr || beta_device == nullptr ||
+        minibatch <= 0 || sample < 0 || sample >= minibatch || options.maxT <= 0 || options.maxU <= 0 || loc_of(options) != RNNT_GPU ||
+        dtype_code < 0 || dtype_code > 3)
+        return RNNT_STATUS_INVALID_VALUE;
+    const int A = options.blank_label >= 0 ? options.blank_label + 1 : 1;           // (the plan only checks the blank against it)
+    const unsigned cells = static_cast<unsigned>(options.maxT) * static_cast<unsigned>(options.maxU);
+    const dim3 grid((cells + 255) / 256);
+    if (dtype_code == 1) {
+        Plan<double> p;
+        if (!make_plan(p, A, minibatch, options, const_cast<void*>(workspace), nullptr, label_lengths, input_lengths, static_cast<double*>(nullptr)))
+            return RNNT_STATUS_INVALID_VALUE;
+        hipLaunchKernelGGL((lattice_dump_kernel<double>), grid, dim3(256), 0, p.stream, p.alpha, p.beta, p.offa, p.offb, input_lengths,
+                           label_lengths, sample, p.maxT, p.maxU, p.Up, p.lat_w, p.lat_sh, alpha_device, beta_device);
+    } else {
+        Plan<float> p;
+        if (!make_plan(p, A, minibatch, options, const_cast<void*>(workspace), nullptr, label_lengths, input_lengths, static_cast<float*>(nullptr)))
+            return RNNT_STATUS_INVALID_VALUE;
+        hipLaunchKernelGGL((lattice_dump_kernel<float>), grid, dim3(256), 0, p.stream, p.alpha, p.beta, p.offa, p.offb, input_lengths,
+                           label_lengths, sample, p.maxT, p.maxU, p.Up, p.lat_w, p.lat_sh, alpha_device, beta_device);
+    }
+    return hipGetLastError() == hipSuccess ? RNNT_STATUS_SUCCESS : RNNT_STATUS_EXECUTION_FAILED;
+}
+
 rnntStatus_t compute_rnnt_loss_fastemit(const void* activations, void* gradients, const int* const flat_labels,
                                         const int* const label_lengths, const int* const input_lengths,
                                         int alphabet_size, int minibatch, void* costs_device,

@@ -1770,6 +1770,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void c
 }
 
 // ------------------------------------------------------------------------------------------
+// Debug aid (compute_rnnt_loss_lattice_dump): one sample's alpha / beta out of the skewed, base-2, re-centred workspace
+// arrays into natural (t, u) order and natural logs; the same reconstruction the coefficient kernels do (coef_fetch).
+template <typename L>
+__global__ __launch_bounds__(256) void lattice_dump_kernel(
+        const L* __restrict__ alpha, const L* __restrict__ beta, const double* __restrict__ offa, const double* __restrict__ offb,
+        const int* __restrict__ xlen, const int* __restrict__ ylen, int b, int maxT, int maxU, int Up, int lw, int lsh,
+        double* __restrict__ a_out, double* __restrict__ b_out) {
+    const int cell = blockIdx.x * 256 + threadIdx.x;
+    if (cell >= maxT * maxU) return;
+    const int t = cell / maxU, u = cell - t * maxU, n = t + u;
+    int Tb, Ub;
+    coef_lens(xlen, ylen, b, maxT, maxU, Tb, Ub);
+    if (t >= Tb || u >= Ub) { a_out[cell] = __builtin_nan(""); b_out[cell] = __builtin_nan(""); return; }
+    const size_t Dp = lat_rows(maxT, maxU);
+    const size_t idx = lat_index(b, n, u, maxT, maxU, Up);
+    const size_t o = (static_cast<size_t>(b) * lw + (u >> lsh)) * Dp + kLatPad + n;
+    a_out[cell] = (static_cast<double>(alpha[idx]) + offa[o]) * kLn2;
+    b_out[cell] = (static_cast<double>(beta[idx]) + offb[o]) * kLn2;
+}
+
+// ------------------------------------------------------------------------------------------
 // [summed loss, sample count] of a shard in fp64 -- the 16-byte payload of the batch-sharded step's one collective
 // (compute_rnnt_loss_sharded).  One block of 256 threads; a marker NaN of an invalid sample propagates into the sum.
 template <typename C>

@@ -45,6 +45,7 @@ EXPORTS = {
                                         C.c_int, C.c_int]),
     "compute_rnnt_loss_bwd": (C.c_int, [_PTR, _PTR, _PTR, C.c_int, C.c_int, _PTR, rnntOptions, C.c_int]),
     "compute_rnnt_loss_likelihoods": (C.c_int, [_PTR, C.c_int, rnntOptions, C.c_int, _PTR, _PTR]),
+    "compute_rnnt_loss_lattice_dump": (C.c_int, [_PTR, _PTR, _PTR, C.c_int, C.c_int, rnntOptions, C.c_int, _PTR, _PTR]),
     "compute_rnnt_loss_fastemit": (C.c_int, [_PTR, _PTR, _PTR, _PTR, _PTR, C.c_int, C.c_int, _PTR,
                                              _PTR, _PTR, rnntOptions, C.c_int, C.c_float]),
     "compute_rnnt_loss_fwd_fastemit": (C.c_int, [_PTR, _PTR, _PTR, _PTR, C.c_int, C.c_int, _PTR, _PTR, rnntOptions,

@@ -110,6 +110,34 @@ def cpu_model():
     return platform.processor() or platform.machine() or "unknown"
 
 
+def cpu_topology():
+    """Logical CPUs, physical cores and threads per core of the host, and how the baseline's OpenMP threads are placed
+    (`cores: 128` next to a 256-CPU host must say which 128)."""
+    logical = os.cpu_count() or 1
+    cores = set()
+    try:
+        phys = core = None
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("physical id"):
+                phys = line.split(":")[1].strip()
+            elif line.startswith("core id"):
+                core = line.split(":")[1].strip()
+            elif not line.strip() and phys is not None and core is not None:
+                cores.add((phys, core)); phys = core = None
+    except OSError:
+        pass
+    physical = len(cores) or logical
+    try:
+        allowed = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        allowed = logical
+    return {"logical_cpus": logical, "physical_cores": physical, "threads_per_core": max(1, logical // max(physical, 1)),
+            "cpus_this_process_may_use": allowed,
+            "omp_places": os.environ.get("OMP_PLACES", "(unset)"), "omp_proc_bind": os.environ.get("OMP_PROC_BIND", "(unset)"),
+            "placement": "not pinned: the OpenMP runtime's threads float, the kernel scheduler spreads them over idle cores first "
+                         "(with fewer threads than physical cores no SMT sibling has to be shared)"}
+
+
 def cpu_baseline(w, acts, labels, act_lens, label_lens, budget_samples):
     """The REFERENCE's own CPU path (oracle/_ref, compiled from /root/reference) on the host
     cores of this box, on a bounded sample of the same workload (last row).  Three legs:
@@ -165,7 +193,9 @@ def cpu_baseline(w, acts, labels, act_lens, label_lens, budget_samples):
         return xx.grad
     ms_full = timed(full, reps=2) * (N / n2)
     shape = "T=%d,U=%d,A=%d" % (w["T"], w["L"] + 1, w["A"])
-    return dict(value=round(ms_all, 3), unit="ms/batch", cores=threads, cpu_model=cpu_model(), kind=kind,
+    return dict(value=round(ms_all, 3), unit="ms/batch", cores=threads, cpu_model=cpu_model(), kind=kind, host=cpu_topology(),
+                threads_note="one OpenMP thread per sample -- the reference parallelises over the batch only (cpu_rnnt.h:290), so a batch "
+                             "of %d samples can occupy at most %d threads whatever the host has" % (n, n),
                 sample="%d of %d samples (%s, fp32 log-probs in, sparse log-prob grads out), "
                        "median of 3 warmed calls, scaled x%.2f to the full batch; host has %d cores"
                        % (n, N, shape, N / n, cores),

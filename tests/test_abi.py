@@ -151,3 +151,45 @@ def test_round3_extension_entries_without_a_gpu():
     assert lib.compute_rnnt_loss_sharded(*args, None, None, p, gpu, 0) == 2
     assert lib.compute_rnnt_loss_sharded(*args, p, None, p, cpu, 0) == 2
     assert lib.compute_rnnt_loss_sharded(None, None, i.ctypes.data, i.ctypes.data, i.ctypes.data, 3, 1, p, None, p, None, p, gpu, 0) == 2
+
+
+def test_workspace_size_is_monotone_in_every_argument():
+    """get_workspace_size / get_workspace_size_add never shrink when a dimension, the batch or the element size grows (callers that
+    cache a workspace for "the largest shape so far" rely on it), for both locations; the GPU formula is private but
+    at least the reference's (3 T U + 2) N s (src/rnnt_entrypoint.cpp:96-128), so a buffer sized for this library also serves it."""
+    from warprnnt_pytorch import _lib
+    lib = _lib.lib()
+    import ctypes as C
+
+    def size(T, U, N, gpu, esz):
+        return _lib.workspace_bytes(T, U, N, gpu, esz)
+
+    def size_add(T, U, N):
+        n = C.c_size_t()
+        assert lib.get_workspace_size_add(T, U, N, C.byref(n)) == 0
+        return n.value
+
+    Ts, Us, Ns = [1, 2, 7, 16, 33, 150, 151, 1500], [1, 2, 8, 9, 21, 41, 64, 65, 301, 1024], [1, 2, 3, 16, 64, 128, 1024]
+    for gpu in (True, False):
+        for esz in (2, 4, 8):
+            for U in Us:
+                for N in (1, 16):
+                    vals = [size(T, U, N, gpu, esz) for T in Ts]
+                    assert vals == sorted(vals), ("T", gpu, esz, U, N, vals)
+            for T in (1, 33, 150):
+                for N in (1, 16):
+                    vals = [size(T, U, N, gpu, esz) for U in Us]
+                    assert vals == sorted(vals), ("U", gpu, esz, T, N, vals)
+                for U in (1, 21, 65):
+                    vals = [size(T, U, N, gpu, esz) for N in Ns]
+                    assert vals == sorted(vals), ("N", gpu, esz, T, U, vals)
+        for T, U, N in ((150, 21, 128), (1500, 301, 64), (7, 3, 2)):
+            by_esz = [size(T, U, N, gpu, e) for e in (2, 4, 8)]
+            assert by_esz == sorted(by_esz)
+            if gpu:
+                assert size(T, U, N, True, 4) >= (3 * T * U + 2) * N * 4
+                assert size_add(T, U, N) >= size(T, U, N, True, 4)            # a workspace of the additive-joint size serves every GPU entry
+    vals = [size_add(T, 21, 16) for T in Ts]
+    assert vals == sorted(vals)
+    vals = [size_add(150, U, 16) for U in Us]
+    assert vals == sorted(vals)

@@ -153,6 +153,8 @@ def test_bench_two_ranks_on_one_gpu():
     assert m["one_gpu_full_batch_ms"] > 0 and m["speedup"] > 0 and abs(m["strong_scaling_efficiency"] - m["speedup"] / 2) < 1e-3
     assert abs(max(m["per_rank_ms"]) - line["value"]) <= 1e-3 * line["value"]
     assert line["check"]["passed"], line["check"]
+    # the one-GPU base of the strong scaling under the SAME key the one-GPU line uses (tests/test_bench_cli.py)
+    assert line["other_workloads"]["c5_full_1024_on_one_gpu"]["ms_per_step"] == m["one_gpu_full_batch_ms"]
     # the weak form is still there
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--oversubscribe-gloo", "--per-gpu-batch", "16",
                           "--steps", "2", "--warmup", "1", "--no-verify"], capture_output=True, text=True, timeout=900)

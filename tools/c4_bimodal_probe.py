@@ -149,7 +149,7 @@ def matrix():
         wss.append(torch.empty(wsb, dtype=torch.uint8, device=dev))
     grads = torch.empty(E, device=dev)
     live = bool(os.environ.get("RNNT_TUNE_LIVE"))
-    variants = ["t2ord=0", "t2ord=1", "t2ord=2"] if live else [""]
+    variants = (os.environ.get("VARIANTS", "t2ord=0;t2ord=1;t2ord=2").split(";")) if live else [""]
     for rnd in range(2):
         for ia, a in enumerate(acts):
             for iw, w in enumerate(wss):

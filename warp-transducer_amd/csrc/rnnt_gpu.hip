@@ -59,7 +59,7 @@ static void launch_row_stats(Plan<typename Tag::comp>& p, const typename Tag::st
         if (ntile < (1ull << 30)) {
             const int order = tn.t2ord;
             const unsigned long long pts = static_cast<unsigned long long>(tilesT) * tilesU;
-            const unsigned xgrid = order == 2 ? static_cast<unsigned>(static_cast<unsigned long long>(p.N) * 8 * ((pts + 7) / 8))
+            const unsigned xgrid = (order & 3) == 2 ? static_cast<unsigned>(static_cast<unsigned long long>(p.N) * 8 * ((pts + 7) / 8))
                                               : static_cast<unsigned>((ntile + 7) / 8 * 8);
             // (the 256 results overlay the tile: TT rows of TU + 1 {pair, log Z} records of the lattice type)
             const size_t lds2 = static_cast<size_t>(TT) * piece > 8192 ? static_cast<size_t>(TT) * piece : 8192;

@@ -675,9 +675,9 @@ __global__ __launch_bounds__(256) void row_stats_tile2d_kernel(
     // each SAMPLE's tiles (grid = N * 8 * ceil(tiles per sample / 8)).
     const unsigned ntile = static_cast<unsigned>(N) * tilesT * tilesU;
     unsigned tile_id;
-    if (order == 1) {
+    if ((order & 3) == 1) {
         tile_id = blockIdx.x;
-    } else if (order == 2) {
+    } else if ((order & 3) == 2) {
         const unsigned pts = static_cast<unsigned>(tilesT) * tilesU, per2 = (pts + 7u) >> 3;
         const unsigned bs = blockIdx.x / (8u * per2), r = blockIdx.x - bs * 8u * per2;
         const unsigned within = (r & 7u) * per2 + (r >> 3);
@@ -776,8 +776,8 @@ __global__ __launch_bounds__(256) void row_stats_tile2d_kernel(
         const int d = slot / TT, i = slot % TT, j = d - i;
         if (slot < NSLOT && j >= 0 && j < nu && i < nt) {
             const size_t idx = lat_index(b, t0 + u0 + d, u0 + j, maxT, maxU, Up);
-            lp2[idx] = out_lp[i][j];
             const C lz = out_lz[i][j];
+            lp2[idx] = out_lp[i][j];
             logz[idx] = lz;
             note_non_finite(poison, b, t0 + u0 + d, u0 + j, Up, lz);
         }

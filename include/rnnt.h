@@ -209,7 +209,11 @@ rnntStatus_t compute_rnnt_loss_async(const void* activations,
  * ALL RANKS OR NONE: once the arguments every rank shares are accepted (loss_sum_count_device, loc, RCCL available), a
  * rank whose LOCAL part fails (INVALID_VALUE for its shard's shape, a launch error) still joins the collective, with a
  * NaN pair, and then returns its own status: its peers are not left blocked in ncclAllReduce, and every rank's reduced
- * loss is NaN. */
+ * loss is NaN.  NOT covered: a rank on which RCCL cannot be resolved at all (none found, or two copies mapped and none registered) returns
+ * EXECUTION_FAILED BEFORE the collective -- it has no function to call -- so a job in which only SOME ranks are in that state must be stopped
+ * by its launcher; make the ranks alike (rnnt_set_rccl_all_reduce on every rank) and the case cannot arise.
+ * STATUS OF THIS ENTRY: run on one-rank communicators and, with two processes, up to RCCL's refusal of two ranks on one device
+ * (tests/test_gpu_sharded_rccl.py); no box with two GPUs has executed it yet. */
 rnntStatus_t compute_rnnt_loss_sharded(const void* activations,
                                        void* gradients,
                                        const int* const flat_labels,

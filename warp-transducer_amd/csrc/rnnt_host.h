@@ -427,7 +427,7 @@ static inline int loc_of(const rnntOptions& o) {
     return v;
 }
 
-static bool bad_args(const void* acts, const int* labels, const int* label_lengths,
+static inline bool bad_args(const void* acts, const int* labels, const int* label_lengths,
                      const int* input_lengths, const void* costs, const void* workspace, int A, int N,
                      const rnntOptions& o) {
     // reference src/rnnt_entrypoint.cpp:49-59

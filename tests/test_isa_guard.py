@@ -59,6 +59,6 @@ def test_no_kernel_uses_scratch_or_spills_vector_registers(device_asm):
         if name not in guard.NO_LIN:
             assert guard.check(other) == [], name          # their copy of lattice_lin_kernel
     joint = guard.joint_asm
-    assert len(res.kernels(joint)) > 100 and res.check(joint) == []
+    assert len(res.kernels(joint)) > 40 and res.check(joint) == []      # (fp32 storage; bf16 and fp16 have code objects of their own: other_asms)
     assert guard.check(joint) == []                      # the second copy of lattice_lin_kernel (the joint translation unit's)
     assert res.check(joint.replace(".private_segment_fixed_size: 0", ".private_segment_fixed_size: 64", 1)) != []   # the check can fail

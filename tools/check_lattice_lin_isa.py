@@ -21,7 +21,7 @@ import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 # both translation units instantiate the kernel (launch_lattice lives in rnnt_host.h): two code objects, two copies to check
-SRCS = [os.path.join(ROOT, "warp-transducer_amd", "csrc", name) for name in ("rnnt_gpu.hip", "rnnt_joint.hip", "rnnt_gpu_f64.hip", "rnnt_gpu_h16.hip")]
+SRCS = [os.path.join(ROOT, "warp-transducer_amd", "csrc", name) for name in ("rnnt_gpu.hip", "rnnt_joint.hip", "rnnt_gpu_f64.hip", "rnnt_gpu_h16.hip", "rnnt_joint_bf16.hip", "rnnt_joint_fp16.hip")]
 NO_LIN = ("rnnt_gpu_f64.hip",)        # translation units without the linear-domain lattice kernel (it exists for fp32 lattices only)
 PFD, KW = 8, 4                                   # lattice_lin_body: chunks in flight, rows per operand wavefront and chunk
 VMEM = re.compile(r"^(buffer|global|flat|scratch)_(load|store|atomic)")

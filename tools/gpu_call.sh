@@ -6,8 +6,8 @@ set -x
 TAG=${1:-rXX}
 cd "${GRAFT_REPO_ROOT:-.}"
 mkdir -p gpurun_out
-( timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -15 ) > gpurun_out/pytest_gpu.log
-python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/smoke.log 2>&1
+( timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -15 ) > gpurun_out/${TAG}_pytest_gpu.log
+python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/${TAG}_smoke.log 2>&1
 python bench.py > gpurun_out/${TAG}_bench_default.json 2> gpurun_out/${TAG}_bench_default.err
 timeout 1500 tools/gpu_profile.sh "$TAG" "c3 c4 c5 c2" pmc > gpurun_out/profile.log 2>&1
 # additive joint: fp32 / bf16 / fp16 storage, kernel traces of the c3 shape; RNNTLoss through autograd
@@ -22,3 +22,9 @@ python bench.py --workload c2 --pinned-costs --no-cpu-baseline --no-traffic-pass
 python bench.py --workload c4 --aux-stream --steps 50 --no-cpu-baseline --no-traffic-pass > gpurun_out/${TAG}_bench_c4_aux_stream.json 2> /dev/null
 python bench.py --gpus 2 --oversubscribe-gloo --steps 5 --warmup 2 > gpurun_out/${TAG}_bench_2ranks_oversubscribed.json 2> /dev/null
 ( cd /tmp && bash $OLDPWD/tools/joint_c4_profile.sh $TAG > /dev/null 2>&1 )
+# round 5: a roofline per kernel of the additive joint, the first call of a process per storage type, the c4 placement matrix
+( cd /tmp && for s in "c3" "--bf16 c3" "c4"; do n=$(echo $s | tr -d " -"); timeout 400 python $OLDPWD/tools/add_network_roofline.py $s > $OLDPWD/gpurun_out/${TAG}_add_roofline_$n.md 2>/dev/null; done )
+( python tools/first_call.py x; python tools/first_call.py; python tools/first_call.py add; python tools/first_call.py add16 ) 2>&1 | grep -v amdgpu.ids > gpurun_out/${TAG}_first_call.log
+timeout 300 python tools/c4_bimodal_probe.py matrix 2> /dev/null > gpurun_out/${TAG}_c4_placement_matrix.jsonl
+timeout 300 python tools/materialised_fuzz.py 200 7 2>&1 | tail -1 > gpurun_out/${TAG}_materialised_fuzz.log
+python tools/readme_table.py > gpurun_out/${TAG}_readme_table.md 2> gpurun_out/${TAG}_readme_table.err

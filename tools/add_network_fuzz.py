@@ -36,8 +36,11 @@ for case in range(cases):
         f[..., blank] = torch.nan_to_num(f[..., blank], neginf=0.0)     # the blank stays possible
         g[..., blank] = torch.nan_to_num(g[..., blank], neginf=0.0)
     labels = rng.integers(0, A, size=(N, max(U - 1, 0)))
-    if A > 1:
-        labels[labels == blank] = (blank + 1) % A
+    # labels EQUAL to the blank stay in (round 5: both corrections then fall on the blank column, gpu_rnnt_kernel.h:161-174; the fp64
+    # materialised path this sweep compares with is pinned against autograd for that case: tests/test_gpu_label_equals_blank.py);
+    # a third of the cases get many of them on purpose
+    if rng.random() < 0.33:
+        labels[rng.random(labels.shape) < 0.4] = blank
     tl = rng.integers(1, T + 1, size=N); tl[rng.integers(0, N)] = T
     ll = rng.integers(0, U, size=N); ll[rng.integers(0, N)] = U - 1
     lab, ttl, tll = (torch.tensor(a.astype(np.int32), device=dev) for a in (labels, tl, ll))

@@ -940,6 +940,17 @@ def main():
                    "vs_published_1080ti": (round(ems / ew["published_ms"], 5) if ew["published_ms"] else None),
                    "check": dict({"loss_sum": e["loss_sum"]}, **(e.get("verify") or {})),
                    "wall_s": round(time.perf_counter() - t_e, 2)}
+            # HBM traffic of its gradient kernel: the committed rocprofv3 --pmc passes of the newest profile set (the headline's is
+            # measured for THIS run; running two more profiler passes per extra workload would triple the line's wall clock)
+            try:
+                import glob
+                tfile = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))[-1]
+                tb = json.load(open(tfile))[name]["grad_flat_kernel"]["traffic_bytes"]
+                if rec["roofline"] is not None:
+                    rec["roofline"]["traffic"] = tb
+                    rec["roofline"]["traffic_source"] = "profiles/%s (committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes; not measured in this run)" % os.path.basename(tfile)
+            except (OSError, KeyError, ValueError, IndexError):
+                pass
             extra[key] = rec
         for key in ADD_WORKLOADS:
             t_e = time.perf_counter()

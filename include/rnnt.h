@@ -508,7 +508,11 @@ rnntStatus_t compute_rnnt_loss_add_bwd_dt(const void* trans_acts,
  * path, the streaming kernels slow by 0.1 ms beside it -- but the forward half of a two-phase pair gets SLOWER (its second lattice
  * has only the first half's coefficient kernel to hide behind): opt-in, for the one-call entries.  Applies to calls from the
  * thread that set it, for lattices of 768 anti-diagonals and more and batches of two samples and more; NULL (the default)
- * switches it off.  The stream must belong to the device of the call and must outlive the calls that use it. */
+ * switches it off.  The stream must belong to the device of the call and must outlive the calls that use it.  A thread that moves to
+ * another GPU hands over a stream of THAT device: the four fork / join events are the calling thread's, made on the device of the call,
+ * destroyed and made again when the stream is replaced or the device changes (NULL releases them); if they cannot be made or recorded, the
+ * call runs the one-stream schedule.  The split falls on a 16-byte boundary of the tensors, and kernel forms that depend on the batch
+ * size are chosen for the WHOLE batch, so the bits are the one-stream schedule's for any N (tests/test_gpu_parity_large.py). */
 void rnnt_set_aux_stream(CUstream stream);
 
 /* Revision of the extension entry points below (the reference's get_warprnnt_version() stays 1).

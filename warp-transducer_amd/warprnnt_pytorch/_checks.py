@@ -54,12 +54,12 @@ def certify_inputs(log_probs, labels, lengths, label_lengths, read_lengths=True)
         raise ValueError("Output length mismatch")
 
 
-def check_gpu_arguments(acts, labels, lengths, label_lengths, workspace=None, workspace_bytes=None):
+def check_gpu_arguments(acts, labels=None, lengths=None, label_lengths=None, workspace=None, workspace_bytes=None):
     """The GPU location dereferences labels and both length vectors on the device of the activations: a host tensor (or one
     of another GPU) there would be a GPU fault, not an exception.  A caller-owned workspace must live on that device too
     and hold at least what get_workspace_size asks for TODAY (the layout is private and has grown between versions)."""
     for name, t in (("labels", labels), ("lengths", lengths), ("label_lengths", label_lengths)):
-        if name == "labels" and t.numel() == 0:
+        if t is None or (name == "labels" and t.numel() == 0):
             continue
         if not t.is_cuda or t.device != acts.device:
             raise ValueError("%s must be on the device of the activations (%s), got %s" % (name, acts.device, t.device))

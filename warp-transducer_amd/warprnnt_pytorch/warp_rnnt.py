@@ -249,7 +249,7 @@ def gpu_rnnt_bwd(acts, grads, grad_scale, workspace, blank_label):
     lib = _lib.lib()
     N, T, U, A = acts.shape
     code, esz = _DT[acts.dtype]
-    check_gpu_arguments(acts, acts, acts, acts, workspace, _workspace_bytes_cached(T, U, N, esz))     # (only the workspace is an argument here)
+    check_gpu_arguments(acts, workspace=workspace, workspace_bytes=_workspace_bytes_cached(T, U, N, esz))
     index = acts.device.index
     with _on_device(index):
         stream = _raw_stream(index)

@@ -924,7 +924,12 @@ def main():
         esteps, ewarm = max(5, min(args.steps, 20)), max(2, min(args.warmup, 5))
         for key, name in OTHER_WORKLOADS.items():
             t_e = time.perf_counter()
-            e = run_workload(name, esteps, ewarm, with_cpu=False)
+            try:
+                e = run_workload(name, esteps, ewarm, with_cpu=False)
+            except Exception as exc:                                   # noqa: BLE001 -- an extra workload must never cost the headline its line
+                extra[key] = {"error": repr(exc)[:400], "check": {"passed": False}}
+                torch.cuda.empty_cache()
+                continue
             eb, ew, ems = e["bytes"], e["w"], e["ms_per_step"]
             sm = e["stage_ms"]
             rec = {"workload": "%s: N=%d T=%d U=%d(L=%d) A=%d %s, loss+grad via compute_rnnt_loss%s"
@@ -954,7 +959,12 @@ def main():
             extra[key] = rec
         for key in ADD_WORKLOADS:
             t_e = time.perf_counter()
-            rec = run_add_workload(lib, dev, key, esteps, ewarm, verify=not args.no_verify)
+            try:
+                rec = run_add_workload(lib, dev, key, esteps, ewarm, verify=not args.no_verify)
+            except Exception as exc:                                   # noqa: BLE001
+                extra[key] = {"error": repr(exc)[:400], "check": {"passed": False}}
+                torch.cuda.empty_cache()
+                continue
             rec["wall_s"] = round(time.perf_counter() - t_e, 2)
             extra[key] = rec
         out["other_workloads"] = extra

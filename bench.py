@@ -324,20 +324,29 @@ def native_communicator(world, rank, dev, timeout_s=120.0):
 def verify_batch(w, acts, labels, act_lens, label_lens, grads, costs):
     """Parity evidence for THIS run, outside the timed region: the first and the last sample of the timed batch (the
     gradients and costs the last timed step left behind) against the fp64 oracle on the same -- storage-rounded --
-    inputs.  Tolerances are north_star's: loss 1e-4 relative, gradients 1e-3 absolute (bf16 storage: 4e-3, its quantum)."""
+    inputs.  Loss: north_star's 1e-4, relative.  Gradients: north_star's 1e-3 absolute (bf16 storage: 4e-3) is kept, but at
+    A = 5000 / 1024 it exceeds every non-blank / non-label entry, so the deciding bound is per element (oracle.grad_bound):
+    |got - ref| <= q |ref| + r mag + a, q = one rounding of the stored value (2^-8 bf16, 0 fp32), r mag = the fp32 arithmetic
+    ahead of it relative to the terms of the element (1e-3 fp32, 2^-13 bf16), a = 1e-5 / 2e-6.  `max_err_over_quantum` is
+    the largest error / bound (<= 1 passes), `max_rel_grad_err` the largest error / terms."""
     from oracle import oracle as O
     N = acts.shape[0]
     pick = sorted({0, N - 1})
     xs = acts[pick].double().cpu().numpy()
     O.lib().oracle_set_num_threads(min(len(pick), os.cpu_count() or 1))
-    ref_c, ref_g = O.rnnt_logits(xs, labels[pick].cpu().numpy(), act_lens[pick].cpu().numpy(), label_lens[pick].cpu().numpy())
+    ref_c, ref_g, mag = O.rnnt_logits(xs, labels[pick].cpu().numpy(), act_lens[pick].cpu().numpy(), label_lens[pick].cpu().numpy(),
+                                      want_mag=True)
     got_c = costs[pick].double().cpu().numpy()
     got_g = grads[pick].double().cpu().numpy()
     rel = float((np.abs(got_c - ref_c) / np.maximum(1.0, np.abs(ref_c))).max())
-    gerr = float(np.abs(got_g - ref_g).max())
     tol_g = 1e-3 if w["dtype"] == "fp32" else 4e-3
-    return {"samples_checked": pick, "max_rel_loss_err": rel, "max_abs_grad_err": gerr,
-            "tolerance": {"loss_rel": 1e-4, "grad_abs": tol_g}, "passed": bool(rel <= 1e-4 and gerr <= tol_g),
+    chk = O.grad_check(got_g, ref_g, mag, w["dtype"])
+    return {"samples_checked": pick, "max_rel_loss_err": rel, "max_abs_grad_err": chk["max_abs_grad_err"],
+            "max_rel_grad_err": chk["max_rel_grad_err"], "max_err_over_quantum": chk["max_err_over_quantum"],
+            "tolerance": {"loss_rel": 1e-4, "grad_abs": tol_g,
+                          "grad_per_element": "|got-ref| <= %.3g*|ref| + %.3g*terms + %.0e (oracle.grad_bound)"
+                                              % (O.QUANTUM[w["dtype"]], O._REL[w["dtype"]], O._ABS[w["dtype"]])},
+            "passed": bool(rel <= 1e-4 and chk["max_abs_grad_err"] <= tol_g and chk["passed"]),
             "against": "oracle/ (fp64 restatement of the reference CPU path) on the same inputs, outside the timed region"}
 
 
@@ -414,10 +423,11 @@ def run_add_workload(lib, dev, name, steps, warmup, verify=True):
         pick = sorted({0, N - 1})
         fr, gr = f[pick].double().cpu().numpy(), g[pick].double().cpu().numpy()
         O.lib().oracle_set_num_threads(min(len(pick), os.cpu_count() or 1))
-        ref_c, ref_gz = O.rnnt_logits(fr[:, :, None, :] + gr[:, None, :, :], labels[pick].cpu().numpy(), tl[pick].cpu().numpy(),
-                                      ll[pick].cpu().numpy())
+        ref_c, ref_gz, mag = O.rnnt_logits(fr[:, :, None, :] + gr[:, None, :, :], labels[pick].cpu().numpy(), tl[pick].cpu().numpy(),
+                                           ll[pick].cpu().numpy(), want_mag=True)
         rdf, rdg = ref_gz.sum(axis=2), ref_gz.sum(axis=1)
-        del ref_gz
+        mdf, mdg = mag.sum(axis=2), mag.sum(axis=1)                  # the terms a summed element is made of
+        del ref_gz, mag
         rel = float((np.abs(costs[pick].double().cpu().numpy() - ref_c) / np.maximum(1.0, np.abs(ref_c))).max())
         # df sums U per-cell gradients, dg sums T of them: north_star's per-element 1e-3 is kept per SUMMED element
         # relative to the count (tests/test_gpu_add_network.py uses the same form); bf16 storage: + half an ulp of the stored value
@@ -425,11 +435,18 @@ def run_add_workload(lib, dev, name, steps, warmup, verify=True):
         edf = np.abs(df[pick].double().cpu().numpy() - rdf) - ulp * np.abs(rdf)
         edg = np.abs(dg[pick].double().cpu().numpy() - rdg) - ulp * np.abs(rdg)
         tol_df, tol_dg = 2e-4 * max(1.0, U / 32), 2e-4 * max(1.0, T / 32)
+        # the absolute figures above exceed most entries of df / dg at A = 5000; per element, relative to the summed terms
+        # (the contraction runs on the matrix cores from factorised exponentials: 1e-3 of the terms for either storage type)
+        cdf = O.grad_check(df[pick].double().cpu().numpy(), rdf, mdf, dtype, rel=1e-3)
+        cdg = O.grad_check(dg[pick].double().cpu().numpy(), rdg, mdg, dtype, rel=1e-3)
         rec["check"] = {"samples_checked": pick, "max_rel_loss_err": rel, "max_abs_df_err": float(edf.max()), "max_abs_dg_err": float(edg.max()),
+                        "max_abs_grad_err": max(cdf["max_abs_grad_err"], cdg["max_abs_grad_err"]),
+                        "max_rel_grad_err": max(cdf["max_rel_grad_err"], cdg["max_rel_grad_err"]),
+                        "max_err_over_quantum": max(cdf["max_err_over_quantum"], cdg["max_err_over_quantum"]),
                         "tolerance": {"loss_rel": 1e-4, "df_abs": tol_df, "dg_abs": tol_dg,
                                       "note": "absolute, after subtracting %.1e x |reference| (accumulation over U resp. T terms%s)"
                                               % (ulp, "" if dtype == "fp32" else "; bf16 storage quantum")},
-                        "passed": bool(rel <= 1e-4 and edf.max() <= tol_df and edg.max() <= tol_dg),
+                        "passed": bool(rel <= 1e-4 and edf.max() <= tol_df and edg.max() <= tol_dg and cdf["passed"] and cdg["passed"]),
                         "against": "oracle/ (fp64) on the MATERIALISED joint f_t + g_u of these samples, gradients summed over u / t"}
     del f, g, df, dg, ws
     torch.cuda.empty_cache()

@@ -176,6 +176,35 @@ ORACLE_API int oracle_rnnt_logits_##SUFFIX(const real* acts, real* grads, const 
             for (int v = 0; v < A; ++v) g[v] -= EXP(lp[v]) * s;                                      \
     }                                                                                                \
     return 0;                                                                                        \
+}                                                                                                    \
+                                                                                                     \
+/* The same, plus the SIZE OF THE TERMS each dense gradient element is made of:                      \
+ *   mag[v] = |g_lp[v]| + softmax[v] * |sum_v' g_lp[v']|  >=  |g_logit[v]|.                          \
+ * The blank / label entries are differences of two terms (include/detail/gpu_rnnt_kernel.h:159-176: \
+ * exp(logpk + ...) minus the emission term); a rounding error of the arithmetic scales with the     \
+ * terms, not with their difference, so a per-element tolerance relative to the result alone would   \
+ * be unfair exactly there.  Everywhere else mag == |g_logit|.  Used by oracle.grad_check(). */      \
+ORACLE_API int oracle_rnnt_logits_mag_##SUFFIX(const real* acts, real* grads, const int* labels,     \
+        const int* label_lengths, const int* input_lengths, int A, int N, int maxT, int maxU,        \
+        int blank, real* costs, real* scratch, real* mag) {                                          \
+    size_t rows = (size_t)N * maxT * maxU;                                                           \
+    oracle_log_softmax_##SUFFIX(acts, rows, A, scratch);                                             \
+    oracle_rnnt_logprobs_##SUFFIX(scratch, grads, labels, label_lengths, input_lengths, A, N,        \
+                                  maxT, maxU, blank, costs);                                         \
+    _Pragma("omp parallel for schedule(static)")                                                     \
+    for (long long r = 0; r < (long long)rows; ++r) {                                                \
+        real* g = grads + (size_t)r * A;                                                             \
+        real* m = mag + (size_t)r * A;                                                               \
+        const real* lp = scratch + (size_t)r * A;                                                    \
+        real s = 0;                                                                                  \
+        for (int v = 0; v < A; ++v) s += g[v];                                                       \
+        for (int v = 0; v < A; ++v) {                                                                \
+            real soft = (s != 0) ? EXP(lp[v]) * s : 0;                                               \
+            m[v] = FABS(g[v]) + FABS(soft);                                                          \
+            g[v] -= soft;                                                                            \
+        }                                                                                            \
+    }                                                                                                \
+    return 0;                                                                                        \
 }
 
 DEFINE_ORACLE(f32, float, expf, logf, log1pf, fabsf)

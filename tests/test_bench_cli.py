@@ -46,12 +46,15 @@ def test_default_line_carries_every_workload_with_a_passing_check():
     assert len(lines) == 1
     rec = json.loads(lines[0])
     assert rec["config"]["workload"].startswith("c3") and rec["check"]["passed"] and rec["roofline"]["frac"] > 0.5
+    assert rec["check"]["max_err_over_quantum"] <= 1.0 and rec["check"]["max_rel_grad_err"] <= 1e-3
     other = rec["other_workloads"]
     assert set(other) == EXPECTED_OTHER
     for key, e in other.items():
         assert e["ms_per_step"] > 0 and e["step_ms"]["p10"] <= e["step_ms"]["median"] <= e["step_ms"]["p90"], key
         assert e["stage_ms"] and e["path_frac"] > 0, key
         assert e["check"]["passed"], (key, e["check"])
+        # the per-element keys: error / (one rounding of the stored value + fp32 arithmetic) <= 1
+        assert 0 < e["check"]["max_err_over_quantum"] <= 1.0 and e["check"]["max_rel_grad_err"] < 5e-3, (key, e["check"])
         assert ("roofline" in e) or ("mfma_roofline" in e), key
     assert rec["other_workloads_all_checks_passed"]
     assert other["c5_full_1024_on_one_gpu"]["ms_per_step"] > 4 * other["c5_per_gpu"]["ms_per_step"]

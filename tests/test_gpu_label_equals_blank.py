@@ -62,7 +62,9 @@ def c_abi(x, labels, tl, ll, blank):
     return costs.double().numpy(), grads.double().cpu().numpy()
 
 
-TOL = {torch.float32: (1e-4, 1e-4), torch.float64: (1e-10, 1e-9), torch.bfloat16: (1e-4, 4e-3)}
+# (cost relative, gradient absolute, gradient relative to the stored value): bf16 = one rounding of the stored element
+# (2^-8 |ref|) on top of the fp32 figure -- not an absolute 4e-3, which entries of this size never reach
+TOL = {torch.float32: (1e-4, 1e-4, 0.0), torch.float64: (1e-10, 1e-9, 0.0), torch.bfloat16: (1e-4, 1e-4, 2.0 ** -8)}
 
 
 @pytest.mark.parametrize("where", WHERE)
@@ -74,10 +76,10 @@ def test_materialised_padded(shape, dtype, where):
     x = torch.tensor(rng.standard_normal(shape) * 2.0, device="cuda:0").to(dtype).contiguous()
     ref_c, ref_g = rnnt_autograd(x.double().cpu().numpy(), labels, tl, ll, blank)       # on the storage-rounded inputs
     costs, grads = c_abi(x, labels, tl, ll, blank)
-    tol_c, tol_g = TOL[dtype]
+    tol_c, tol_g, tol_q = TOL[dtype]
     assert np.abs(costs - ref_c).max() <= tol_c * max(1.0, np.abs(ref_c).max())
-    err = np.abs(grads - ref_g)
-    assert err.max() <= tol_g, (err.max(), np.unravel_index(err.argmax(), err.shape))
+    err = np.abs(grads - ref_g) / (tol_g + tol_q * np.abs(ref_g))
+    assert err.max() <= 1.0, (err.max(), np.unravel_index(err.argmax(), err.shape))
     # the cells under test carry real mass in the blank column, and the CPU reference's "assignment" answer would fail here
     N = shape[0]
     both = [(b, u) for b in range(N) for u in range(ll[b]) if labels[b, u] == blank]
@@ -123,9 +125,9 @@ def test_materialised_packed(shape, dtype, where):
     loss.backward(torch.tensor(weights, device=dev, dtype=loss.dtype))
     ref_c, ref_g = rnnt_autograd(x.double().cpu().numpy(), labels, tl, ll, blank, weights)
     ref_pk = np.concatenate([ref_g[b, :tl[b], :ll[b] + 1].reshape(-1, shape[3]) for b in range(N)])
-    tol_c, tol_g = TOL[dtype]
+    tol_c, tol_g, tol_q = TOL[dtype]
     assert np.abs(loss.detach().double().cpu().numpy() - ref_c).max() <= tol_c * max(1.0, np.abs(ref_c).max())
-    assert np.abs(p.grad.double().cpu().numpy() - ref_pk).max() <= tol_g * 2.0          # |weights| <= 2
+    assert (np.abs(p.grad.double().cpu().numpy() - ref_pk) <= tol_g * 2.0 + tol_q * np.abs(ref_pk)).all()   # |weights| <= 2
 
 
 # ------------------------------------------------------------------------------------------------ additive joint

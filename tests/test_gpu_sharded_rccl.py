@@ -196,6 +196,7 @@ def test_bench_sharded_step_on_one_rank():
     # every line carries its own parity evidence (two samples of the timed batch against the fp64 oracle)
     for line in lines:
         assert line["check"]["passed"] and line["check"]["max_abs_grad_err"] <= 4e-3, line["check"]
+        assert line["check"]["max_err_over_quantum"] <= 1.0, line["check"]      # per element: one rounding of the stored bf16
 
 
 def test_bench_refuses_more_gpus_than_visible():

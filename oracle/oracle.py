@@ -255,6 +255,32 @@ def ref_rnnt_logprobs(log_probs, labels, act_lens, label_lens, blank=0, want_gra
     return costs, grads
 
 
+class RefCall:
+    """The reference's compute_rnnt_loss (RNNT_CPU) with every buffer it writes -- gradients, workspace, costs --
+    allocated and TOUCHED once here, so that repeated calls measure arithmetic (and the reference's own memset of the
+    gradient slab, include/detail/cpu_rnnt.h:155-158), not first-touch page faults of fresh allocations: the steady-state
+    protocol BASELINE.md 3 promised next to the reference harness's (tests/test_time.cpp:57-60 allocates per iteration)."""
+
+    def __init__(self, log_probs, labels, act_lens, label_lens, blank=0, num_threads=0):
+        lp = np.ascontiguousarray(log_probs)
+        N, T, U, A = lp.shape
+        self.lp, self.N, self.A = lp, N, A
+        self.labels, self.tl, self.ll = _i32(labels), _i32(act_lens), _i32(label_lens)
+        self.costs = np.zeros(N, dtype=lp.dtype)
+        self.grads = np.zeros_like(lp)                                  # zeros: every page touched
+        nbytes = C.c_size_t(0)
+        assert ref().get_workspace_size(T, U, N, False, C.byref(nbytes), lp.dtype.itemsize) == 0
+        self.ws = np.zeros(nbytes.value + 16, dtype=np.uint8)
+        self.opt = rnntOptions(loc=0, num_threads=num_threads, stream=None, blank_label=blank, maxT=T, maxU=U, batch_first=True)
+        self.fn = ref().compute_rnnt_loss if lp.dtype == np.float32 else ref().compute_rnnt_loss_fp64
+
+    def __call__(self):
+        st = self.fn(self.lp.ctypes.data, self.grads.ctypes.data, self.labels.ctypes.data, self.ll.ctypes.data,
+                     self.tl.ctypes.data, self.A, self.N, self.costs.ctypes.data, self.ws.ctypes.data, self.opt)
+        assert st == 0, st
+        return self.costs, self.grads
+
+
 def chain_rule_to_logits(log_probs, g_lp):
     """g_logit = g_lp - softmax * sum_v g_lp  (SURVEY.md 8c)."""
     s = g_lp.sum(axis=-1, keepdims=True)

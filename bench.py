@@ -349,7 +349,7 @@ def native_communicator(world, rank, dev, timeout_s=120.0):
     return state["rccl"], state["comm"]
 
 
-def verify_batch(w, acts, labels, act_lens, label_lens, grads, costs):
+def verify_batch(w, acts, labels, act_lens, label_lens, grads, costs, acts_picked=None):
     """Parity evidence for THIS run, outside the timed region: the first and the last sample of the timed batch (the
     gradients and costs the last timed step left behind) against the fp64 oracle on the same -- storage-rounded --
     inputs.  Loss: north_star's 1e-4, relative.  Gradients: north_star's 1e-3 absolute (bf16 storage: 4e-3) is kept, but at
@@ -360,7 +360,7 @@ def verify_batch(w, acts, labels, act_lens, label_lens, grads, costs):
     from oracle import oracle as O
     N = acts.shape[0]
     pick = sorted({0, N - 1})
-    xs = acts[pick].double().cpu().numpy()
+    xs = (acts[pick] if acts_picked is None else acts_picked).double().cpu().numpy()     # (in-place runs: the logits are gone)
     O.lib().oracle_set_num_threads(min(len(pick), os.cpu_count() or 1))
     ref_c, ref_g, mag = O.rnnt_logits(xs, labels[pick].cpu().numpy(), act_lens[pick].cpu().numpy(), label_lens[pick].cpu().numpy(),
                                       want_mag=True)
@@ -585,6 +585,9 @@ def main():
     ap.add_argument("--aux-stream", action="store_true",
                     help="hand the library a second stream (rnnt_set_aux_stream): long lattices (c4) then run the two-half "
                          "schedule -- the lattice kernel of one half of the batch beside the streaming kernels of the other")
+    ap.add_argument("--in-place", action="store_true",
+                    help="gradients == activations (rnnt.h, IN PLACE): the gradient overwrites the logits; every step restores "
+                         "nothing -- after the first step the 'logits' are gradients, the arithmetic and the traffic are the same")
     ap.add_argument("--force-sharded", action="store_true",
                     help="dev: run the multi-GPU step (async entry + RCCL all-reduce) even with one rank")
     ap.add_argument("--no-full-batch", action="store_true",
@@ -599,7 +602,7 @@ def main():
     if args.gpus < 1:
         ap.error("--gpus must be >= 1")
     plain_line = not (args.override or args.varlen or args.packed or args.graph or args.aux_stream or args.pinned_costs
-                      or args.force_sharded)
+                      or args.force_sharded or args.in_place)
     want_extra = args.gpus == 1 and not args.no_extra and (args.extra or (args.workload is None and plain_line))
     if args.workload is None:
         args.workload = "c3" if args.gpus == 1 else "c5"
@@ -731,7 +734,7 @@ def main():
             del acts_padded
             torch.cuda.empty_cache()
             offs = row_offsets(act_lens, label_lens)
-        grads = torch.empty_like(acts)
+        grads = acts if args.in_place else torch.empty_like(acts)
         esz = ESIZE[w["dtype"]]
         ws = torch.empty(_lib.workspace_bytes(T, U, N, True, esz), dtype=torch.uint8, device=dev)
         stream = torch.cuda.current_stream(dev).cuda_stream
@@ -944,7 +947,17 @@ def main():
                    plain_step_ms=plain, multi=multi,
                    loss_sum=float(out.sum()) if not sharded else float(out[0]))
         if rank == 0 and not args.no_verify and not args.packed:
-            res["verify"] = verify_batch(w, acts, labels, act_lens, label_lens, grads, costs)
+            picked = None
+            if args.in_place:
+                # the timed steps have long turned the logits into gradients of gradients: one more step on fresh logits (same
+                # seed), outside the timed region, is what the check judges
+                fresh = make_inputs(w, dev, 1234 + rank)[0]
+                picked = fresh[sorted({0, N - 1})].clone()
+                acts.copy_(fresh)
+                del fresh
+                step()
+                torch.cuda.synchronize(dev)
+            res["verify"] = verify_batch(w, acts, labels, act_lens, label_lens, grads, costs, picked)
         if with_cpu and rank == 0 and not args.packed:
             res["cpu"] = cpu_baseline(w, acts, labels, act_lens, label_lens, args.cpu_samples)
         if comm is not None:
@@ -969,6 +982,7 @@ def main():
                                   (", VARIABLE lengths T_b~U[T/2,T] L_b~U[L/2,L]" if args.varlen else "")
                                   + (", PACKED layout (compute_rnnt_loss_packed)" if args.packed else "")
                                   + (", host costs in pinned memory" if args.pinned_costs else "")
+                                  + (", IN PLACE (gradients == activations)" if args.in_place else "")
                                   + (", compute_rnnt_loss_async replayed from a HIP graph" if args.graph else "")
                                   + (", second stream handed to the library (rnnt_set_aux_stream: two-half schedule on long lattices)"
                                      if args.aux_stream else "")),

@@ -101,7 +101,14 @@ typedef struct rnntOptions rnntOptions;
  *     `if`s) -- the true derivative; pinned against fp64 autograd by tests/test_gpu_label_equals_blank.py;
  *   RNNT_CPU: the label term is ASSIGNED after the blank term and overwrites it (reference include/detail/cpu_rnnt.h:253-267);
  *     kept as is -- it is what a caller of the reference's CPU location gets (tests/test_cpu_location.py).
- * The costs agree in both. */
+ * The costs agree in both.
+ * IN PLACE (RNNT_GPU, extension revision 5; every materialised entry point, padded and packed, one-call and two-phase):
+ * `gradients == activations` is a supported call -- the gradient overwrites the logits it was computed from, which halves
+ * the activation footprint of a training step (8 GB at N=128,T=150,U=21,A=5000 fp32).  The gradient pass reads an element
+ * and writes the same element from the same thread, after the statistics pass has finished with the logits; the two
+ * pointers are not declared __restrict__ for that reason.  The reference cannot do this: it memsets the gradient tensor
+ * before it reads the activations (include/detail/gpu_rnnt.h:107-110).  Partial overlap of the two tensors is NOT supported
+ * (RNNT_STATUS_INVALID_VALUE).  Results are bit-identical to the out-of-place call (tests/test_gpu_parity.py). */
 rnntStatus_t compute_rnnt_loss(const float* const activations,
                                float* gradients,
                                const int* const flat_labels,

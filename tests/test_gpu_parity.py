@@ -883,6 +883,89 @@ def test_padding_flag_follows_the_batch(oracle, dtype, A):
     assert torch.equal(dcosts, dcosts2) and torch.equal(grads, grads2)
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float64])
+@pytest.mark.parametrize("shape", [(3, 17, 6, 40),        # flat packets, several rows per packet chunk
+                                   (2, 9, 5, 5003),       # long unaligned rows: straddling packets, row-skipping form
+                                   (4, 12, 7, 1024),      # 2-4 KB rows: the padflag form
+                                   (2, 33, 70, 12),       # tiny vocabulary, 2-D statistics tiles
+                                   (2, 810, 4, 16)])      # long lattice (two-half schedule when an aux stream is set)
+def test_gradients_in_place(oracle, shape, dtype):
+    """`gradients == activations` (rnnt.h, IN PLACE): the gradient overwrites the logits, bit-identical to the out-of-place
+    call -- one-call entry, scaled asynchronous entry, two-phase pair, packed layout, and the row-form kernel of an
+    unaligned tensor; tensors that overlap partially are refused.  The reference memsets the gradient tensor before it
+    reads the activations (include/detail/gpu_rnnt.h:107-110) and cannot do this."""
+    from warprnnt_pytorch import warp_rnnt, _lib
+    from warprnnt_pytorch.packed import pack_joint, row_offsets
+    dev = torch.device("cuda:0")
+    N, T, U, A = shape
+    rng = np.random.default_rng(sum(shape))
+    base = torch.tensor(rng.standard_normal(shape) * 2.0, device=dev).to(dtype)
+    labels = torch.tensor(rng.integers(1, A, size=(N, U - 1)).astype(np.int32), device=dev)
+    tl_np = rng.integers(max(1, T // 2), T + 1, size=N).astype(np.int32); tl_np[0] = T
+    ll_np = rng.integers(0, U, size=N).astype(np.int32); ll_np[-1] = U - 1
+    tl, ll = torch.tensor(tl_np, device=dev), torch.tensor(ll_np, device=dev)
+    cdt = torch.float64 if dtype == torch.float64 else torch.float32
+    # one-call entry
+    c0, g0 = torch.zeros(N, dtype=cdt), torch.full_like(base, 3.0)
+    assert warp_rnnt.gpu_rnnt(base, labels, tl, ll, c0, g0, 0, 0) == 0
+    x = base.clone()
+    c1 = torch.zeros(N, dtype=cdt)
+    assert warp_rnnt.gpu_rnnt(x, labels, tl, ll, c1, x, 0, 0) == 0
+    assert torch.equal(c0, c1) and torch.equal(g0.view(torch.uint8), x.view(torch.uint8))
+    ref_c, ref_g, mag = oracle.rnnt_logits(base.double().cpu().numpy(), labels.cpu().numpy(), tl_np, ll_np, want_mag=True)
+    oracle.assert_grads(x.double().cpu().numpy(), ref_g, mag, dtype, rel=1e-3 if dtype != torch.float64 else None)
+    # asynchronous entry with a per-sample scale folded in
+    scale = torch.tensor(rng.uniform(0.25, 2.0, size=N), device=dev, dtype=cdt)
+    dc0, gs0 = torch.zeros(N, device=dev, dtype=cdt), torch.empty_like(base)
+    warp_rnnt.gpu_rnnt_async(base, labels, tl, ll, dc0, gs0, 0, grad_scale=scale)
+    x = base.clone(); dc1 = torch.zeros(N, device=dev, dtype=cdt)
+    warp_rnnt.gpu_rnnt_async(x, labels, tl, ll, dc1, x, 0, grad_scale=scale)
+    torch.cuda.synchronize()
+    assert torch.equal(dc0, dc1) and torch.equal(gs0.view(torch.uint8), x.view(torch.uint8))
+    # two-phase pair: the forward phase leaves only the workspace, the backward phase overwrites the logits
+    x = base.clone(); dc2 = torch.zeros(N, device=dev, dtype=cdt)
+    ws = warp_rnnt.gpu_rnnt_fwd(x, labels, tl, ll, dc2, 0, True)
+    warp_rnnt.gpu_rnnt_bwd(x, x, scale, ws, 0)
+    torch.cuda.synchronize()
+    assert torch.equal(dc0, dc2) and torch.equal(gs0.view(torch.uint8), x.view(torch.uint8))
+    # packed layout
+    if dtype != torch.float64:
+        p0 = pack_joint(base, tl, ll).contiguous()
+        offs = row_offsets(tl, ll)
+        esz = 4 if dtype == torch.float32 else 2
+        code = _lib.DT_F32 if dtype == torch.float32 else _lib.DT_BF16
+        wsp = torch.empty(_lib.workspace_bytes(T, U, N, True, esz), dtype=torch.uint8, device=dev)
+        opt = _lib.rnntOptions(loc=_lib.RNNT_GPU, num_threads=0, stream=torch.cuda.current_stream(dev).cuda_stream, blank_label=0,
+                               maxT=T, maxU=U, batch_first=True)
+        gp0, cp0 = torch.empty_like(p0), torch.zeros(N, device=dev)
+        call = lambda a, g, c: _lib.lib().compute_rnnt_loss_packed(a.data_ptr(), g.data_ptr(), labels.data_ptr(), ll.data_ptr(), tl.data_ptr(),
+                                                                   offs.data_ptr(), a.shape[0], A, N, c.data_ptr(), None, wsp.data_ptr(), opt, code, 0.0)
+        assert call(p0, gp0, cp0) == 0
+        p1, cp1 = p0.clone(), torch.zeros(N, device=dev)
+        assert call(p1, p1, cp1) == 0
+        torch.cuda.synchronize()
+        assert torch.equal(cp0, cp1) and torch.equal(gp0.view(torch.uint8), p1.view(torch.uint8))
+    # an unaligned tensor (base pointer one element off a 16-byte boundary): the row-form gradient kernel
+    buf = torch.zeros(base.numel() + 1, device=dev, dtype=dtype)
+    xu = buf[1:].view(shape); xu.copy_(base)
+    cu = torch.zeros(N, dtype=cdt)
+    assert warp_rnnt.gpu_rnnt(xu, labels, tl, ll, cu, xu, 0, 0) == 0
+    assert torch.allclose(c0, cu, rtol=1e-6, atol=0)       # (other statistics forms for an unaligned tensor: last-bit differences)
+    oracle.assert_grads(xu.double().cpu().numpy(), ref_g, mag, dtype, rel=1e-3 if dtype != torch.float64 else None)
+    # partial overlap: refused, nothing launched
+    big = torch.zeros(base.numel() + 64, device=dev, dtype=dtype)
+    xa, ga = big[:base.numel()].view(shape), big[64:].view(shape)
+    xa.copy_(base)
+    st = _lib.lib().compute_rnnt_loss_async(xa.data_ptr(), ga.data_ptr(), labels.data_ptr(), ll.data_ptr(), tl.data_ptr(), A, N,
+                                            dc1.data_ptr(), None, ws.data_ptr(),
+                                            _lib.rnntOptions(loc=_lib.RNNT_GPU, num_threads=0, stream=torch.cuda.current_stream(dev).cuda_stream,
+                                                             blank_label=0, maxT=T, maxU=U, batch_first=True),
+                                            {torch.float32: _lib.DT_F32, torch.bfloat16: _lib.DT_BF16, torch.float64: _lib.DT_F64}[dtype])
+    assert st == _lib.RNNT_STATUS_INVALID_VALUE
+    torch.cuda.synchronize()
+    assert torch.equal(xa, base)
+
+
 @pytest.mark.parametrize("loader", ["ext", "ctypes"])
 def test_binding_rejects_host_side_arguments_and_short_workspaces(monkeypatch, loader):
     """labels / lengths on the host next to device activations used to be a GPU fault, and a caller-owned

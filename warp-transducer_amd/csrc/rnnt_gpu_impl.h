@@ -393,6 +393,13 @@ rnntStatus_t run_gpu(const typename Tag::store* acts, typename Tag::store* grads
 
     // 16-byte packets need acts and grads rows to share their alignment phase.
     const uintptr_t pa = reinterpret_cast<uintptr_t>(acts), pg = reinterpret_cast<uintptr_t>(grads);
+    // gradients == activations is supported (every gradient kernel reads an element and writes the same element from the
+    // same thread: rnnt.h, "IN PLACE"); tensors that overlap in any other way are not
+    if (do_bwd && pg != pa) {
+        const unsigned long long rows = p.offsets != nullptr ? p.packed_rows : static_cast<unsigned long long>(N) * p.cells_per_sample;
+        const unsigned long long bytes = rows * static_cast<unsigned long long>(A) * sizeof(S);
+        if ((pg > pa ? pg - pa : pa - pg) < bytes) return RNNT_STATUS_INVALID_VALUE;
+    }
     int vec_ok = (pa % sizeof(S) == 0) ? 1 : 0;
     if (grads != nullptr && ((pa ^ pg) & 15u)) vec_ok = 0;
     // the packed layout has only the flat gradient kernel: both tensors 16-byte aligned

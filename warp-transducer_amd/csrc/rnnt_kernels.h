@@ -1837,7 +1837,7 @@ __global__ __launch_bounds__(256) void fill_row_scale_kernel(
 template <typename Tag, int SCALE, int PPT, int PADSKIP>   // SCALE: 0 none, 1 per sample (padded layout), 2 per row (packed); PPT = packets per thread and iteration;
                                                             // PADSKIP: the logits of padded rows are not read -- 0 never, 1 always, 2 when the batch has padding (padflag)
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(typename Tag::comp) == 8 ? 1 : 8))) void grad_flat_kernel(
-        const typename Tag::store* __restrict__ acts, typename Tag::store* __restrict__ grads,
+        const typename Tag::store* acts, typename Tag::store* grads,       // NOT __restrict__: gradients == activations is a supported call (rnnt.h)
         const Cell<typename Tag::comp>* __restrict__ rowtab, const typename Tag::comp* __restrict__ grad_scale,
         unsigned long long E, unsigned long long R, int A, int blank, int TU, float invA,
         unsigned long long dq, int drem, const typename Tag::comp* __restrict__ rowscale, const int* __restrict__ padflag) {
@@ -2053,7 +2053,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(type
 // grid = (ceil(maxT*maxU / WAVES), N), block = WAVES*64.
 template <typename Tag, int WAVES, bool SCALED>
 __global__ __launch_bounds__(WAVES * 64) void grad_rows_kernel(
-        const typename Tag::store* __restrict__ acts, typename Tag::store* __restrict__ grads,
+        const typename Tag::store* acts, typename Tag::store* grads,       // NOT __restrict__: in-place calls (see grad_flat_kernel)
         const Cell<typename Tag::comp>* __restrict__ rowtab, const typename Tag::comp* __restrict__ grad_scale,
         int maxT, int maxU, int A, int blank, int vec_ok, int b0) {
     using S = typename Tag::store;

@@ -12,6 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 
 RNNT_CPU, RNNT_GPU = 0, 1
 STATUS_SUCCESS = 0
+RNNT_STATUS_INVALID_VALUE, RNNT_STATUS_EXECUTION_FAILED = 2, 3          # include/rnnt.h:48-52
 
 # dtype codes of compute_rnnt_loss_async (include/rnnt.h)
 DT_F32, DT_F64, DT_BF16, DT_F16 = 0, 1, 2, 3

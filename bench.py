@@ -337,11 +337,22 @@ def native_communicator(world, rank, dev, timeout_s=120.0):
     except Exception as e:                                         # noqa: BLE001 -- fall back to torch.distributed's collective
         state["why"] = repr(e)
         state["comm"] = None
+    if state["comm"] is not None:
+        # Introduce the communicator to the library HERE, before the ranks agree: the library must call the ncclAllReduce of
+        # the RCCL copy that made `comm` (say which, do not let it guess), and rnnt_sharded_prepare resolves it now -- a rank
+        # on which that fails votes "no" below instead of failing in front of a collective its peers have entered.
+        from warprnnt_pytorch import _lib as _wl
+        _wl.lib().rnnt_set_rccl_all_reduce(C.cast(state["rccl"].ncclAllReduce, C.c_void_p))
+        if _wl.lib().rnnt_sharded_prepare(state["comm"]) != 0:
+            state["why"] = "rnnt_sharded_prepare failed (no unambiguous RCCL in this process)"
+            state["rccl"].ncclCommDestroy(state["comm"])
+            state["comm"] = None
     ok = torch.tensor([1 if state["comm"] is not None else 0], dtype=torch.int32, device=dev)
     if world > 1:
         dist.all_reduce(ok, op=dist.ReduceOp.MIN)
     if int(ok.item()) == 0:
         if state["comm"] is not None:                              # another rank could not join: nobody uses the native path
+            _wl.lib().rnnt_sharded_release(state["comm"])
             state["rccl"].ncclCommDestroy(state["comm"])
         print("bench.py: no native RCCL communicator on rank %d (%s); every rank uses torch.distributed's all-reduce"
               % (rank, state["why"] or "another rank could not join"), file=sys.stderr)
@@ -807,9 +818,6 @@ def main():
                 return dist.all_reduce(packed, async_op=async_op)
 
             rccl_lib, comm = (None, None) if (args.torch_collective or args.overlap_collective or gloo) else native_communicator(world, rank, dev)
-            if comm is not None:
-                # the library must call the ncclAllReduce of the RCCL copy that made `comm`: say which, do not let it guess
-                lib.rnnt_set_rccl_all_reduce(C.cast(rccl_lib.ncclAllReduce, C.c_void_p))
             pair = torch.zeros(2, dtype=torch.float64, device=dev)       # [summed loss, sample count] of the whole job
             sh_argv = (acts.data_ptr(), grads.data_ptr(), labels.data_ptr(), label_lens.data_ptr(), act_lens.data_ptr(), A, N,
                        costs.data_ptr(), None, pair.data_ptr(), comm, ws.data_ptr(), opt, code)
@@ -962,6 +970,7 @@ def main():
             res["cpu"] = cpu_baseline(w, acts, labels, act_lens, label_lens, args.cpu_samples)
         if comm is not None:
             torch.cuda.synchronize(dev)
+            lib.rnnt_sharded_release(comm)
             rccl_lib.ncclCommDestroy(comm)
         del acts, grads, ws
         torch.cuda.empty_cache()

@@ -211,16 +211,19 @@ rnntStatus_t compute_rnnt_loss_async(const void* activations,
  * /opt/rocm/lib/librccl.so; a communicator handed to the other copy is undefined behaviour).  The pointer is, in order:
  * the one registered with rnnt_set_rccl_all_reduce(); else the ncclAllReduce of the ONE librccl already mapped into the
  * process (opened with RTLD_NOLOAD: nothing new is loaded); else -- none mapped -- librccl.so.1 / librccl.so by name.
- * Two different copies mapped and none registered: EXECUTION_FAILED and a line on stderr naming them, never a guess.
- * EXECUTION_FAILED also if RCCL cannot be found or the collective fails.
- * ALL RANKS OR NONE: once the arguments every rank shares are accepted (loss_sum_count_device, loc, RCCL available), a
- * rank whose LOCAL part fails (INVALID_VALUE for its shard's shape, a launch error) still joins the collective, with a
- * NaN pair, and then returns its own status: its peers are not left blocked in ncclAllReduce, and every rank's reduced
- * loss is NaN.  NOT covered: a rank on which RCCL cannot be resolved at all (none found, or two copies mapped and none registered) returns
- * EXECUTION_FAILED BEFORE the collective -- it has no function to call -- so a job in which only SOME ranks are in that state must be stopped
- * by its launcher; make the ranks alike (rnnt_set_rccl_all_reduce on every rank) and the case cannot arise.
- * STATUS OF THIS ENTRY: run on one-rank communicators and, with two processes, up to RCCL's refusal of two ranks on one device
- * (tests/test_gpu_sharded_rccl.py); no box with two GPUs has executed it yet. */
+ * Two different copies mapped and none registered: EXECUTION_FAILED and a line on stderr naming them, never a guess --
+ * from rnnt_sharded_prepare(), NOT from this call (extension revision 5): a communicator must be introduced once with
+ * rnnt_sharded_prepare(comm) before its first step; RCCL is resolved there, on every rank, before any collective can be
+ * entered, so a rank that cannot resolve it fails where its launcher can still stop the job.  A non-NULL `rccl_comm` that
+ * was not prepared is INVALID_VALUE (nothing enqueued) -- a programming error every rank of a job makes alike.
+ * EXECUTION_FAILED from this call means the collective itself failed.
+ * ALL RANKS OR NONE, without exception: once the arguments every rank shares are accepted (loss_sum_count_device, loc, a
+ * prepared communicator), a rank whose LOCAL part fails (INVALID_VALUE for its shard's shape, a launch error) still joins
+ * the collective, with a NaN pair, and then returns its own status: its peers are not left blocked in ncclAllReduce, and
+ * every rank's reduced loss is NaN (tests/test_gpu_sharded_rccl.py runs this with two ranks, the all-reduce carried by gloo
+ * through a registered function).
+ * STATUS OF THIS ENTRY: run on one-rank RCCL communicators, with two processes up to RCCL's refusal of two ranks on one
+ * device, and with two ranks over a registered (gloo-carried) all-reduce; no box with two GPUs has executed it yet. */
 rnntStatus_t compute_rnnt_loss_sharded(const void* activations,
                                        void* gradients,
                                        const int* const flat_labels,
@@ -242,6 +245,16 @@ rnntStatus_t compute_rnnt_loss_sharded(const void* activations,
  * path of the mapped library, the name it was opened by, or "" when there is none) -- for logs and tests. */
 void rnnt_set_rccl_all_reduce(void* nccl_all_reduce_fn);
 const char* rnnt_rccl_source(void);
+
+/* Introduce a communicator to compute_rnnt_loss_sharded (extension revision 5): resolves the ncclAllReduce that will be
+ * called for it (see WHICH RCCL above) and remembers the pair.  Call it on EVERY rank right after the communicator is
+ * made (and after rnnt_set_rccl_all_reduce, if that is used): RNNT_STATUS_EXECUTION_FAILED here -- no RCCL found, or two
+ * copies mapped and none registered -- comes before any collective exists, so the ranks can still agree not to step.
+ * INVALID_VALUE for NULL.  Preparing a communicator again re-resolves it.  rnnt_sharded_release() forgets it (call it
+ * before ncclCommDestroy: a later communicator may reuse the address).  Host-side bookkeeping only: no device work, no
+ * allocation on the device. */
+rnntStatus_t rnnt_sharded_prepare(void* rccl_comm);
+void rnnt_sharded_release(void* rccl_comm);
 
 /* Two-phase form for autograd frameworks ("fused backward").
  * compute_rnnt_loss_fwd enqueues the row statistics, the lattice and -- with prepare_backward != 0 --
@@ -525,7 +538,10 @@ void rnnt_set_aux_stream(CUstream stream);
 /* Revision of the extension entry points below (the reference's get_warprnnt_version() stays 1).
  *   3: the additive-joint entries (compute_rnnt_loss_add*) must be given a workspace sized by
  *      get_workspace_size_add(); get_workspace_size() covers the materialised entries only.
- *      Host staging of pageable costs became opt-in (rnnt_host_staging). */
+ *      Host staging of pageable costs became opt-in (rnnt_host_staging).
+ *   4: compute_rnnt_loss_lattice_dump exists.
+ *   5: rnnt_sharded_prepare / rnnt_sharded_release exist and compute_rnnt_loss_sharded REQUIRES a prepared communicator;
+ *      gradients == activations (in place) is supported by every materialised entry. */
 int get_warprnnt_extension_version(void);
 
 /* Memory the library itself allocates.  By DEFAULT: none, on the host or on the device, in any entry point -- as the

@@ -131,7 +131,10 @@ def test_round3_extension_entries_without_a_gpu():
     """What the round-3 extension entries do before they touch a device: the extension revision, the staging switch (off
     unless asked for; nothing allocated by toggling it), and INVALID_VALUE for missing arguments / the CPU location."""
     lib = _lib.lib()
-    assert lib.get_warprnnt_extension_version() == 3
+    assert lib.get_warprnnt_extension_version() == 5          # 4: lattice dump; 5: rnnt_sharded_prepare, in-place gradients
+    # a communicator has to be introduced before a sharded step may name it: NULL is refused, an unprepared one is INVALID_VALUE
+    assert lib.rnnt_sharded_prepare(None) == 2
+    lib.rnnt_sharded_release(C.c_void_p(0x1234))                # (unknown: ignored)
     assert lib.rnnt_host_staging(-1) == 0 and lib.rnnt_host_staging_bytes() == 0        # default: the library allocates nothing
     assert lib.rnnt_host_staging(1) == 0 and lib.rnnt_host_staging(-1) == 1
     assert lib.rnnt_host_staging(0) == 1 and lib.rnnt_host_staging(-1) == 0
@@ -150,6 +153,7 @@ def test_round3_extension_entries_without_a_gpu():
     args = (p, None, i.ctypes.data, i.ctypes.data, i.ctypes.data, 3, 1, p, None)
     assert lib.compute_rnnt_loss_sharded(*args, None, None, p, gpu, 0) == 2
     assert lib.compute_rnnt_loss_sharded(*args, p, None, p, cpu, 0) == 2
+    assert lib.compute_rnnt_loss_sharded(*args, p, C.c_void_p(0x1234), p, gpu, 0) == 2      # a communicator nobody prepared
     assert lib.compute_rnnt_loss_sharded(None, None, i.ctypes.data, i.ctypes.data, i.ctypes.data, 3, 1, p, None, p, None, p, gpu, 0) == 2
 
 

@@ -243,10 +243,18 @@ def _sharded_call(acts, labels, tl, ll, comm):
     ws = torch.empty(_lib.workspace_bytes(T, U, N, True, 4), dtype=torch.uint8, device=dev)
     opt = _lib.rnntOptions(loc=1, num_threads=0, stream=torch.cuda.current_stream(dev).cuda_stream, blank_label=0, maxT=T,
                            maxU=U, batch_first=True)
-    st = lib.compute_rnnt_loss_sharded(acts.data_ptr(), grads.data_ptr(), labels.data_ptr(), ll.data_ptr(), tl.data_ptr(), A, N,
-                                       costs.data_ptr(), None, pair.data_ptr(), comm, ws.data_ptr(), opt, _lib.DT_F32)
+    argv = (acts.data_ptr(), grads.data_ptr(), labels.data_ptr(), ll.data_ptr(), tl.data_ptr(), A, N,
+            costs.data_ptr(), None, pair.data_ptr(), comm, ws.data_ptr(), opt, _lib.DT_F32)
+    if comm is not None:
+        # a communicator the library has not been introduced to is refused before anything is enqueued (rnnt.h: revision 5)
+        lib.rnnt_sharded_release(comm)
+        assert lib.compute_rnnt_loss_sharded(*argv) == _lib.RNNT_STATUS_INVALID_VALUE
+        assert lib.rnnt_sharded_prepare(comm) == 0
+    st = lib.compute_rnnt_loss_sharded(*argv)
     assert st == 0, _lib.status_string(st)
     torch.cuda.synchronize(dev)
+    if comm is not None:
+        lib.rnnt_sharded_release(comm)
     return costs, grads, pair
 
 
@@ -307,6 +315,7 @@ def test_native_sharded_entry_on_one_rank():
         bad = _lib.rnntOptions(loc=1, num_threads=0, stream=torch.cuda.current_stream(dev).cuda_stream, blank_label=10 ** 6,
                                maxT=acts.shape[1], maxU=acts.shape[2], batch_first=True)
         pair3 = torch.zeros(2, dtype=torch.float64, device=dev)
+        assert lib.rnnt_sharded_prepare(comm) == 0
         ws = torch.empty(_lib.workspace_bytes(acts.shape[1], acts.shape[2], acts.shape[0], True, 4), dtype=torch.uint8, device=dev)
         st = lib.compute_rnnt_loss_sharded(acts.data_ptr(), grads.data_ptr(), labels.data_ptr(), ll.data_ptr(), tl.data_ptr(),
                                            acts.shape[3], acts.shape[0], costs.data_ptr(), None, pair3.data_ptr(), comm,
@@ -314,6 +323,7 @@ def test_native_sharded_entry_on_one_rank():
         torch.cuda.synchronize(dev)
         assert st == 2 and torch.isnan(pair3).all()
     finally:
+        lib.rnnt_sharded_release(comm)
         rccl.ncclCommDestroy(comm)
 
 
@@ -364,6 +374,91 @@ def test_native_sharded_entry_over_two_rccl_ranks():
     for rank, costs, pair in got:
         assert pair[1] == 6 and abs(pair[0] - total) <= 1e-9 * abs(total)
         assert np.array_equal(costs, ref_c[:4].cpu().numpy() if rank == 0 else ref_c[4:].cpu().numpy())
+
+
+def _gloo_carried_worker(rank, world, port, fail_rank, q):
+    """One rank of a two-rank job whose ranks SHARE device 0: compute_rnnt_loss_sharded with the collective carried by gloo
+    through a registered all-reduce function (the library calls it exactly where it would call ncclAllReduce)."""
+    for p in (ROOT, os.path.join(ROOT, "warp-transducer_amd")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch.distributed as dist
+    from warprnnt_pytorch import _lib
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    lib = _lib.lib()
+    acts, labels, tl, ll = _batch(dev)
+    sl = slice(0, 4) if rank == 0 else slice(4, 6)                  # ragged shards: 4 + 2 samples
+    a, lab, t, l = (v[sl].contiguous() for v in (acts, labels, tl, ll))
+    N, T, U, A = a.shape
+    costs, grads = torch.zeros(N, device=dev), torch.zeros_like(a)
+    pair = torch.full((2,), -1.0, dtype=torch.float64, device=dev)
+    ws = torch.empty(_lib.workspace_bytes(T, U, N, True, 4), dtype=torch.uint8, device=dev)
+    calls = []
+
+    @C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p)
+    def all_reduce(send, recv, count, dtype, op, comm, stream):
+        # ncclAllReduce's signature; in place on `pair` (the library passes its loss_sum_count_device twice)
+        calls.append((send == pair.data_ptr() and recv == pair.data_ptr(), count, dtype, op, comm))
+        torch.cuda.synchronize(dev)
+        host = pair.cpu()
+        dist.all_reduce(host)
+        pair.copy_(host)
+        return 0
+
+    token = C.c_void_p(0xC0FFEE0 + rank)                             # stands for an ncclComm_t
+    lib.rnnt_set_rccl_all_reduce(C.cast(all_reduce, C.c_void_p))
+    assert lib.rnnt_sharded_prepare(token) == 0
+    # a shard only THIS rank cannot run: its blank label lies outside the vocabulary
+    blank = 10 ** 6 if rank == fail_rank else 0
+    opt = _lib.rnntOptions(loc=1, num_threads=0, stream=torch.cuda.current_stream(dev).cuda_stream, blank_label=blank, maxT=T,
+                           maxU=U, batch_first=True)
+    st = lib.compute_rnnt_loss_sharded(a.data_ptr(), grads.data_ptr(), lab.data_ptr(), l.data_ptr(), t.data_ptr(), A, N,
+                                       costs.data_ptr(), None, pair.data_ptr(), token, ws.data_ptr(), opt, _lib.DT_F32)
+    torch.cuda.synchronize(dev)
+    q.put((rank, st, pair.cpu().numpy(), costs.cpu().numpy(), calls))
+    lib.rnnt_sharded_release(token)
+    lib.rnnt_set_rccl_all_reduce(None)
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("fail_rank", [-1, 1, 0])
+def test_two_ranks_all_or_none_over_a_registered_all_reduce(fail_rank):
+    """The native sharded step with world = 2: both ranks on device 0, the 16-byte all-reduce
+    carried by gloo through rnnt_set_rccl_all_reduce.  Healthy: every rank's pair is the GLOBAL [sum, count] of 4 + 2 samples.
+    One rank's shard fails: that rank STILL joins the collective, with a NaN pair, so every rank's reduced pair is NaN and
+    nobody is left blocked; it returns its own status, its peer SUCCESS."""
+    import socket
+    import torch.multiprocessing as mp
+    from warprnnt_pytorch import warp_rnnt
+    dev = torch.device("cuda:0")
+    acts, labels, tl, ll = _batch(dev)
+    ref_c = torch.zeros(acts.shape[0], device=dev)
+    warp_rnnt.gpu_rnnt_async(acts, labels, tl, ll, ref_c, torch.zeros_like(acts), 0)
+    torch.cuda.synchronize()
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_gloo_carried_worker, args=(r, 2, port, fail_rank, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted((q.get(timeout=300) for _ in procs), key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    total = ref_c.double().sum().item()
+    for rank, st, pair, costs, calls in got:
+        assert len(calls) == 1 and calls[0][0] and calls[0][1:4] == (2, 8, 0)        # in place, 2 x ncclFloat64, ncclSum
+        if fail_rank < 0:
+            assert st == 0 and pair[1] == 6 and abs(pair[0] - total) <= 1e-9 * abs(total)
+            assert np.array_equal(costs, ref_c[:4].cpu().numpy() if rank == 0 else ref_c[4:].cpu().numpy())
+        else:
+            assert st == (2 if rank == fail_rank else 0)
+            assert np.isnan(pair).all()                                              # every rank sees that the step failed
 
 
 def _duplicate_device_worker(rank, world, uid_bytes, q):

@@ -18,7 +18,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, reduction, q, ragged=False):
+def _worker(rank, world, port, reduction, q, ragged=False, fail_rank=-1, state_global=True):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     for p in (root, os.path.join(root, "warp-transducer_amd")):
@@ -27,24 +27,43 @@ def _worker(rank, world, port, reduction, q, ragged=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from warprnnt_pytorch.sharded import ShardedRNNTLoss
-    acts, labels, tl, ll = _batch()
+    acts, labels, tl, ll = _batch(5 if ragged else 4)
     n = acts.shape[0] // world
     sl = slice(rank * n, (rank + 1) * n)
-    if ragged:                                  # rank 0 gets three of the four samples, rank 1 the last one
-        sl = slice(0, 3) if rank == 0 else slice(3, 4)
+    if ragged:                                  # five samples: rank 0 gets three, rank 1 the last two (ceil(5 / 2) = 3 is the capacity)
+        sl = slice(0, 3) if rank == 0 else slice(3, 5)
     x = acts[sl].clone().requires_grad_(True)
-    loss = ShardedRNNTLoss(blank=0, reduction=reduction)(x, labels[sl].contiguous(), tl[sl].contiguous(),
-                                                        ll[sl].contiguous())
-    w = torch.arange(1, loss.numel() + 1, dtype=loss.dtype)
-    (loss * w).sum().backward()
-    q.put((rank, loss.detach().numpy(), x.grad.numpy()))
+    # every collective the step issues, counted: DESIGN 7 promises ONE ('none' used to need two
+    # all-gathers and a host read of the shard sizes in between)
+    seen = []
+    for name in ("all_reduce", "all_gather", "all_gather_into_tensor", "broadcast", "all_gather_object"):
+        def counted(*a, _f=getattr(dist, name), _n=name, **k):
+            seen.append(_n)
+            return _f(*a, **k)
+        setattr(dist, name, counted)
+    lab = labels[sl].contiguous()
+    if rank == fail_rank:
+        lab = lab.long()                        # a shard only this rank cannot run: certify_inputs rejects int64 labels
+    crit = ShardedRNNTLoss(blank=0, reduction=reduction,
+                           global_batch=(acts.shape[0] if (ragged and reduction == "none" and state_global) else None))
+    try:
+        loss = crit(x, lab, tl[sl].contiguous(), ll[sl].contiguous())
+    except TypeError as exc:
+        q.put((rank, "raised: %s" % type(exc).__name__, None, list(seen)))
+    else:
+        if torch.isnan(loss).any():
+            q.put((rank, loss.detach().numpy(), None, list(seen)))
+        else:
+            w = torch.arange(1, loss.numel() + 1, dtype=loss.dtype)
+            (loss * w).sum().backward()
+            q.put((rank, loss.detach().numpy(), x.grad.numpy(), list(seen)))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def _batch():
+def _batch(N=4):
     g = torch.Generator().manual_seed(7)
-    N, T, U, A = 4, 6, 4, 5
+    T, U, A = 6, 4, 5
     acts = torch.randn(N, T, U, A, generator=g)
     labels = torch.randint(1, A, (N, U - 1), generator=g, dtype=torch.int32)
     tl = torch.full((N,), T, dtype=torch.int32)        # every shard must contain the max lengths
@@ -71,16 +90,18 @@ def test_two_rank_shard_equals_single(reduction):
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    for rank, loss, grad in got:
+    for rank, loss, grad, seen in got:
         assert np.allclose(loss, ref.detach().numpy(), atol=1e-5)          # global loss on every rank
         assert np.allclose(grad, x.grad[rank * 2:(rank + 1) * 2].numpy(), atol=1e-6)
+        assert seen == (["all_gather_into_tensor"] if reduction == "none" else ["all_reduce"]), seen   # ONE collective
 
 
 @pytest.mark.parametrize("reduction", ["mean", "none"])
 def test_ragged_shards(reduction):
-    """A last shard with fewer samples: 'mean' divides by the global count, 'none' returns all costs in batch order."""
+    """A last shard with fewer samples: 'mean' divides by the global count, 'none' returns all costs in batch order
+    (global_batch stated: the shard capacity ceil(5 / 2) = 3 is known to every rank without a size exchange)."""
     from warprnnt_pytorch import RNNTLoss
-    acts, labels, tl, ll = _batch()
+    acts, labels, tl, ll = _batch(5)
     x = acts.clone().requires_grad_(True)
     ref = RNNTLoss(reduction=reduction)(x, labels, tl, ll)
     w = torch.arange(1, ref.numel() + 1, dtype=ref.dtype)
@@ -95,8 +116,61 @@ def test_ragged_shards(reduction):
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    bounds = [(0, 3), (3, 4)]
-    for rank, loss, grad in got:
+    bounds = [(0, 3), (3, 5)]
+    for rank, loss, grad, seen in got:
         assert np.allclose(loss, ref.detach().numpy(), atol=1e-5)
         lo, hi = bounds[rank]
         assert np.allclose(grad, x.grad[lo:hi].numpy(), atol=1e-6)
+        assert len(seen) == 1, seen
+
+
+def _run(reduction, **kw):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, reduction, q), kwargs=kw) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted((q.get(timeout=120) for _ in procs), key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    return got
+
+
+@pytest.mark.parametrize("reduction", ["mean", "none"])
+def test_a_failing_shard_reaches_every_rank_as_nan(reduction):
+    """ALL RANKS OR NONE with world = 2: rank 1's shard cannot run (int64 labels).  It still joins
+    the ONE collective, with NaNs, and then raises its own error; rank 0 is not left blocked and its loss is NaN."""
+    got = _run(reduction, fail_rank=1)
+    (r0, loss0, _, seen0), (r1, what1, _, seen1) = got
+    assert what1 == "raised: TypeError" and len(seen1) == 1          # joined, then raised
+    assert len(seen0) == 1 and np.isnan(np.asarray(loss0)).any()
+    if reduction == "mean":
+        assert np.isnan(np.asarray(loss0)).all()
+
+
+def test_unequal_shards_without_global_batch_are_visible():
+    """reduction='none' without `global_batch` assumes equal shards; 3 + 2 samples cannot even be gathered (the payloads differ
+    in size) -- or, where the backend pads, every cost is NaN.  Either way nothing is silently mis-sliced: the equal-size
+    contract is checked on the device, not trusted."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, "none", q), kwargs=dict(ragged=True, state_global=False)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = []
+    import queue as queue_mod
+    try:
+        for _ in procs:
+            got.append(q.get(timeout=60))
+    except queue_mod.Empty:
+        pass
+    for p in procs:
+        p.join(timeout=20)
+        if p.is_alive():
+            p.terminate()
+    for item in got:
+        loss = item[1]
+        assert isinstance(loss, str) or np.isnan(np.asarray(loss)).all(), item

@@ -46,7 +46,7 @@ using namespace rnnt;
 extern "C" {
 
 int get_warprnnt_version() { return 1; }
-int get_warprnnt_extension_version(void) { return 3; }
+int get_warprnnt_extension_version(void) { return 5; }
 
 const char* rnntGetStatusString(rnntStatus_t status) {
     // Same strings as the reference (src/rnnt_entrypoint.cpp:18-35) so log scrapers keep working.
@@ -188,6 +188,9 @@ struct Rccl {
     bool tried = false;
     AllReduce found = nullptr;
     char from[512] = {0};                           // where `found` came from (rnnt_rccl_source)
+    // communicators introduced through rnnt_sharded_prepare, each with the ncclAllReduce resolved for it THEN: a sharded
+    // step never has to look RCCL up, so it has no way to fail in front of its collective
+    std::vector<std::pair<void*, AllReduce>> prepared;
 };
 static Rccl& rccl_state() { static Rccl r; return r; }
 
@@ -240,6 +243,33 @@ void rnnt_set_rccl_all_reduce(void* nccl_all_reduce_fn) {
     if (nccl_all_reduce_fn == nullptr) { r.tried = false; r.found = nullptr; r.from[0] = 0; }   // NULL: forget, look again at the next call
 }
 
+rnntStatus_t rnnt_sharded_prepare(void* rccl_comm) {
+    if (rccl_comm == nullptr) return RNNT_STATUS_INVALID_VALUE;
+    const Rccl::AllReduce fn = rccl_all_reduce();                 // (takes the lock itself)
+    if (fn == nullptr) return RNNT_STATUS_EXECUTION_FAILED;       // no (unambiguous) RCCL in this process: said so on stderr
+    Rccl& r = rccl_state();
+    std::lock_guard<std::mutex> g(r.mu);
+    for (auto& e : r.prepared)
+        if (e.first == rccl_comm) { e.second = fn; return RNNT_STATUS_SUCCESS; }
+    r.prepared.emplace_back(rccl_comm, fn);
+    return RNNT_STATUS_SUCCESS;
+}
+
+void rnnt_sharded_release(void* rccl_comm) {
+    Rccl& r = rccl_state();
+    std::lock_guard<std::mutex> g(r.mu);
+    for (size_t i = 0; i < r.prepared.size(); ++i)
+        if (r.prepared[i].first == rccl_comm) { r.prepared.erase(r.prepared.begin() + static_cast<long>(i)); return; }
+}
+
+static Rccl::AllReduce prepared_all_reduce(void* rccl_comm) {
+    Rccl& r = rccl_state();
+    std::lock_guard<std::mutex> g(r.mu);
+    for (const auto& e : r.prepared)
+        if (e.first == rccl_comm) return e.second;
+    return nullptr;
+}
+
 const char* rnnt_rccl_source(void) {
     if (rccl_all_reduce() == nullptr) return "";
     Rccl& r = rccl_state();
@@ -254,8 +284,12 @@ rnntStatus_t compute_rnnt_loss_sharded(const void* activations, void* gradients,
                                        void* workspace, rnntOptions options, int dtype_code) {
     // (argument errors every rank of a job makes alike return before anything is enqueued)
     if (loss_sum_count_device == nullptr || loc_of(options) != RNNT_GPU) return RNNT_STATUS_INVALID_VALUE;
+    // A communicator must have been introduced with rnnt_sharded_prepare(): RCCL was resolved THERE, where a failure is an
+    // ordinary error on that rank before any collective exists.  An unprepared communicator is a programming error every
+    // rank of a job makes alike (same code), like the two above: INVALID_VALUE, nothing enqueued.  From here on nothing
+    // can stop this rank short of the collective.
     Rccl::AllReduce all_reduce = nullptr;
-    if (rccl_comm != nullptr && (all_reduce = rccl_all_reduce()) == nullptr) return RNNT_STATUS_EXECUTION_FAILED;   // no (unambiguous) RCCL in this process
+    if (rccl_comm != nullptr && (all_reduce = prepared_all_reduce(rccl_comm)) == nullptr) return RNNT_STATUS_INVALID_VALUE;
     hipStream_t stream = reinterpret_cast<hipStream_t>(options.stream);
     rnntStatus_t st = bad_args(activations, flat_labels, label_lengths, input_lengths, costs_device, workspace,
                                alphabet_size, minibatch, options)

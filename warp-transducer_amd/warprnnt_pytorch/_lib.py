@@ -75,6 +75,8 @@ EXPORTS = {
     "rnnt_host_staging_bytes": (C.c_longlong, []),
     "rnnt_host_staging_release": (C.c_longlong, []),
     "rnnt_set_rccl_all_reduce": (None, [_PTR]),
+    "rnnt_sharded_prepare": (C.c_int, [_PTR]),
+    "rnnt_sharded_release": (None, [_PTR]),
     "rnnt_set_aux_stream": (None, [_PTR]),
     "rnnt_rccl_source": (C.c_char_p, []),
     "rnnt_profile_enable": (None, [C.c_int]),

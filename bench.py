@@ -517,6 +517,21 @@ def run_add_workload(lib, dev, name, steps, warmup, verify=True):
                              "note": "three contractions of 2*N*T*U*A flops over the WHOLE step (lattice and coefficient kernels included)"},
            "path_frac": round(hbm / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "bytes_algo": hbm,
            "materialised_equivalent_bytes": 3 * N * T * U * A * s}
+    # The bound that matters: these GEMMs are thin (U / 4 flop per byte) -- HBM, not the matrix cores.
+    # Over the whole step; `traffic` = HBM bytes per step counted by the committed rocprofv3 --pmc passes per kernel
+    # (tools/add_network_roofline.py --json; FETCH_SIZE calibrated for these kernels' load shapes: profiles/r06/fetch_calibration.md)
+    rec["roofline"] = {"bound": "hbm", "achieved": round(hbm / (ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                       "frac": rec["path_frac"], "bytes_algo": hbm, "traffic": None,
+                       "note": "whole step (forward + backward phase, every kernel and launch gap) against 8 TB/s"}
+    try:
+        import glob
+        tfile = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_add_traffic.json")))[-1]
+        tj = json.load(open(tfile))[name]
+        rec["roofline"]["traffic"] = tj["traffic_bytes_per_step"]
+        rec["roofline"]["traffic_over_algorithmic"] = round(tj["traffic_bytes_per_step"] / hbm, 3)
+        rec["roofline"]["traffic_source"] = "profiles/%s (committed rocprofv3 --pmc passes per kernel; not measured in this run)" % os.path.basename(tfile)
+    except (OSError, KeyError, ValueError, IndexError):
+        pass
     if verify:
         from oracle import oracle as O
         pick = sorted({0, N - 1})

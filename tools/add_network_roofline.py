@@ -9,7 +9,9 @@ coefficient kernels beside them) on one shape,
     cycles (SQ_VALU_MFMA_BUSY_CYCLES) as a fraction of the SIMD-cycles the kernel had (duration x clock x SIMDs).
 Every counter set is its own `rocprofv3 --pmc ... --kernel-trace` run of tools/add_network_bench.py --fused-only (no other
 trace domain), as the guide prescribes.
-Usage: python tools/add_network_roofline.py [--bf16] c3|c4|c5f32 > profiles/rNN_add_roofline_<shape>.md"""
+`--json FILE` also writes the counted HBM bytes per kernel launch and per step (launches of a kernel / launches of joint_prep_kernel or
+of the lattice kernel = launches per step) -- what bench.py reports as `other_workloads.add_*.roofline.traffic`.
+Usage: python tools/add_network_roofline.py [--bf16] [--json FILE] c3|c4|c5f32 > profiles/rNN_add_roofline_<shape>.md"""
 import glob
 import os
 import re
@@ -57,8 +59,14 @@ def one_pass(counters, argv, tmp):
 
 
 def main():
-    args = [a for a in sys.argv[1:] if not a.startswith("--")] or ["c3"]
-    half = [a for a in sys.argv[1:] if a in ("--bf16", "--fp16")]
+    argv = sys.argv[1:]
+    json_path = None
+    if "--json" in argv:
+        i = argv.index("--json")
+        json_path = argv[i + 1]
+        del argv[i:i + 2]
+    args = [a for a in argv if not a.startswith("--")] or ["c3"]
+    half = [a for a in argv if a in ("--bf16", "--fp16")]
     shape = args[0]
     N, T, U, A = SHAPES[shape]
     peak_tf = 2500.0 if half else 157.3
@@ -95,6 +103,28 @@ def main():
               % (k[:60], t["calls"], t["ns"] / 1e3, "%.1f" % tf if gemm else "-", "%.3f" % (tf / peak_tf) if gemm else "-",
                  mops * 512 / sec / 1e12, hbm / sec / 1e9, hbm / sec / 1e9 / 8000.0, valu / max(waves, 1), mfma / max(waves, 1),
                  "%.0f" % (valu / mfma) if mfma else "-", 4.0 * valu / simd_cycles, m.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / simd_cycles))
+    if json_path:
+        import json
+        steps = max([t["calls"] for k, t in trace.items() if "lattice" in k] or [1])
+        per = {}
+        for k, t in trace.items():
+            m = merged.get(k, {})
+            if "FETCH_SIZE" not in m and "WRITE_SIZE" not in m:
+                continue
+            if k.startswith("at::") or "rocclr" in k.lower() or "elementwise" in k:
+                continue
+            b = (2 * m.get("FETCH_SIZE", 0.0) + m.get("WRITE_SIZE", 0.0)) * 1024
+            per[k] = {"launches_per_step": t["calls"] / steps, "traffic_bytes_per_launch": int(b), "avg_us": round(t["ns"] / 1e3, 2),
+                      "traffic_bytes_per_step": int(b * t["calls"] / steps)}
+        key = "add_%s_%s" % (shape, (half or ["f32"])[0].strip("-").replace("fp32", "f32"))
+        try:
+            doc = json.load(open(json_path))
+        except (OSError, ValueError):
+            doc = {}
+        doc[key] = {"shape": [N, T, U, A], "kernels": per, "traffic_bytes_per_step": int(sum(v["traffic_bytes_per_step"] for v in per.values())),
+                    "how": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE with --kernel-trace, separate passes; 2 x FETCH_SIZE + WRITE_SIZE KiB "
+                           "(the x2 holds for every read shape of these kernels: profiles/r06/fetch_calibration.md)"}
+        json.dump(doc, open(json_path, "w"), indent=1, sort_keys=True)
     print("\n(counters are per launch, averaged over the launches of the run; `VALU-issue share` counts 4 SIMD-cycles per vector instruction "
           "-- 1.0 = the vector pipes never idle; `MFMA-busy share` = SQ_VALU_MFMA_BUSY_CYCLES over the same SIMD-cycles)")
 

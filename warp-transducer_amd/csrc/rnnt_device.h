@@ -276,4 +276,26 @@ template <typename T> __device__ __forceinline__ T wave_sum(T v) {
 // Force a wave-uniform value into an SGPR so that address arithmetic built on it is scalar.
 __device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
+// XCD-aware block order for launches whose logical blocks are (x, y, z) -- gx * gy * gz of them -- and whose gy blocks of
+// one (x, z) pair read the SAME operand slab (the label rows' g columns under every time tile of a sample, ...).  HIP hands
+// workgroup L of a launch to XCD L % 8, and each XCD has its own 4 MB L2: in the natural (x fastest) order the gy sharers
+// land on different XCDs and every one of them fetches the slab from memory again (additive joint, c3 shape: g re-read five
+// times, 1.9x the algorithmic bytes of the Z kernel by the memory-side counters).  Here the launch is one-dimensional,
+// ceil(gx gz / 8) * 8 * gy blocks (xcd_shared_grid), and block L takes y = (L / 8) % gy of group (L / 8 / gy) * 8 + L % 8:
+// the gy sharers of a group are consecutive workgroups of ONE XCD, so all but the first find the slab in that L2.
+struct XcdBlock { int x, y, z; bool live; };
+__device__ __forceinline__ XcdBlock xcd_shared_y(int gx, int gy, int gz) {
+    const unsigned L = blockIdx.x, q = L >> 3;
+    const unsigned grp = (q / static_cast<unsigned>(gy)) * 8u + (L & 7u);
+    XcdBlock o;
+    o.y = static_cast<int>(q % static_cast<unsigned>(gy));
+    o.x = static_cast<int>(grp % static_cast<unsigned>(gx));
+    o.z = static_cast<int>(grp / static_cast<unsigned>(gx));
+    o.live = grp < static_cast<unsigned>(gx) * static_cast<unsigned>(gz);
+    return o;
+}
+inline unsigned xcd_shared_grid(int gx, int gy, int gz) {
+    return (static_cast<unsigned>(gx) * static_cast<unsigned>(gz) + 7u) / 8u * 8u * static_cast<unsigned>(gy);
+}
+
 }  // namespace rnnt

@@ -144,14 +144,16 @@ __global__ __launch_bounds__(256, NT == 4 ? 2 : 1) void joint_dg16_kernel(
         const float* __restrict__ wmat, const float* __restrict__ scale, const int* __restrict__ xlen,
         const int* __restrict__ ylen, typename Tag::store* __restrict__ dg, int maxT, int maxU, int Upad, int A, int N,
         const int* __restrict__ labels, int blank, const float* __restrict__ sgb, const float* __restrict__ sgl) {
-    const int b = blockIdx.z;
+    const XcdBlock blk = xcd_shared_y((A + 128 * NT - 1) / (128 * NT), (maxU + 31) / 32, N);   // (block order: as joint_dg_kernel)
+    if (!blk.live) return;
+    const int b = blk.z;
     const int lane = threadIdx.x & 63, wave = uniform(threadIdx.x >> 6), half = lane >> 5, col = lane & 31;
     using PK = Packet16<Tag, NT>;
-    const int k0 = (static_cast<int>(blockIdx.x) * 4 + wave) * (32 * NT);
+    const int k0 = (blk.x * 4 + wave) * (32 * NT);
     if (k0 >= A) return;
     const int kc = k0 + NT * col;                          // first of this lane's NT columns
     const bool kin = kc < A;                               // A % NT == 0: all of them or none
-    const int u0 = blockIdx.y * 32;
+    const int u0 = blk.y * 32;
     const int Tb = clamp_len(xlen[b], maxT), Ub = clamp_len(ylen[b] + 1, maxU);
     const float* mg = rowmax + static_cast<size_t>(N) * maxT + static_cast<size_t>(b) * maxU;
     f32x16 acc[NT];
@@ -254,14 +256,16 @@ __global__ __launch_bounds__(256, NT == 4 ? 2 : 1) void joint_df16_kernel(
         const float* __restrict__ wmat, const float* __restrict__ scale, const int* __restrict__ labels,
         const int* __restrict__ xlen, const int* __restrict__ ylen, typename Tag::store* __restrict__ df, int maxT, int maxU,
         int Upad, int A, int N, int blank, const float* __restrict__ sfb) {
-    const int b = blockIdx.z;
+    const XcdBlock blk = xcd_shared_y((A + 128 * NT - 1) / (128 * NT), (maxT + 31) / 32, N);   // (block order: as joint_df_kernel)
+    if (!blk.live) return;
+    const int b = blk.z;
     const int lane = threadIdx.x & 63, wave = uniform(threadIdx.x >> 6), half = lane >> 5, col = lane & 31;
     using PK = Packet16<Tag, NT>;
-    const int k0 = (static_cast<int>(blockIdx.x) * 4 + wave) * (32 * NT);
+    const int k0 = (blk.x * 4 + wave) * (32 * NT);
     if (k0 >= A) return;
     const int kc = k0 + NT * col;
     const bool kin = kc < A;
-    const int t0 = blockIdx.y * 32;
+    const int t0 = blk.y * 32;
     const int Tb = clamp_len(xlen[b], maxT), Ub = clamp_len(ylen[b] + 1, maxU);
     const float* mf = rowmax + static_cast<size_t>(b) * maxT;
     const typename Tag::store* fb = f + static_cast<size_t>(b) * maxT * A + (kin ? kc : A - NT);
@@ -435,10 +439,17 @@ __global__ __launch_bounds__(S == 1 ? 256 : S * 64) void joint_z16_kernel(
     (void)refs; (void)xch;
     if constexpr (!SAMPLED)                                // the exact pass behind a sampled one: only when the gate is raised
         if (gate != nullptr && *gate != seq) return;
-    const int b = blockIdx.y;
     const int lane = threadIdx.x & 63, wave = uniform(threadIdx.x >> 6), half = lane >> 5, col = lane & 31;
-    const int group = S == 1 ? static_cast<int>((blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3))
-                             : static_cast<int>(blockIdx.x);
+    int b, group;                                          // (block order: as joint_z_kernel)
+    if constexpr (S == 1) {
+        b = blockIdx.y;
+        group = static_cast<int>((blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3));
+    } else {
+        const XcdBlock o = xcd_shared_y(1, tiles, N);
+        if (!o.live) return;
+        b = o.z;
+        group = o.y;
+    }
     const int tile = S == 1 ? group * 4 + wave : group;
     if (tile >= tiles) return;                             // S == 1 only: a whole wavefront leaves
     const int Tb = clamp_len(xlen[b], maxT), Ub = clamp_len(ylen[b] + 1, maxU);

@@ -94,11 +94,11 @@ rnntStatus_t run_gpu_joint(const typename Tag::store* f, const typename Tag::sto
             else { if (vec) RNNT_JMAX(true, 1, SIDE, GATE); else RNNT_JMAX(false, 1, SIDE, GATE); }             \
         } while (0)
 #define RNNT_JZ(SS, VV, SAMP, GATE)                                                                              \
-    hipLaunchKernelGGL((joint_z_kernel<Tag, SS, VV, SAMP>), dim3(SS == 1 ? ((tiles + 3) / 4 + 7) / 8 * 8 : tiles, N),               \
+    hipLaunchKernelGGL((joint_z_kernel<Tag, SS, VV, SAMP>), SS == 1 ? dim3(((tiles + 3) / 4 + 7) / 8 * 8, N) : dim3(xcd_shared_grid(1, tiles, N)),               \
                        dim3(SS == 1 ? 256 : SS * 64), 0, p.stream, f, g, p.rowmax, labels, input_lengths,        \
                        label_lengths, p.lp2, p.logz, maxT, maxU, p.Up, A, p.blank, tilesU, tiles, N, GATE, seq, p.poison)
 #define RNNT_JZ16(SS, SAMP, GATE)                                                                                \
-    hipLaunchKernelGGL((joint_z16_kernel<Tag, SS, SAMP>), dim3(SS == 1 ? ((tiles + 3) / 4 + 7) / 8 * 8 : tiles, N),    \
+    hipLaunchKernelGGL((joint_z16_kernel<Tag, SS, SAMP>), SS == 1 ? dim3(((tiles + 3) / 4 + 7) / 8 * 8, N) : dim3(xcd_shared_grid(1, tiles, N)),    \
                        dim3(SS == 1 ? 256 : SS * 64), 0, p.stream, f, g, p.rowmax, labels, input_lengths,        \
                        label_lengths, p.lp2, p.logz, maxT, maxU, p.Up, A, p.blank, tilesU, tiles, N, GATE, seq, p.poison)
 #define RNNT_JZ_ALL(SAMP, GATE)                                                                                  \
@@ -204,27 +204,27 @@ rnntStatus_t run_gpu_joint(const typename Tag::store* f, const typename Tag::sto
         // not grow with T (N=16, T=1500, U=301, A=1024: 320 blocks, 276 us; split 192 us), at T = 150 / 200 the split form loses 5-10 %
         const bool split_g = tn.jsplit && maxT >= 64 && (groups(NKg) <= 2 || maxT >= 512 || tn.jsplit >= 2);
 #define RNNT_JDF_SPLIT(NN, OO)                                                                                   \
-    hipLaunchKernelGGL((joint_df_kernel<Tag, NN, true, OO, true, false>), dim3((A + 32 * NN - 1) / (32 * NN), tilesT, N), dim3(256), 0, \
+    hipLaunchKernelGGL((joint_df_kernel<Tag, NN, true, OO, true, false>), dim3(xcd_shared_grid((A + 32 * NN - 1) / (32 * NN), tilesT, N)), dim3(256), 0, \
                        p.stream, f, g, p.rowmax, p.wmat, grad_scale, labels, input_lengths, label_lengths, df, maxT,  \
                        maxU, Upad, A, N, p.blank, sfb)
 #define RNNT_JDF_SPLIT_BS(NN)                                                                                    \
-    hipLaunchKernelGGL((joint_df_kernel<Tag, NN, true, true, true, true>), dim3((A + 32 * NN - 1) / (32 * NN), tilesT, N), dim3(256), 0, \
+    hipLaunchKernelGGL((joint_df_kernel<Tag, NN, true, true, true, true>), dim3(xcd_shared_grid((A + 32 * NN - 1) / (32 * NN), tilesT, N)), dim3(256), 0, \
                        p.stream, f, g, p.rowmax, p.wmat, grad_scale, labels, input_lengths, label_lengths, df, maxT,  \
                        maxU, Upad, A, N, p.blank, sfb)
 #define RNNT_JDF_BS(NN)                                                                                          \
-    hipLaunchKernelGGL((joint_df_kernel<Tag, NN, true, true, false, true>), dim3((A + 128 * NN - 1) / (128 * NN), tilesT, N), dim3(256), 0, \
+    hipLaunchKernelGGL((joint_df_kernel<Tag, NN, true, true, false, true>), dim3(xcd_shared_grid((A + 128 * NN - 1) / (128 * NN), tilesT, N)), dim3(256), 0, \
                        p.stream, f, g, p.rowmax, p.wmat, grad_scale, labels, input_lengths, label_lengths, df, maxT,  \
                        maxU, Upad, A, N, p.blank, sfb)
 #define RNNT_JDG_SPLIT(NN)                                                                                       \
-    hipLaunchKernelGGL((joint_dg_kernel<Tag, NN, true, true>), dim3((A + 32 * NN - 1) / (32 * NN), tilesU, N), dim3(256), 0, \
+    hipLaunchKernelGGL((joint_dg_kernel<Tag, NN, true, true>), dim3(xcd_shared_grid((A + 32 * NN - 1) / (32 * NN), tilesU, N)), dim3(256), 0, \
                        p.stream, f, g, p.rowmax, p.wmat, grad_scale, input_lengths, label_lengths, dg, maxT,     \
                        maxU, Upad, A, N, labels, p.blank, sgb, sgl)
 #define RNNT_JDF(NN, PP, OO)                                                                                     \
-    hipLaunchKernelGGL((joint_df_kernel<Tag, NN, PP, OO>), dim3((A + 128 * NN - 1) / (128 * NN), tilesT, N), dim3(256), 0, \
+    hipLaunchKernelGGL((joint_df_kernel<Tag, NN, PP, OO>), dim3(xcd_shared_grid((A + 128 * NN - 1) / (128 * NN), tilesT, N)), dim3(256), 0, \
                        p.stream, f, g, p.rowmax, p.wmat, grad_scale, labels, input_lengths, label_lengths, df, maxT,  \
                        maxU, Upad, A, N, p.blank, sfb)
 #define RNNT_JDG(NN, PP)                                                                                         \
-    hipLaunchKernelGGL((joint_dg_kernel<Tag, NN, PP>), dim3((A + 128 * NN - 1) / (128 * NN), tilesU, N), dim3(256), 0, \
+    hipLaunchKernelGGL((joint_dg_kernel<Tag, NN, PP>), dim3(xcd_shared_grid((A + 128 * NN - 1) / (128 * NN), tilesU, N)), dim3(256), 0, \
                        p.stream, f, g, p.rowmax, p.wmat, grad_scale, input_lengths, label_lengths, dg, maxT,     \
                        maxU, Upad, A, N, labels, p.blank, sgb, sgl)
         // 16-bit storage: the operand ping-pong doubles the AGPR count of these kernels (172 + 128 registers: one wavefront
@@ -235,7 +235,7 @@ rnntStatus_t run_gpu_joint(const typename Tag::store* f, const typename Tag::sto
             df16 = (jbits & 2) != 0 && A % 8 == 0 && (all4 & 15u) == 0 && A >= 512;
             if (df16) {
 #define RNNT_JDF16(NN, PP)                                                                                       \
-    hipLaunchKernelGGL((joint_df16_kernel<Tag, NN, PP>), dim3((A + 128 * NN - 1) / (128 * NN), tilesT, N), dim3(256), 0, p.stream, \
+    hipLaunchKernelGGL((joint_df16_kernel<Tag, NN, PP>), dim3(xcd_shared_grid((A + 128 * NN - 1) / (128 * NN), tilesT, N)), dim3(256), 0, p.stream, \
                        f, g, p.rowmax, p.wmat, grad_scale, labels, input_lengths, label_lengths, df, maxT, maxU, Upad, A, N, \
                        p.blank, sfb)
                 if (tn.j16nt == 8) { if (tn.j16pf) RNNT_JDF16(8, true); else RNNT_JDF16(8, false); }
@@ -257,7 +257,7 @@ rnntStatus_t run_gpu_joint(const typename Tag::store* f, const typename Tag::sto
             dg16 = (jbits & 1) != 0 && A % 8 == 0 && (all4 & 15u) == 0 && A >= 512;
             if (dg16) {
 #define RNNT_JDG16(NN, PP)                                                                                       \
-    hipLaunchKernelGGL((joint_dg16_kernel<Tag, NN, PP>), dim3((A + 128 * NN - 1) / (128 * NN), tilesU, N), dim3(256), 0, p.stream, \
+    hipLaunchKernelGGL((joint_dg16_kernel<Tag, NN, PP>), dim3(xcd_shared_grid((A + 128 * NN - 1) / (128 * NN), tilesU, N)), dim3(256), 0, p.stream, \
                        f, g, p.rowmax, p.wmat, grad_scale, input_lengths, label_lengths, dg, maxT, maxU, Upad, A, N,  \
                        labels, p.blank, sgb, sgl)
                 if (tn.j16nt == 8) { if (tn.j16pf) RNNT_JDG16(8, true); else RNNT_JDG16(8, false); }

@@ -262,13 +262,22 @@ __global__ __launch_bounds__(S == 1 ? 256 : S * 64) void joint_z_kernel(
     float* stage = reinterpret_cast<float*>(stage4);
     if constexpr (!SAMPLED)                                // the exact pass behind a sampled one: only when the gate is raised
         if (gate != nullptr && *gate != seq) return;
-    const int b = blockIdx.y;
     const int lane = threadIdx.x & 63, wave = uniform(threadIdx.x >> 6), half = lane >> 5, col = lane & 31;
     // S == 1 (many tiles): XCD-aware order -- workgroup i runs on XCD i % 8, so every XCD is given one
     // contiguous range of tile groups and the partial lines of the skewed arrays that neighbouring tiles
     // write meet in one L2 (gridDim.x is a multiple of 8 then; see row_stats_tile_kernel)
-    const int group = S == 1 ? static_cast<int>((blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3))
-                             : static_cast<int>(blockIdx.x);
+    // S > 1 (one tile per block, few tiles): the tiles of ONE sample share its g rows (and, across label tiles, its f rows):
+    // a one-dimensional launch in xcd_shared_y order keeps them on one XCD (rnnt_device.h)
+    int b, group;
+    if constexpr (S == 1) {
+        b = blockIdx.y;
+        group = static_cast<int>((blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3));
+    } else {
+        const XcdBlock o = xcd_shared_y(1, tiles, N);
+        if (!o.live) return;
+        b = o.z;
+        group = o.y;
+    }
     const int tile = S == 1 ? group * 4 + wave : group;
     if (tile >= tiles) return;                             // S == 1 only: a whole wavefront leaves
     const int Tb = clamp_len(xlen[b], maxT), Ub = clamp_len(ylen[b] + 1, maxU);
@@ -794,13 +803,16 @@ __global__ __launch_bounds__(256) void joint_df_kernel(
         int Upad, int A, int N, int blank, const float* __restrict__ sfb) {
     __shared__ float red[SPLIT ? NK * 16 * 64 : 1];
     (void)red;
-    const int b = blockIdx.z;
+    // block order: the time tiles of one (column group, sample) share the g columns -- one XCD, consecutive (xcd_shared_y)
+    const XcdBlock blk = xcd_shared_y((A + (SPLIT ? 32 : 128) * NK - 1) / ((SPLIT ? 32 : 128) * NK), (maxT + 31) / 32, N);
+    if (!blk.live) return;
+    const int b = blk.z;
     const int lane = threadIdx.x & 63, wave = uniform(threadIdx.x >> 6), half = lane >> 5, col = lane & 31;
-    const int k0 = SPLIT ? static_cast<int>(blockIdx.x) * (32 * NK) : (static_cast<int>(blockIdx.x) * 4 + wave) * (32 * NK);
+    const int k0 = SPLIT ? blk.x * (32 * NK) : (blk.x * 4 + wave) * (32 * NK);
     if (k0 >= A) return;                                   // (SPLIT: block-uniform)
     const int kc = k0 + NK * col;                          // first of this lane's NK columns
     const bool kin = kc < A;                               // A % NK == 0: all NK columns or none
-    const int t0 = blockIdx.y * 32;
+    const int t0 = blk.y * 32;
     const int Tb = clamp_len(xlen[b], maxT), Ub = clamp_len(ylen[b] + 1, maxU);
     const float* mf = rowmax + static_cast<size_t>(b) * maxT;
     using ST = typename Tag::store;
@@ -1038,13 +1050,16 @@ __global__ __launch_bounds__(256) void joint_dg_kernel(
         const int* __restrict__ labels, int blank, const float* __restrict__ sgb, const float* __restrict__ sgl) {
     __shared__ float red[SPLIT ? NK * 16 * 64 : 1];
     (void)red;
-    const int b = blockIdx.z;
+    // block order: the label tiles of one (column group, sample) share the f columns -- one XCD, consecutive (xcd_shared_y)
+    const XcdBlock blk = xcd_shared_y((A + (SPLIT ? 32 : 128) * NK - 1) / ((SPLIT ? 32 : 128) * NK), (maxU + 31) / 32, N);
+    if (!blk.live) return;
+    const int b = blk.z;
     const int lane = threadIdx.x & 63, wave = uniform(threadIdx.x >> 6), half = lane >> 5, col = lane & 31;
-    const int k0 = SPLIT ? static_cast<int>(blockIdx.x) * (32 * NK) : (static_cast<int>(blockIdx.x) * 4 + wave) * (32 * NK);
+    const int k0 = SPLIT ? blk.x * (32 * NK) : (blk.x * 4 + wave) * (32 * NK);
     if (k0 >= A) return;                                   // (SPLIT: block-uniform)
     const int kc = k0 + NK * col;
     const bool kin = kc < A;
-    const int u0 = blockIdx.y * 32;
+    const int u0 = blk.y * 32;
     const int Tb = clamp_len(xlen[b], maxT), Ub = clamp_len(ylen[b] + 1, maxU);
     const float* mg = rowmax + static_cast<size_t>(N) * maxT + static_cast<size_t>(b) * maxU;
     f32x16 acc[NK];

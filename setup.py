@@ -12,6 +12,7 @@ import importlib.util
 import os
 import shutil
 import subprocess
+import sys
 
 from setuptools import setup
 from setuptools.command.build_py import build_py
@@ -32,6 +33,11 @@ class build_native(build_py):
 
     def run(self):
         super().run()
+        if getattr(self, "editable_mode", False):
+            # PEP 660 (`pip install -e .` with setuptools >= 64, editable_wheel): the package is imported from the SOURCE tree, so
+            # the native pair must be built there -- build_lib is a temporary directory nothing will ever import from
+            _build_in_tree()
+            return
         pkg_out = os.path.join(self.build_lib, "warprnnt_pytorch")
         lib_out = os.path.join(pkg_out, "lib")
         os.makedirs(lib_out, exist_ok=True)
@@ -53,15 +59,19 @@ class build_native(build_py):
         be.build(force=True, lib_dir=lib_out, out_dir=pkg_out)
 
 
+def _build_in_tree():
+    if not os.environ.get("WARP_RNNT_PATH"):
+        subprocess.run(["make", "-j3", "-C", os.path.join(ROOT, "warp-transducer_amd"), "lib/libwarprnnt.so"], check=True)
+    subprocess.run([sys.executable, os.path.join(PKG_SRC, "build_ext.py")], check=True)
+
+
 class develop_native(develop):
     """`pip install -e .` / `setup.py develop`: the package runs from the source tree, so the native pair is built IN the
     tree (what __graft_entry__.build() does) -- an editable install without it would silently fall back to the ctypes
     loader, or find no library at all."""
 
     def run(self):
-        if not os.environ.get("WARP_RNNT_PATH"):
-            subprocess.run(["make", "-j3", "-C", os.path.join(ROOT, "warp-transducer_amd"), "lib/libwarprnnt.so"], check=True)
-        subprocess.run([os.sys.executable, os.path.join(PKG_SRC, "build_ext.py")], check=True)
+        _build_in_tree()
         super().run()
 
 

@@ -41,7 +41,7 @@ def device_asm(path=None, SRC=SRCS[0]):
 def check(asm):
     lines = asm.split("\n")
     problems = []
-    starts = [i for i, l in enumerate(lines) if l.startswith("_ZN4rnnt18lattice_lin_kernel") and ":" in l]
+    starts = [i for i, l in enumerate(lines) if (l.startswith("_ZN4rnnt18lattice_lin_kernel") or l.startswith("_ZN4rnntL18lattice_lin_kernel")) and ":" in l]   # (L: internal linkage -- the kernel is TU-local since round 6)
     if not starts:
         return ["lattice_lin_kernel not found in the device code"]
     start = starts[0]

@@ -4,7 +4,11 @@
 //     rnnt_gpu.hip      F32  (+ every C entry point)        rnnt_gpu_f64.hip   F64        rnnt_gpu_h16.hip   BF16, F16
 // -- because a translation unit is a code object and HIP loads a code object on the first launch of one of its kernels: with all
 // four storage types in one object the first call of a process cost 3.9 ms, most of it loading kernels of types the caller never
-// uses (tools/first_call.py; EXPERIMENTS.md 12).  State shared by the instantiations (staging buffers, the auxiliary stream, the
+// uses (tools/first_call.py; EXPERIMENTS.md 12).  The kernels that depend on the LATTICE type only (lattice_kernel, lattice_lin_kernel,
+// coef_kernel, coef_cell_kernel, ... and joint_prep / joint_sums) are instantiated by several of these units with the same template
+// arguments: they are `static` (internal linkage) so that every unit launches -- and every code object holds -- its OWN copy; as
+// ordinary templates their host-side handles merged at link time, one module's copy served all of them, and a bf16 call loaded
+// the fp32 unit's code object as well (`nm build/*.o` shows no weak kernel handle now).  State shared by the instantiations (staging buffers, the auxiliary stream, the
 // profile timers) is defined once, in rnnt_gpu.hip; the small non-template helpers are `inline` so that their function-local
 // statics are one object for the whole library.
 #pragma once

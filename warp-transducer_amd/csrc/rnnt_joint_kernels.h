@@ -236,7 +236,7 @@ __device__ __forceinline__ float4 joint_load4(const typename Tag::store* __restr
 // correction sums, the +inf sentinel).
 constexpr float kJointGuard = 40.0f;
 template <int UNUSED = 0>                            // (a template so that the translation units of the three storage types share one definition)
-__global__ __launch_bounds__(256) void joint_prep_kernel(float* __restrict__ rowmax, float* __restrict__ side, unsigned nside,
+static __global__ __launch_bounds__(256) void joint_prep_kernel(float* __restrict__ rowmax, float* __restrict__ side, unsigned nside,
                                                          int* __restrict__ gate, int seq, unsigned sentinel) {
     const unsigned gid = blockIdx.x * 256u + threadIdx.x;
     if (side != nullptr && gid < nside) side[gid] = 0.0f;
@@ -1198,7 +1198,7 @@ __device__ __forceinline__ Cell<float> joint_cell(const Cell<float>* __restrict_
 }
 
 template <int UNUSED = 0>                            // (as joint_prep_kernel)
-__global__ __launch_bounds__(256) void joint_sums_kernel(
+static __global__ __launch_bounds__(256) void joint_sums_kernel(
         const Cell<float>* __restrict__ rowtab, const int* __restrict__ xlen, const int* __restrict__ ylen,
         float* __restrict__ sfb, float* __restrict__ sgb, float* __restrict__ sgl, int* __restrict__ farflag,
         int maxT, int maxU, int N, const float* __restrict__ planes, int Upad) {

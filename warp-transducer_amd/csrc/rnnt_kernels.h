@@ -1181,7 +1181,7 @@ __device__ __forceinline__ void lattice_body(
 }
 
 template <typename L, int MAXW, int COLS>
-__global__ __launch_bounds__(MAXW * 64) void lattice_kernel(
+static __global__ __launch_bounds__(MAXW * 64) void lattice_kernel(
         const LogPair<L>* __restrict__ lp2, L* __restrict__ alpha, L* __restrict__ beta,
         double* __restrict__ offa, double* __restrict__ offb, double* __restrict__ ll_fwd,
         double* __restrict__ ll_bwd, L* __restrict__ costs_dev, const int* __restrict__ xlen,
@@ -1466,8 +1466,8 @@ __device__ __forceinline__ void lattice_lin_body(
     __syncthreads();
 }
 
-template <int UNUSED = 0>                            // (a template so that the two translation units share one definition)
-__global__ __launch_bounds__(kLinThreads) void lattice_lin_kernel(
+template <int UNUSED = 0>                            // (a template: defined in a header; static: every translation unit owns its copy, rnnt_gpu_impl.h)
+static __global__ __launch_bounds__(kLinThreads) void lattice_lin_kernel(
         const LogPair<float>* __restrict__ lp2, float* __restrict__ alpha, float* __restrict__ beta,
         double* __restrict__ offa, double* __restrict__ offb, double* __restrict__ ll_fwd,
         double* __restrict__ ll_bwd, float* __restrict__ costs_dev, const int* __restrict__ xlen,
@@ -1581,7 +1581,7 @@ __device__ __forceinline__ Cell<L> coef_eval(const CoefRaw<L>& r, double ll2, in
 // contiguous range of diagonals, so the partial lines of the row table combine in ONE L2.  gridDim.x is a
 // multiple of 8.  grid = (8 * ceil(D*Up/2048), N), block = 256.
 template <typename L>
-__global__ __launch_bounds__(256) void coef_cell_kernel(
+static __global__ __launch_bounds__(256) void coef_cell_kernel(
         const LogPair<L>* __restrict__ lp2, const L* __restrict__ logz, const L* __restrict__ alpha_arr,
         const L* __restrict__ beta, const double* __restrict__ offa,
         const double* __restrict__ offb, const double* __restrict__ ll_fwd,
@@ -1647,7 +1647,7 @@ __global__ __launch_bounds__(256) void coef_cell_kernel(
 #define COEF_KB 4
 #endif
 template <typename L, bool SUMS = false>   // SUMS: additive joint, the correction sums of the gradient GEMMs' epilogues (see below)
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void coef_kernel(
+static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void coef_kernel(
         const LogPair<L>* __restrict__ lp2, const L* __restrict__ logz, const L* __restrict__ alpha_arr,
         const L* __restrict__ beta, const double* __restrict__ offa,
         const double* __restrict__ offb, const double* __restrict__ ll_fwd,
@@ -1773,7 +1773,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void c
 // Debug aid (compute_rnnt_loss_lattice_dump): one sample's alpha / beta out of the skewed, base-2, re-centred workspace
 // arrays into natural (t, u) order and natural logs; the same reconstruction the coefficient kernels do (coef_fetch).
 template <typename L>
-__global__ __launch_bounds__(256) void lattice_dump_kernel(
+static __global__ __launch_bounds__(256) void lattice_dump_kernel(
         const L* __restrict__ alpha, const L* __restrict__ beta, const double* __restrict__ offa, const double* __restrict__ offb,
         const int* __restrict__ xlen, const int* __restrict__ ylen, int b, int maxT, int maxU, int Up, int lw, int lsh,
         double* __restrict__ a_out, double* __restrict__ b_out) {
@@ -1794,7 +1794,7 @@ __global__ __launch_bounds__(256) void lattice_dump_kernel(
 // [summed loss, sample count] of a shard in fp64 -- the 16-byte payload of the batch-sharded step's one collective
 // (compute_rnnt_loss_sharded).  One block of 256 threads; a marker NaN of an invalid sample propagates into the sum.
 template <typename C>
-__global__ __launch_bounds__(256) void loss_sum_kernel(const C* __restrict__ costs, int N, double* __restrict__ out2) {
+static __global__ __launch_bounds__(256) void loss_sum_kernel(const C* __restrict__ costs, int N, double* __restrict__ out2) {
     __shared__ double part[4];
     double s = 0.0;
     for (int i = threadIdx.x; i < N; i += 256) s += static_cast<double>(costs[i]);
@@ -1812,7 +1812,7 @@ __global__ __launch_bounds__(256) void loss_sum_kernel(const C* __restrict__ cos
 // needs no search (rowscale lives in the `alpha` array of the workspace, dead once the coefficients exist).
 // grid = (N, 8), block = 256.
 template <typename C>
-__global__ __launch_bounds__(256) void fill_row_scale_kernel(
+static __global__ __launch_bounds__(256) void fill_row_scale_kernel(
         const long long* __restrict__ offsets, const C* __restrict__ grad_scale, C* __restrict__ rowscale,
         long long total_rows) {
     const int b = blockIdx.x;

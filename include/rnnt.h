@@ -136,8 +136,11 @@ rnntStatus_t compute_rnnt_loss_fp64(const double* const activations,
 /* Bytes of workspace compute_rnnt_loss* needs for these dimensions, in the
  * memory space of the activations (gpu = true: device).  dtype_size is the
  * element size of the activations (2, 4 or 8).  The reference's formula
- * (src/rnnt_entrypoint.cpp:96-128) is private to it; callers always query,
- * so only the signature and the no-internal-malloc contract are kept.
+ * (src/rnnt_entrypoint.cpp:96-128: (3 T U + 2) N values) is private to it; callers always query,
+ * so only the signature and the no-internal-malloc contract are kept.  Here: five lattice values per
+ * cell of the diagonal-skewed lattice in per-sample blocks, + the part of the 16-byte-per-row coefficient
+ * table that does not overlay blocks already consumed (all of it up to 32 MB, an eighth beyond):
+ * N=64,T=1500,U=301 fp32 0.78 GB (reference 0.35), N=128,T=150,U=21 19 MB (4.8).  Monotone in every argument.
  * Replaces reference include/rnnt.h:139-143.  INVALID_VALUE on dims <= 0. */
 rnntStatus_t get_workspace_size(int maxT, int maxU,
                                 int minibatch,
@@ -307,7 +310,15 @@ rnntStatus_t compute_rnnt_loss_likelihoods(const void* workspace,
  * natural logs, alpha(t,u) = log P(y_1..u emitted by time t), beta(t,u) as in include/detail/gpu_rnnt_kernel.h:79-113
  * (beta(0,0) = log P(y|x)); cells outside the sample's T_b x U_b lattice are NaN.  The workspace's private layout (diagonal-skewed,
  * base-2, re-centred per chunk with fp64 offsets) is undone here so that no caller has to know it.  input_lengths /
- * label_lengths: the device arrays of the call.  Enqueue only (one small kernel on options.stream), nothing allocated. */
+ * label_lengths: the device arrays of the call.  Enqueue only (one small kernel on options.stream), nothing allocated.
+ * WHICH SAMPLES ARE STILL THERE.  The record table of the gradient stage overlays the lattice data of the samples in front
+ * of the ones being processed (that is what keeps the workspace at 2.2x the reference's instead of 3.4x on long utterances).
+ * After a call that computed the coefficient table (gradients != NULL, or compute_rnnt_loss_fwd with prepare_backward != 0)
+ * whose table exceeds 32 MB, the FIRST samples of the batch have lost their alpha / beta: for those the two arrays come back
+ * all NaN.  Every sample is intact after a score-only call (gradients == NULL / prepare_backward == 0: same alpha, and a
+ * score-only call runs no beta sweep: beta is undefined then) -- and in any call whose record table is at most 32 MB
+ * (T * U * minibatch <= 2 M cells for an fp32 lattice): debugging shapes.  The likelihoods of
+ * compute_rnnt_loss_likelihoods are kept for every sample in every case. */
 rnntStatus_t compute_rnnt_loss_lattice_dump(const void* workspace,
                                             const int* const label_lengths,
                                             const int* const input_lengths,

@@ -34,7 +34,7 @@ def test_operand_role_holds_only_its_own_memory_instructions(device_asm):
 def test_guard_trips_on_a_planted_instruction(device_asm):
     guard, asm = device_asm
     lines = asm.split("\n")
-    start = next(i for i, l in enumerate(lines) if l.startswith("_ZN4rnnt18lattice_lin_kernel") and ":" in l)
+    start = next(i for i, l in enumerate(lines) if (l.startswith("_ZN4rnnt18lattice_lin_kernel") or l.startswith("_ZN4rnntL18lattice_lin_kernel")) and ":" in l)
     waits = [i for i in range(start, len(lines)) if "vmcnt(%d)" % ((guard.PFD - 1) * guard.KW) in lines[i]]
     for where, what in ((waits[2] + 5, "\tglobal_load_dword v99, v98, s[0:1]"), (waits[11] + 3, "\tscratch_load_dword v7, off, s32")):
         bad = list(lines)

@@ -373,13 +373,13 @@ rnntStatus_t compute_rnnt_loss_lattice_dump(const void* workspace, const int* co
         if (!make_plan(p, A, minibatch, options, const_cast<void*>(workspace), nullptr, label_lengths, input_lengths, static_cast<double*>(nullptr)))
             return RNNT_STATUS_INVALID_VALUE;
         hipLaunchKernelGGL((lattice_dump_kernel<double>), grid, dim3(256), 0, p.stream, p.alpha, p.beta, p.offa, p.offb, input_lengths,
-                           label_lengths, sample, p.maxT, p.maxU, p.Up, p.lat_w, p.lat_sh, alpha_device, beta_device);
+                           label_lengths, sample, p.maxT, p.maxU, p.Up, p.lat_w, p.lat_sh, alpha_device, beta_device, p.padflag + 2);
     } else {
         Plan<float> p;
         if (!make_plan(p, A, minibatch, options, const_cast<void*>(workspace), nullptr, label_lengths, input_lengths, static_cast<float*>(nullptr)))
             return RNNT_STATUS_INVALID_VALUE;
         hipLaunchKernelGGL((lattice_dump_kernel<float>), grid, dim3(256), 0, p.stream, p.alpha, p.beta, p.offa, p.offb, input_lengths,
-                           label_lengths, sample, p.maxT, p.maxU, p.Up, p.lat_w, p.lat_sh, alpha_device, beta_device);
+                           label_lengths, sample, p.maxT, p.maxU, p.Up, p.lat_w, p.lat_sh, alpha_device, beta_device, p.padflag + 2);
     }
     return hipGetLastError() == hipSuccess ? RNNT_STATUS_SUCCESS : RNNT_STATUS_EXECUTION_FAILED;
 }

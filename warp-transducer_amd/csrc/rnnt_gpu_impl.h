@@ -176,7 +176,7 @@ static void launch_grad(Plan<typename Tag::comp>& p, const typename Tag::store* 
         using CC = typename Tag::comp;
         CC* rowscale = nullptr;
         if (packed && grad_scale) {
-            rowscale = reinterpret_cast<CC*>(p.alpha);
+            rowscale = p.rowscale;                 // (lattice blocks that are dead by now: make_layout)
             hipLaunchKernelGGL((fill_row_scale_kernel<CC>), dim3(p.N, 8), dim3(256), 0, p.stream, p.offsets, grad_scale,
                                rowscale, static_cast<long long>(p.packed_rows));
         }
@@ -332,16 +332,17 @@ inline bool aux_prepare() {
 // samples [b0, b0 + n) of plan p as a plan of their own
 template <typename C> static Plan<C> sub_plan(const Plan<C>& p, int b0, int n) {
     Plan<C> q = p;
-    const size_t Dp = lat_rows(p.maxT, p.maxU), sk = static_cast<size_t>(b0) * Dp * p.Up;
+    const size_t Dp = lat_rows(p.maxT, p.maxU), sk = lat_sample(b0, p.maxT, p.maxU, p.Up), skp = lat_sample_pair(b0, p.maxT, p.maxU, p.Up);
     q.N = n;
+    q.first_sample = p.first_sample + b0;
     q.labels = p.labels + static_cast<size_t>(b0) * (p.maxU - 1);
     q.input_lengths = p.input_lengths + b0;
     q.label_lengths = p.label_lengths + b0;
-    q.lp2 = p.lp2 + sk; q.logz = p.logz + sk; q.alpha = p.alpha + sk; q.beta = p.beta + sk;
+    q.lp2 = p.lp2 + skp; q.logz = p.logz + sk; q.alpha = p.alpha + sk; q.beta = p.beta + sk;   // (per-sample blocks: rnnt_kernels.h, lat_block)
     q.rowtab = p.rowtab + static_cast<size_t>(b0) * p.cells_per_sample;
     q.offa = p.offa + static_cast<size_t>(b0) * p.lat_w * Dp;
     q.offb = p.offb + static_cast<size_t>(b0) * p.lat_w * Dp;
-    q.llf = p.llf + b0; q.llb = p.llb + b0; q.poison = p.poison + b0;
+    q.llf = p.llf + b0; q.llb = p.llb + b0; q.poison = p.poison + b0; q.coef_done = p.coef_done + kCoefDoneStride * static_cast<size_t>(b0);
     q.costs_dev = p.costs_dev + b0;
     return q;
 }

@@ -28,7 +28,29 @@ static inline size_t align_up(size_t x) { return (x + kAlign - 1) / kAlign * kAl
 
 struct Layout {
     size_t lp2, logz, alpha, rowtab, beta, offa, offb, llf, llb, costs, padflag, poison, rowmax, side, side_bytes, wmat, total;
+    size_t rowscale;         // packed layout with per-sample scales: one scale per packed row, for the gradient kernel (dead lattice blocks by then)
+    size_t coef_done;        // per sample: tiles of the coefficient kernel that have finished reading its block (the overlay guard of coef_kernel)
+    int group;               // samples whose records fit the head (N: the record table overlays nothing)
 };
+
+// The record table (16 B per row of the tensor for an fp32 lattice, written by the coefficient kernel, read by the gradient
+// kernel) is ONE contiguous array at the front of the workspace -- and it OVERLAYS the lattice side data: the per-sample
+// blocks [lp2 | logz | alpha | beta] (lat_block) start `head` bytes in.  The records of sample s end at rec * (s + 1) <=
+// head + s * block -- the start of block s -- because head >= rec and a sample's records are smaller than its block
+// (rec = 4 lat T U < 5 lat Dp Up): they can only fall on blocks of EARLIER samples, about 0.65 (s - head / rec) of them on
+// long utterances.  Those must be dead -- read by every coefficient tile that needs them -- before the records are stored:
+//   * the tiled coefficient kernel (maxU > 48) stays ONE launch, sample-major, and guards the overlay itself: a tile
+//     announces the end of its reads in a per-sample counter and waits, before storing, for the tiles of the samples its
+//     records can touch (coef_kernel; they were dispatched thousands of workgroups earlier: the wait is a formality);
+//   * the cell-per-thread form (small lattices, many samples) runs in groups of `group` samples, launch after launch: when
+//     group [s, s + m) runs every block below s is dead and its records end below head + s * block (head >= rec * m).
+// Padded and packed layout alike (packed rows only come earlier); one-call, two-phase and two-half forms (each half's
+// coefficient kernel runs in stream order behind the other half's coefficient and gradient kernels).
+// The workspace is head + N blocks instead of records + N blocks: c4 (N=64, T=1500, U=301) 1.18 -> 0.77 GB against the
+// reference's 0.35 (src/rnnt_entrypoint.cpp:96-128: three words per cell).  Small problems keep ONE group (one launch): the
+// head is the whole table below kOneGroupBytes, never less than that above it (get_workspace_size stays monotone).
+constexpr size_t kOneGroupBytes = 32u << 20;
+constexpr int kCoefGroups = 8;
 
 // lat = bytes of one lattice value (4: fp32 lattice for 16/32-bit activations, 8: fp64).
 // joint: also the additive-joint planes (get_workspace_size_add); they sit BEHIND everything the
@@ -37,20 +59,38 @@ static Layout make_layout(int maxT, int maxU, int N, size_t lat, bool joint) {
     const size_t D = lat_rows(maxT, maxU);      // diagonals + padding rows
     const size_t Up = lat_stride(maxU);         // row stride of the skewed arrays
     const size_t W = (Up + 63) / 64;            // wavefronts of a lattice block at one column per lane
-    const size_t sk = D * Up * N;               // skewed lattice cells
+    const size_t block = lat_block(maxT, maxU, static_cast<int>(Up)) * lat;      // one sample's [lp2 | logz | alpha | beta], bytes
+    const size_t rec1 = static_cast<size_t>(maxT) * maxU * 4 * lat;              // one sample's records, bytes
+    const size_t recs = rec1 * N;
     Layout l{};
-    size_t o = 0;
-    l.lp2 = o;   o = align_up(o + sk * 2 * lat);
-    l.logz = o;  o = align_up(o + sk * lat);
-    l.alpha = o; o = align_up(o + sk * lat);
-    l.rowtab = o; o = align_up(o + static_cast<size_t>(maxT) * maxU * N * 4 * lat);
-    l.beta = o;  o = align_up(o + (sk + Up + 64) * lat);
+    // head of the workspace = the part of the record table no block lies under
+    size_t head = recs;
+    l.group = N;
+    if (recs > kOneGroupBytes) {
+        head = (recs + kCoefGroups - 1) / kCoefGroups;
+        if (head < kOneGroupBytes) head = kOneGroupBytes;
+        if (head < rec1) head = rec1;
+        l.group = static_cast<int>(head / rec1);        // >= 1
+        if (l.group > N) l.group = N;
+    }
+    head = align_up(head);
+    l.rowtab = 0;
+    l.lp2 = head;
+    l.logz = head + lat_block_logz(maxT, maxU, static_cast<int>(Up)) * lat;
+    l.alpha = head + lat_block_alpha(maxT, maxU, static_cast<int>(Up)) * lat;
+    l.beta = head + lat_block_beta(maxT, maxU, static_cast<int>(Up)) * lat;
+    size_t o = align_up(head + block * N);
+    // one scale per packed row (packed layout with grad_scale): behind the record table's last possible row, inside blocks
+    // that are dead when the gradient stage starts (5 lat T U N <= head + N block)
+    l.rowscale = align_up(recs);
+    if (l.rowscale + static_cast<size_t>(maxT) * maxU * N * lat > o) o = align_up(l.rowscale + static_cast<size_t>(maxT) * maxU * N * lat);   // (cannot happen: kept as a guard)
     l.offa = o;  o = align_up(o + D * W * N * sizeof(double));
     l.offb = o;  o = align_up(o + (D * W * N + D) * sizeof(double));
     l.llf = o;   o = align_up(o + N * sizeof(double));
     l.llb = o;   o = align_up(o + N * sizeof(double));
     l.costs = o; o = align_up(o + N * sizeof(double));
-    l.padflag = o; o = align_up(o + sizeof(int));   // "some record of this batch is padding": zeroed by the lattice kernel, set by the coefficient kernel, read by the gradient kernel
+    l.coef_done = o; o = align_up(o + kCoefDoneStride * static_cast<size_t>(N) * sizeof(int));
+    l.padflag = o; o = align_up(o + 4 * sizeof(int));   // [0] "some record of this batch is padding": zeroed by the lattice kernel, set by the coefficient kernel, read by the gradient kernel; [1] the same for the second half of a two-half call; [2] samples whose lattice block the record table has overlaid (lattice dump)
     l.poison = o; o = align_up(o + N * sizeof(int));   // per sample: the statistics kernels' hint of a row with a non-finite log Z (rnnt_kernels.h: note_non_finite)
     // additive joint only: row maxima of f and g, dense matrices W, CB, CL (row stride = maxU rounded up to 8)
     l.rowmax = o; l.wmat = o; l.side = o; l.side_bytes = 0;
@@ -214,7 +254,8 @@ static void ranges_mark(int i, bool do_fwd, bool do_bwd, const char* const names
 // t2ord = tile order of the 2-D statistics kernel: 0 an eighth of the batch per XCD, 1 plain, 2 an eighth of each sample per XCD.
 struct Tune { int sw = 4, nta = 1, gmax = 4194304, rows = 0, tile = 1, tilekb = 52, ppt = 2;
               int jfnk = 0, jfpf = 1, jgnk = 0, jgpf = 1, blk = 1, jzs = 0, xcd = 1, ctile = 1, pskip = 1, joh = -1;
-              int lat2 = -1, xst = 0, jsamp = 1, tilemax = kTileMaxRowBytes, j16 = 7, j16pf = 1, j16nt = 4, tile2d = 2, latlin = 1, pskipb = 8192, pskipmin = 128, jfsum = 1, jsplit = 1, jnocb = 1, t2ord = 2; };
+              int lat2 = -1, xst = 0, jsamp = 1, tilemax = kTileMaxRowBytes, j16 = 7, j16pf = 1, j16nt = 4, tile2d = 2, latlin = 1, pskipb = 8192, pskipmin = 128, jfsum = 1, jsplit = 1, jnocb = 1, t2ord = 2;
+              int ovg = 2; };   // ovg (dev): overlay guard of the tiled coefficient kernel: 0 none (UNSAFE: timing only), 1 announce only (UNSAFE), 2 announce + wait
 #ifdef RNNT_DEV
 static Tune read_tune() {
     Tune t;
@@ -225,7 +266,7 @@ static Tune read_tune() {
         {"tilekb", &t.tilekb}, {"ppt", &t.ppt}, {"jfnk", &t.jfnk}, {"jfpf", &t.jfpf}, {"jgnk", &t.jgnk},
         {"jgpf", &t.jgpf}, {"blk", &t.blk}, {"jzs", &t.jzs}, {"xcd", &t.xcd}, {"ctile", &t.ctile},
         {"pskip", &t.pskip}, {"joh", &t.joh}, {"lat2", &t.lat2}, {"xst", &t.xst}, {"jsamp", &t.jsamp}, {"tilemax", &t.tilemax},
-        {"j16", &t.j16}, {"j16pf", &t.j16pf}, {"j16nt", &t.j16nt}, {"tile2d", &t.tile2d}, {"latlin", &t.latlin}, {"pskipb", &t.pskipb}, {"pskipmin", &t.pskipmin}, {"jfsum", &t.jfsum}, {"jsplit", &t.jsplit}, {"jnocb", &t.jnocb}, {"t2ord", &t.t2ord}};
+        {"j16", &t.j16}, {"j16pf", &t.j16pf}, {"j16nt", &t.j16nt}, {"tile2d", &t.tile2d}, {"latlin", &t.latlin}, {"pskipb", &t.pskipb}, {"pskipmin", &t.pskipmin}, {"jfsum", &t.jfsum}, {"jsplit", &t.jsplit}, {"jnocb", &t.jnocb}, {"t2ord", &t.t2ord}, {"ovg", &t.ovg}};
     // tokens are separated by ',', a token is key=value with the WHOLE key compared
     for (const char* p = e; *p;) {
         const char* end = strchr(p, ',');
@@ -260,7 +301,13 @@ template <typename C> struct Plan {
     int cells_per_sample;          // maxT * maxU
     hipStream_t stream;
     const int *labels, *input_lengths, *label_lengths;
-    LogPair<C>* lp2; C *logz, *alpha, *beta; Cell<C>* rowtab;
+    LogPair<C>* lp2; C *logz, *alpha, *beta; Cell<C>* rowtab;     // lp2 .. beta: SAMPLE 0's arrays; sample b's are lat_sample(b) values on (lp2: lat_sample_pair)
+    C* rowscale = nullptr;         // packed layout with per-sample scales (launch_grad)
+    int coef_group = 0;            // samples per coefficient launch of the cell-per-thread form (make_layout)
+    bool overlay = false;          // the record table reaches into the lattice blocks (whole batch's layout)
+    int* coef_done = nullptr;      // the tiled coefficient kernel's per-sample counters (overlay guard)
+    int first_sample = 0;          // a half of the two-half schedule: its first sample in the whole batch (the overlay bookkeeping is global)
+    size_t head_bytes = 0, block_bytes = 0;
     double *offa, *offb, *llf, *llb;
     int* padflag;
     int* poison;
@@ -309,6 +356,12 @@ static bool make_plan(Plan<C>& p, int A, int N, const rnntOptions& opt, void* wo
     p.alpha = reinterpret_cast<C*>(ws + lay.alpha);
     p.rowtab = reinterpret_cast<Cell<C>*>(ws + lay.rowtab);
     p.beta = reinterpret_cast<C*>(ws + lay.beta);
+    p.rowscale = reinterpret_cast<C*>(ws + lay.rowscale);
+    p.coef_group = lay.group;
+    p.overlay = lay.group < N;
+    p.coef_done = reinterpret_cast<int*>(ws + lay.coef_done);
+    p.head_bytes = lay.lp2;
+    p.block_bytes = lat_block(p.maxT, p.maxU, p.Up) * sizeof(C);
     p.offa = reinterpret_cast<double*>(ws + lay.offa);
     p.offb = reinterpret_cast<double*>(ws + lay.offb);
     p.llf = reinterpret_cast<double*>(ws + lay.llf);
@@ -349,7 +402,7 @@ template <typename C> static void launch_lattice(Plan<C>& p, bool with_beta) {
 #define RNNT_LATTICE(MW, CC)                                                                                     \
     hipLaunchKernelGGL((lattice_kernel<C, MW, CC>), dim3(p.N * dirs), dim3(p.lat_w * 64), 0, p.stream, p.lp2,          \
                        p.alpha, p.beta, p.offa, p.offb, p.llf, p.llb, p.costs_dev, p.input_lengths, p.label_lengths,  \
-                       p.maxT, p.maxU, p.Up, dirs, p.padflag, p.logz, p.poison)
+                       p.maxT, p.maxU, p.Up, dirs, p.padflag, p.logz, p.poison, p.coef_done)
     // One-wavefront fp32 lattices with at most one block per compute unit: the linear-domain chain with helper wavefronts
     // (range guard + log-domain fallback inside).  Its eight wavefronts per (sample, direction) buy latency with idle
     // SIMDs; past one block per CU there are none and the one-wavefront kernel is the faster again (N=128 T=200 U=41:
@@ -358,7 +411,7 @@ template <typename C> static void launch_lattice(Plan<C>& p, bool with_beta) {
         if constexpr (sizeof(C) == 4)
             hipLaunchKernelGGL((lattice_lin_kernel<0>), dim3(p.N * dirs), dim3(kLinThreads), 0, p.stream, p.lp2, p.alpha, p.beta, p.offa, p.offb,
                                p.llf, p.llb, p.costs_dev, p.input_lengths, p.label_lengths, p.maxT, p.maxU, p.Up, dirs,
-                               tune().latlin == 2 ? 1 : 0, p.padflag, p.logz, p.poison);
+                               tune().latlin == 2 ? 1 : 0, p.padflag, p.logz, p.poison, p.coef_done);
     }
     else if (p.Up <= 64) RNNT_LATTICE(1, 1);                       // one wavefront, no synchronisation
     else if (p.lat_cols == 1) RNNT_LATTICE(8, 1);                  // maxU <= 512, one column per lane
@@ -383,32 +436,50 @@ template <typename C> static bool launch_coef(Plan<C>& p, bool joint = false, bo
     // the tiled kernel forming the sums itself: nothing reads cb per cell (joint_df_kernel<..., BS> and the epilogue form both take
     // the row sums) nor the records -- W and CL only, whatever the vocabulary
     if (coef_is_tiled(p) && sums != nullptr && joint_planes_onehot(p.maxU) == 4 && tune().jnocb) planes = 5;
+    // Launches of at most `coef_group` samples, in stream order: the records of a group overlay the lattice blocks of the
+    // samples in front of it, which are dead by then (make_layout).  `recycled`: how many blocks, counted from sample 0 of
+    // the WHOLE batch, lie under the records written so far -- left in the workspace for compute_rnnt_loss_lattice_dump.
+    const int step = p.overlay && p.coef_group > 0 && p.coef_group < kGridSamples ? p.coef_group : kGridSamples;   // (cell-per-thread form only)
+    const size_t rec1 = static_cast<size_t>(p.cells_per_sample) * sizeof(Cell<C>);
+    auto recycled_after = [&](int b_end) -> int {          // b_end: samples of this plan processed, exclusive
+        const size_t end = rec1 * (static_cast<size_t>(p.first_sample) + b_end);
+        if (end <= p.head_bytes || p.block_bytes == 0) return 0;
+        return static_cast<int>((end - p.head_bytes + p.block_bytes - 1) / p.block_bytes);
+    };
     if (!coef_is_tiled(p)) {
         // small lattices: one thread per skewed cell, scattered record store
         const long long skew_cells = static_cast<long long>(p.maxT + p.maxU - 1) * ((p.Up + 63) / 64) * 64;   // whole 64-column segments
-        for (int b0 = 0; b0 < p.N; b0 += kGridSamples) {       // (samples on gridDim.y: slices of the batch)
-            const dim3 cgrid(static_cast<unsigned>(((skew_cells + 255) / 256 + 7) / 8 * 8),    // multiple of 8: XCD-aware remap
-                             p.N - b0 < kGridSamples ? p.N - b0 : kGridSamples);
+        for (int b0 = 0; b0 < p.N; b0 += step) {       // (samples on gridDim.y: slices of the batch)
+            const int nb = p.N - b0 < step ? p.N - b0 : step;
+            const dim3 cgrid(static_cast<unsigned>(((skew_cells + 255) / 256 + 7) / 8 * 8), nb);    // multiple of 8: XCD-aware remap
             hipLaunchKernelGGL((coef_cell_kernel<C>), cgrid, dim3(256), 0, p.stream, p.lp2, p.logz, p.alpha, p.beta, p.offa,
                                p.offb, p.llf, p.labels, p.input_lengths, p.label_lengths, p.rowtab, p.maxT, p.maxU, p.Up,
-                               wmat, Upad, p.fastemit, planes, p.offsets, p.lat_w, p.lat_sh, b0, p.N, p.padflag);
+                               wmat, Upad, p.fastemit, planes, p.offsets, p.lat_w, p.lat_sh, b0, p.N, p.padflag, recycled_after(b0 + nb));
         }
     } else {
         const int DN = sizeof(C) == 4 ? 32 : 16;           // diagonals per tile (coef_kernel)
         const int tilesU = (p.maxU + 63) / 64, tilesN = (p.maxT + p.maxU - 1 + DN - 1) / DN;
-        for (int b0 = 0; b0 < p.N; b0 += kGridSamples) {
-            const dim3 cgrid(static_cast<unsigned>(tilesU * tilesN), p.N - b0 < kGridSamples ? p.N - b0 : kGridSamples);
+        // ONE launch (slices of 65535 samples), the overlay guarded inside the kernel
+        int* const done = (p.overlay && tune().ovg != 0) ? p.coef_done : nullptr;
+        const unsigned long long head_arg = tune().ovg == 1 ? (~0ull >> 1) : static_cast<unsigned long long>(p.head_bytes);   // (dev, ovg = 1: nobody waits)
+        const int slice = 0x7fffffff / (tilesU * tilesN) < kGridSamples ? 0x7fffffff / (tilesU * tilesN) : kGridSamples;   // samples per launch (grid limit)
+        for (int b0 = 0; b0 < p.N; b0 += slice) {
+            const int nb = p.N - b0 < slice ? p.N - b0 : slice;
+            const int recycled = recycled_after(b0 + nb);
+            const dim3 cgrid(static_cast<unsigned>(tilesU * tilesN) * static_cast<unsigned>(nb));   // one-dimensional, sample-major (coef_kernel)
             if (sums != nullptr)
                 hipLaunchKernelGGL((coef_kernel<C, true>), cgrid, dim3(256), 0, p.stream, p.lp2, p.logz, p.alpha, p.beta, p.offa,
                                    p.offb, p.llf, p.labels, p.input_lengths, p.label_lengths, p.rowtab, p.maxT, p.maxU, p.Up,
                                    wmat, Upad, tilesU, p.fastemit, planes, p.offsets, p.lat_w, p.lat_sh, b0, p.N, p.padflag,
-                                   sums->sfb, sums->sgb, sums->sgl, sums->farflag);
+                                   sums->sfb, sums->sgb, sums->sgl, sums->farflag, recycled, done, static_cast<unsigned long long>(rec1),
+                                   head_arg, static_cast<unsigned long long>(p.block_bytes), p.first_sample);
             else
                 hipLaunchKernelGGL((coef_kernel<C, false>), cgrid, dim3(256), 0, p.stream, p.lp2, p.logz, p.alpha, p.beta, p.offa,
                                    p.offb, p.llf, p.labels, p.input_lengths, p.label_lengths, p.rowtab, p.maxT, p.maxU, p.Up,
                                    wmat, Upad, tilesU, p.fastemit, planes, p.offsets, p.lat_w, p.lat_sh, b0, p.N, p.padflag,
                                    static_cast<float*>(nullptr), static_cast<float*>(nullptr), static_cast<float*>(nullptr),
-                                   static_cast<int*>(nullptr));
+                                   static_cast<int*>(nullptr), recycled, done, static_cast<unsigned long long>(rec1),
+                                   head_arg, static_cast<unsigned long long>(p.block_bytes), p.first_sample);
         }
         p.check();
         return sums != nullptr;

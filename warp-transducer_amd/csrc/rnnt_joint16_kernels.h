@@ -641,7 +641,7 @@ __global__ __launch_bounds__(S == 1 ? 256 : S * 64) void joint_z16_kernel(
         rec.y = has_lab ? fmaxf(__builtin_fmaf(flb[i], l2e, -mtv[i]) + glab - lz2, log_zero<float>())
                         : log_zero<float>();
         const size_t idx = lat_index(b, t + u, u, maxT, maxU, Up);
-        lp2[idx] = rec;
+        lp2[lat_pair_index(b, t + u, u, maxT, maxU, Up)] = rec;
         logz[idx] = lz;
         note_non_finite(poison, b, t + u, u, Up, lz);
     };

@@ -505,7 +505,7 @@ __global__ __launch_bounds__(S == 1 ? 256 : S * 64) void joint_z_kernel(
         rec.y = has_lab ? fmaxf(__builtin_fmaf(flb[i], l2e, -mtv[i]) + glab - lz2, log_zero<float>())
                         : log_zero<float>();
         const size_t idx = lat_index(b, t + u, u, maxT, maxU, Up);
-        lp2[idx] = rec;
+        lp2[lat_pair_index(b, t + u, u, maxT, maxU, Up)] = rec;
         logz[idx] = lz;
         note_non_finite(poison, b, t + u, u, Up, lz);
     };
@@ -723,7 +723,7 @@ __global__ __launch_bounds__(256) void joint_z_small_kernel(
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     // ... and leave along the anti-diagonals: diagonal d of the tile is cells (t0 + d - j, u0 + j), adjacent in j
-    const size_t base = lat_index(b, t0 + u0, u0, maxT, maxU, Up);
+    const size_t base = lat_index(b, t0 + u0, u0, maxT, maxU, Up), pbase = lat_pair_index(b, t0 + u0, u0, maxT, maxU, Up);
 #pragma unroll 4
     for (int it = 0; it < 32; ++it) {
         const int d = 2 * it + half, tl = d - col;
@@ -732,7 +732,7 @@ __global__ __launch_bounds__(256) void joint_z_small_kernel(
             LogPair<float> rec;
             rec.x = px[tl * kJointZOutPad + col];
             rec.y = py[tl * kJointZOutPad + col];
-            lp2[idx] = rec;
+            lp2[pbase + static_cast<size_t>(d) * Up + col] = rec;
             const float lz = pz[tl * kJointZOutPad + col];
             logz[idx] = lz;
             note_non_finite(poison, b, t0 + u0 + d, col + u0, Up, lz);

@@ -23,8 +23,11 @@
 //   include/detail/gpu_rnnt_kernel.h:143-179 + gpu_rnnt.h:107-110 (gradient kernel + memset)
 //
 // Lattice side data lives in the caller's workspace in a DIAGONAL-SKEWED layout:
-//   cell(b, t, u) -> ((b * Dp + kLatPad + (t + u)) * Up + u),  Dp = maxT + maxU - 1 + 2*kLatPad,
+//   cell(b, t, u) -> (kLatPad + (t + u)) * Up + u  inside sample b's array,  Dp = maxT + maxU - 1 + 2*kLatPad rows,
 //   Up = 8*ceil(maxU/8)                                           (lat_index below)
+// and, since round 6, in PER-SAMPLE BLOCKS [lp2 | logz | alpha | beta] (lat_block): a sample's side data is one contiguous
+// piece of the workspace, which is dead as a whole once its coefficient records exist -- the record table of later samples
+// overlays it (rnnt_host.h, make_layout).
 // so that the lanes of the lattice wavefront (consecutive u on one anti-diagonal t+u = n)
 // touch consecutive addresses.  All indices are 64-bit (the reference's are 32-bit int:
 // gpu_rnnt_kernel.h:7-8,161,174).
@@ -34,7 +37,7 @@
 
 namespace rnnt {
 
-// Skewed lattice arrays (structure of arrays, dense rows of Up values):
+// Skewed lattice arrays (per sample a structure of arrays, dense rows of Up values):
 //   lp2   : {x = log2 p(blank|t,u), y = log2 p(y_u|t,u)}   written by the row-stats pass
 //   logz  : natural-log partition function of the row        written by the row-stats pass
 //   alpha : scaled forward variable (base 2)                 written by the lattice kernel
@@ -92,6 +95,10 @@ __device__ __forceinline__ void coef_lens(const int* __restrict__ xlen, const in
     Ub = bad ? 0 : U;
 }
 
+// Overlay guard of coef_kernel: per sample two words -- tiles that have finished reading the sample's lattice block, and
+// "the sample may store" -- each in a 128-byte line of its own (ints apart).  Packed into four lines, the 18 240 announcements
+// and as many coherent looks of a c4 call queued up at the memory side: the kernel took 1.1 ms instead of 0.28.
+constexpr int kCoefDoneStride = 64;
 // Kernels that put the samples on gridDim.y are launched in slices of at most kGridSamples samples (the hardware
 // limit of that dimension is 65535; the reference puts the samples on gridDim.x, gpu_rnnt.h:127-128, and so takes
 // any batch size): `b0` = first sample of the slice.
@@ -102,9 +109,25 @@ constexpr int kLatPad = 16;
 // were padded to whole 64-lane wavefronts, which tripled the lattice workspace at U = 21.
 __host__ __device__ inline int lat_stride(int maxU) { return (maxU + 7) & ~7; }
 __host__ __device__ inline size_t lat_rows(int maxT, int maxU) { return static_cast<size_t>(maxT) + maxU - 1 + 2 * kLatPad; }
-// element index of (b, n, u) in a skewed array with row stride Up
+// Lattice VALUES in one sample's block [lp2: 2 per cell | logz | alpha | beta + the rows its readers overshoot]; a multiple of
+// 64 values, so that every block (and every array inside it: Dp * Up is a multiple of 8) starts on a 256-byte boundary in fp32
+__host__ __device__ inline size_t lat_block(int maxT, int maxU, int Up) {
+    return (5 * lat_rows(maxT, maxU) * static_cast<size_t>(Up) + Up + 64 + 63) & ~static_cast<size_t>(63);
+}
+// offsets (in values) of the four arrays inside a block
+__host__ __device__ inline size_t lat_block_logz(int maxT, int maxU, int Up) { return 2 * lat_rows(maxT, maxU) * static_cast<size_t>(Up); }
+__host__ __device__ inline size_t lat_block_alpha(int maxT, int maxU, int Up) { return 3 * lat_rows(maxT, maxU) * static_cast<size_t>(Up); }
+__host__ __device__ inline size_t lat_block_beta(int maxT, int maxU, int Up) { return 4 * lat_rows(maxT, maxU) * static_cast<size_t>(Up); }
+// first element of sample b in a VALUE array (logz, alpha, beta: the pointer addresses sample 0's array) ...
+__host__ __device__ inline size_t lat_sample(int b, int maxT, int maxU, int Up) { return static_cast<size_t>(b) * lat_block(maxT, maxU, Up); }
+// ... and in the PAIR array lp2 (elements of two values: half the stride)
+__host__ __device__ inline size_t lat_sample_pair(int b, int maxT, int maxU, int Up) { return static_cast<size_t>(b) * (lat_block(maxT, maxU, Up) >> 1); }
+// element index of (b, n, u) in a value array / in lp2, row stride Up
 __host__ __device__ inline size_t lat_index(int b, int n, int u, int maxT, int maxU, int Up) {
-    return (static_cast<size_t>(b) * lat_rows(maxT, maxU) + kLatPad + n) * Up + u;
+    return lat_sample(b, maxT, maxU, Up) + static_cast<size_t>(kLatPad + n) * Up + u;
+}
+__host__ __device__ inline size_t lat_pair_index(int b, int n, int u, int maxT, int maxU, int Up) {
+    return lat_sample_pair(b, maxT, maxU, Up) + static_cast<size_t>(kLatPad + n) * Up + u;
 }
 
 // NON-FINITE ROW STATISTICS.  A NaN or +inf logit (or a row of -inf only) makes log Z of its row non-finite, and the
@@ -284,7 +307,7 @@ __global__ __launch_bounds__(WAVES * 64) void row_stats_kernel(
         rec.x = vmax((xb - logZ) * C(kLog2e), log_zero<C>());
         rec.y = has_lab ? vmax((xl - logZ) * C(kLog2e), log_zero<C>()) : log_zero<C>();
         const size_t idx = lat_index(b, t + u, u, maxT, maxU, Up);
-        lp2[idx] = rec;
+        lp2[lat_pair_index(b, t + u, u, maxT, maxU, Up)] = rec;
         logz[idx] = logZ;
         note_non_finite(poison, b, t + u, u, Up, logZ);
     }
@@ -375,7 +398,7 @@ __global__ __launch_bounds__(256) void row_stats_block_kernel(
         rec.x = vmax((xb - logZ) * C(kLog2e), log_zero<C>());
         rec.y = has_lab ? vmax((xl - logZ) * C(kLog2e), log_zero<C>()) : log_zero<C>();
         const size_t idx = lat_index(b, t + u, u, maxT, maxU, Up);
-        lp2[idx] = rec;
+        lp2[lat_pair_index(b, t + u, u, maxT, maxU, Up)] = rec;
         logz[idx] = logZ;
         note_non_finite(poison, b, t + u, u, Up, logZ);
     }
@@ -627,14 +650,15 @@ __global__ __launch_bounds__(256) void row_stats_tile_kernel(
         rec.y = has_lab ? vmax((load1<Tag>(rowp + lab) - logZ) * C(kLog2e), log_zero<C>()) : log_zero<C>();
         // two scattered stores per row: they combine into full lines in the XCD's L2 (tile order above)
         const size_t idx = lat_index(b, t + u, u, maxT, maxU, Up);
+        const size_t pidx = lat_pair_index(b, t + u, u, maxT, maxU, Up);
 #ifdef RNNT_DEV
         // development build only (RNNT_TUNE=xst=..): timing experiments on the result stores, results are WRONG
         const int xst = xcd_remap >> 4;
-        if (xst == 1) { reinterpret_cast<Cell<C>*>(lp2)[idx] = Cell<C>{rec.x, rec.y, logZ, C(0)}; return; }   // one 16-byte record
+        if (xst == 1) { reinterpret_cast<Cell<C>*>(lp2)[pidx >> 1] = Cell<C>{rec.x, rec.y, logZ, C(0)}; return; }   // one 16-byte record
         if (xst == 2) { const size_t nat = r0 + rl; lp2[nat] = rec; logz[nat] = logZ; return; }              // natural order
         if (xst == 3) { if (rec.x == C(12345)) logz[idx] = logZ; return; }                                   // no stores
 #endif
-        lp2[idx] = rec;
+        lp2[pidx] = rec;
         logz[idx] = logZ;
         note_non_finite(poison, b, t + u, u, Up, logZ);
     }
@@ -777,7 +801,7 @@ __global__ __launch_bounds__(256) void row_stats_tile2d_kernel(
         if (slot < NSLOT && j >= 0 && j < nu && i < nt) {
             const size_t idx = lat_index(b, t0 + u0 + d, u0 + j, maxT, maxU, Up);
             const C lz = out_lz[i][j];
-            lp2[idx] = out_lp[i][j];
+            lp2[lat_pair_index(b, t0 + u0 + d, u0 + j, maxT, maxU, Up)] = out_lp[i][j];
             logz[idx] = lz;
             note_non_finite(poison, b, t0 + u0 + d, u0 + j, Up, lz);
         }
@@ -946,11 +970,11 @@ __device__ __forceinline__ void lattice_body(
     const int Db = Tb + Ub - 1;
     const size_t Dp = lat_rows(maxT, maxU);
     // descriptors start at the first PAD row of this sample: row n lives at (n + kLatPad)
-    const size_t sample0 = static_cast<size_t>(b) * Dp * Up;
+    const size_t sample0 = lat_sample(b, maxT, maxU, Up);             // (value arrays; lp2 has half the element stride)
     const int cell_row = Up * static_cast<int>(sizeof(LogPair<L>));   // bytes per row of `lp2`
     const int beta_row = Up * static_cast<int>(sizeof(L));            // bytes per row of `alpha` / `beta`
     const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<LogPair<L>*>(lp2) + sample0, 0, static_cast<int>(Dp * cell_row), 0x00020000);
+        const_cast<LogPair<L>*>(lp2) + lat_sample_pair(b, maxT, maxU, Up), 0, static_cast<int>(Dp * cell_row), 0x00020000);
     const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(
         (dir == 0 ? alpha : beta) + sample0, 0, static_cast<int>(Dp * beta_row), 0x00020000);
     // lane offsets of column u0 in an lp2 row / an alpha-beta row; lanes past the row (COLS = 2 rounds the
@@ -1186,9 +1210,10 @@ static __global__ __launch_bounds__(MAXW * 64) void lattice_kernel(
         double* __restrict__ offa, double* __restrict__ offb, double* __restrict__ ll_fwd,
         double* __restrict__ ll_bwd, L* __restrict__ costs_dev, const int* __restrict__ xlen,
         const int* __restrict__ ylen, int maxT, int maxU, int Up, int dirs, int* __restrict__ padflag,
-        const L* __restrict__ logz, int* __restrict__ poison) {
+        const L* __restrict__ logz, int* __restrict__ poison, int* __restrict__ coef_done) {
     const int b = blockIdx.x / dirs;
-    if (blockIdx.x == 0 && threadIdx.x == 0) *padflag = 0;     // (set again by the coefficient kernel if the batch has padding)
+    if (threadIdx.x == 0 && static_cast<int>(blockIdx.x) == b * dirs) { coef_done[kCoefDoneStride * b] = 0; coef_done[kCoefDoneStride * b + kCoefDoneStride / 2] = 0; }   // tiles of coef_kernel that have finished READING this sample's block
+    if (blockIdx.x == 0 && threadIdx.x == 0) { padflag[0] = 0; padflag[2] = 0; }   // "has padding" (set again by the coefficient kernel) and "blocks overlaid by records" (make_layout: [0], [2]; a second half's private pair is [1], [3])
     lattice_body<L, MAXW, COLS>(lp2, alpha, beta, offa, offb, ll_fwd, ll_bwd, costs_dev, xlen, ylen, maxT, maxU, Up, b,
                                 static_cast<int>(blockIdx.x) - b * dirs, static_cast<int>(threadIdx.x), static_cast<int>(blockDim.x >> 6),
                                 logz, poison);
@@ -1263,11 +1288,11 @@ __device__ __forceinline__ void lattice_lin_body(
     const int Ub = Ub_raw < 1 ? 1 : (Ub_raw > maxU ? maxU : Ub_raw);
     const int Db = Tb + Ub - 1;
     const size_t Dp = lat_rows(maxT, maxU);
-    const size_t sample0 = static_cast<size_t>(b) * Dp * Up;
+    const size_t sample0 = lat_sample(b, maxT, maxU, Up), sample0p = lat_sample_pair(b, maxT, maxU, Up);   // value arrays / lp2
     const int cell_row = Up * static_cast<int>(sizeof(LogPair<L>));
     const int val_row = Up * static_cast<int>(sizeof(L));
     const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<LogPair<L>*>(lp2) + sample0, 0, static_cast<int>(Dp * cell_row), 0x00020000);
+        const_cast<LogPair<L>*>(lp2) + sample0p, 0, static_cast<int>(Dp * cell_row), 0x00020000);
     const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(
         (DIR == 0 ? alpha : beta) + sample0, 0, static_cast<int>(Dp * val_row), 0x00020000);
     const int u = lane;
@@ -1318,7 +1343,7 @@ __device__ __forceinline__ void lattice_lin_body(
         // bookkeeping across the loop's back edge collapsed to "wait for everything in flight" in every form tried
         // (measured: this role alone 25-29 ns per diagonal instead of ~8).  Nothing else in this wavefront uses vmcnt.
         typedef int lin_i32x4 __attribute__((ext_vector_type(4)));
-        const unsigned long long cbase = reinterpret_cast<unsigned long long>(lp2 + sample0);
+        const unsigned long long cbase = reinterpret_cast<unsigned long long>(lp2 + sample0p);
         const lin_i32x4 rd = {static_cast<int>(cbase), static_cast<int>((cbase >> 32) & 0xffffu),
                               static_cast<int>(Dp * cell_row), 0x00020000};
         lat_u32x2 ring[PFD][KW];
@@ -1472,10 +1497,11 @@ static __global__ __launch_bounds__(kLinThreads) void lattice_lin_kernel(
         double* __restrict__ offa, double* __restrict__ offb, double* __restrict__ ll_fwd,
         double* __restrict__ ll_bwd, float* __restrict__ costs_dev, const int* __restrict__ xlen,
         const int* __restrict__ ylen, int maxT, int maxU, int Up, int dirs, int force_fallback, int* __restrict__ padflag,
-        const float* __restrict__ logz, int* __restrict__ poison) {
+        const float* __restrict__ logz, int* __restrict__ poison, int* __restrict__ coef_done) {
     __shared__ LinShared sh;
     const int b = blockIdx.x / dirs;
-    if (blockIdx.x == 0 && threadIdx.x == 0) *padflag = 0;     // (set again by the coefficient kernel if the batch has padding)
+    if (threadIdx.x == 0 && static_cast<int>(blockIdx.x) == b * dirs) { coef_done[kCoefDoneStride * b] = 0; coef_done[kCoefDoneStride * b + kCoefDoneStride / 2] = 0; }   // (as lattice_kernel)
+    if (blockIdx.x == 0 && threadIdx.x == 0) { padflag[0] = 0; padflag[2] = 0; }   // (as lattice_kernel)
     const int dir = static_cast<int>(blockIdx.x) - b * dirs;
     if (dir == 0) lattice_lin_body<0>(sh, lp2, alpha, beta, offa, offb, ll_fwd, ll_bwd, costs_dev, xlen, ylen, maxT, maxU, Up, b, force_fallback, logz, poison);
     else lattice_lin_body<1>(sh, lp2, alpha, beta, offa, offb, ll_fwd, ll_bwd, costs_dev, xlen, ylen, maxT, maxU, Up, b, force_fallback, logz, poison);
@@ -1519,7 +1545,7 @@ __device__ __forceinline__ CoefRaw<L> coef_fetch(
     CoefRaw<L> r;
     const size_t Dp = lat_rows(maxT, maxU);
     const size_t idx = lat_index(b, n, u, maxT, maxU, Up);
-    r.p = lp2[idx];
+    r.p = lp2[lat_pair_index(b, n, u, maxT, maxU, Up)];
     r.lz = logz[idx];
     r.al = alpha_arr[idx];
     const L* bp = beta + idx;
@@ -1587,10 +1613,11 @@ static __global__ __launch_bounds__(256) void coef_cell_kernel(
         const double* __restrict__ offb, const double* __restrict__ ll_fwd,
         const int* __restrict__ labels, const int* __restrict__ xlen, const int* __restrict__ ylen,
         Cell<L>* __restrict__ rowtab, int maxT, int maxU, int Up, float* __restrict__ wmat, int Upad, float fastemit,
-        int planes, const long long* __restrict__ offsets, int lw, int lsh, int b0, int N, int* __restrict__ padflag) {   // offsets: packed row order (see row_stats_kernel); b0 = first sample of this launch, N = samples of the batch   // planes: 1 = W only; 2 = W and CL (third plane); 3 = W, CB, CL (one-hot df corrections); 4 = W, CB, CL, no records; the c of a FAR cell (W = kJointFarMark) is
+        int planes, const long long* __restrict__ offsets, int lw, int lsh, int b0, int N, int* __restrict__ padflag, int recycled) {   // recycled: lattice blocks (from sample 0) under the records written up to this launch (launch_coef)   // offsets: packed row order (see row_stats_kernel); b0 = first sample of this launch, N = samples of the batch   // planes: 1 = W only; 2 = W and CL (third plane); 3 = W, CB, CL (one-hot df corrections); 4 = W, CB, CL, no records; the c of a FAR cell (W = kJointFarMark) is
                         // written INTO the record table's memory at the plane index (stride Upad <= 4 maxU floats) -- with the
                         // one-hot DF nothing reads cb / cl / label per record any more, and 12 instead of 28 bytes leave per cell
     const int b = b0 + blockIdx.y;
+    if (recycled > 0 && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) atomicMax(padflag + 2, recycled);
     const unsigned per = gridDim.x >> 3;
     const unsigned blk = (blockIdx.x & 7u) * per + (blockIdx.x >> 3);
     const int D = maxT + maxU - 1;
@@ -1655,7 +1682,8 @@ static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4)))
         Cell<L>* __restrict__ rowtab, int maxT, int maxU, int Up, float* __restrict__ wmat, int Upad, int tilesU,
         float fastemit, int planes, const long long* __restrict__ offsets, int lw, int lsh, int b0, int N,
         int* __restrict__ padflag, float* __restrict__ sfb, float* __restrict__ sgb, float* __restrict__ sgl,
-        int* __restrict__ farflag) {      // additive joint (sfb != nullptr): the correction sums of the gradient GEMMs' epilogues, see below
+        int* __restrict__ farflag, int recycled, int* coef_done, unsigned long long ov_rec, unsigned long long ov_head,
+        unsigned long long ov_block, int first_sample) {      // recycled: as coef_cell_kernel; coef_done .. first_sample: the overlay guard below (nullptr: the record table overlays nothing)      // additive joint (sfb != nullptr): the correction sums of the gradient GEMMs' epilogues, see below
     constexpr int DN = sizeof(L) == 4 ? 32 : 16;           // diagonals per tile (LDS: DN * 64 records)
     __shared__ Cell<L> recs[DN][64];
     // Additive joint: sfb[b][t] = sum_u cb(t,u), sgb[b][u] = sum_t cb(t,u), sgl[b][u] = sum_t cl(t,u) and the "has far cells"
@@ -1663,13 +1691,59 @@ static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4)))
     // as a kernel of its own (joint_sums_kernel, still used behind the cell-per-thread form) they were a second pass over
     // the planes -- 0.11 ms of the 1.3 ms c4-shaped step.  Tile sums go to the side vectors as float atomics (as before).
 
-    const int b = b0 + blockIdx.y;
+    // ONE-dimensional launch, sample-major by construction: workgroup L is tile L % tiles of sample L / tiles (the overlay
+    // guard below relies on the tiles of earlier samples having been DISPATCHED earlier: linear launch order)
+    const int tiles = tilesU * ((maxT + maxU - 1 + DN - 1) / DN);
+    const int tile = static_cast<int>(blockIdx.x % static_cast<unsigned>(tiles));
+    const int b = b0 + static_cast<int>(blockIdx.x / static_cast<unsigned>(tiles));
+    if (recycled > 0 && blockIdx.x == 0 && threadIdx.x == 0) atomicMax(padflag + 2, recycled);
     const int lane = threadIdx.x & 63, wave = uniform(threadIdx.x >> 6);
-    const int tu = static_cast<int>(blockIdx.x) % tilesU, tn = static_cast<int>(blockIdx.x) / tilesU;
+    const int tu = tile % tilesU, tn = tile / tilesU;
     const int n0 = tn * DN, u0 = tu * 64;
     const int D = maxT + maxU - 1;
     int Tb, Ub;
     coef_lens(xlen, ylen, b, maxT, maxU, Tb, Ub);
+
+    // ---- overlay guard (make_layout): the record table of this sample lies OVER the lattice blocks of earlier samples of
+    // the batch.  All samples are in ONE launch (in groups of samples, launch after launch, the kernel lost a third of its
+    // speed to launch gaps and tails: c4 0.26 -> 0.35 ms), so a block (a) announces -- after the barrier that ends its compute
+    // phase -- that it has finished READING its sample's block, and (b) before it stores, makes sure that every tile of every
+    // sample whose block its records may touch has announced the same.  Workgroups are dispatched in launch order
+    // (sample-major: the launch is one-dimensional), so the tiles waited for were dispatched before this one: they are
+    // running or done, and the wait cannot deadlock; it is also a formality -- those tiles are >= head / rec samples,
+    // thousands of workgroups, ahead (counted on c4: 3 spin iterations in 54 720 workgroups).
+    //   * Who looks, and when: tile 0 of a sample reads the counters of the samples its sample's records can touch and raises
+    //     the sample's "clear" word; the other tiles read that one word.  Both looks are taken HERE, when the block starts, so
+    //     the answer is back before the compute phase ends; only a block that saw "not yet" looks again before its barrier.
+    //   * RELAXED atomics: this is a write-after-READ hazard -- nothing a tile has written is published to another tile here
+    //     (records are read by the NEXT kernel), only "my loads have returned", which the block barrier implies for the whole
+    //     block.  Release / acquire at agent scope write back and invalidate the XCD's L2 per tile: 0.26 -> 1.29 ms.
+    //   * ONE 128-byte LINE PER WORD (kCoefDoneStride).  This is what the cost hung on: with the 2 N words of c4 packed into four
+    //     lines, 18 240 announcements and as many coherent reads per call queued up at those lines' home in the memory
+    //     system -- 0.74 to 1.16 ms whoever looked and whenever; a line per word: 0.275 ms (0.269 without any guard).
+    // coef_done[64 s] = tiles of sample s that have finished reading, coef_done[64 s + 32] = sample s may store.
+    auto ov_need_of = [&]() -> int {                       // lattice blocks of this plan that start below the end of sample b's records
+        const unsigned long long end = ov_rec * static_cast<unsigned long long>(first_sample + b + 1);
+        long long need = end > ov_head ? static_cast<long long>((end - ov_head + ov_block - 1) / ov_block) - first_sample : 0;
+        return static_cast<int>(need > b ? b : (need < 0 ? 0 : need));      // (never its own block or a later one: head >= rec)
+    };
+    bool ov_pending = false;                               // wave-uniform, wavefront 0 only
+    if (coef_done != nullptr && wave == 0) {
+        const int need = ov_need_of();
+        if (need > 0) {
+            bool missing = false;
+            if (tile == 0) {
+                for (int s0 = 0; s0 < need; s0 += 64)
+                    if (s0 + lane < need)
+                        missing |= __hip_atomic_load(coef_done + kCoefDoneStride * static_cast<size_t>(s0 + lane), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < tiles;
+            } else {
+                missing = __hip_atomic_load(coef_done + kCoefDoneStride * static_cast<size_t>(b) + kCoefDoneStride / 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0;
+            }
+            ov_pending = __ballot(missing) != 0;           // (looked at again after this wavefront's compute phase)
+            if (tile == 0 && !ov_pending && lane == 0)
+                __hip_atomic_store(coef_done + kCoefDoneStride * static_cast<size_t>(b) + kCoefDoneStride / 2, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
 
     // ---- compute, skewed order: the operands of COEF_KB of the wavefront's DN/4 cells are requested together
     {
@@ -1698,7 +1772,26 @@ static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4)))
             }
         }
     }
+    // (wavefront 0 arrives at the barrier only when the overlay guard lets it: `ov_pending` above)
+    if (coef_done != nullptr && wave == 0 && ov_pending) {
+        // the look taken when the block started did not show the sample clear: look again, and wait
+        if (tile == 0) {
+            const int need = ov_need_of();
+            for (int s0 = 0; s0 < need; s0 += 64)
+                if (s0 + lane < need)
+                    while (__hip_atomic_load(coef_done + kCoefDoneStride * static_cast<size_t>(s0 + lane), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < tiles)
+                        __builtin_amdgcn_s_sleep(8);
+            if (lane == 0)
+                __hip_atomic_store(coef_done + kCoefDoneStride * static_cast<size_t>(b) + kCoefDoneStride / 2, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            while (__hip_atomic_load(coef_done + kCoefDoneStride * static_cast<size_t>(b) + kCoefDoneStride / 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0)
+                __builtin_amdgcn_s_sleep(8);
+        }
+    }
     __syncthreads();
+    // every load of this block has returned (its operands are in LDS): announce it
+    if (coef_done != nullptr && threadIdx.x == 0)
+        __hip_atomic_fetch_add(coef_done + kCoefDoneStride * static_cast<size_t>(b), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if constexpr (SUMS) {
         // passes of their own over the records in LDS (inside the compute phase or the store loop the sums cost the kernel
         // its fourth wavefront per SIMD: it sits at the 128-register line).  Wavefront 0: the tile's column sums of cb and
@@ -1776,13 +1869,15 @@ template <typename L>
 static __global__ __launch_bounds__(256) void lattice_dump_kernel(
         const L* __restrict__ alpha, const L* __restrict__ beta, const double* __restrict__ offa, const double* __restrict__ offb,
         const int* __restrict__ xlen, const int* __restrict__ ylen, int b, int maxT, int maxU, int Up, int lw, int lsh,
-        double* __restrict__ a_out, double* __restrict__ b_out) {
+        double* __restrict__ a_out, double* __restrict__ b_out, const int* __restrict__ recycled) {
     const int cell = blockIdx.x * 256 + threadIdx.x;
     if (cell >= maxT * maxU) return;
     const int t = cell / maxU, u = cell - t * maxU, n = t + u;
     int Tb, Ub;
     coef_lens(xlen, ylen, b, maxT, maxU, Tb, Ub);
-    if (t >= Tb || u >= Ub) { a_out[cell] = __builtin_nan(""); b_out[cell] = __builtin_nan(""); return; }
+    // padding -- and a sample whose lattice block the record table of a gradient-computing call has overlaid (make_layout):
+    // its alpha / beta no longer exist
+    if (t >= Tb || u >= Ub || b < recycled[0]) { a_out[cell] = __builtin_nan(""); b_out[cell] = __builtin_nan(""); return; }
     const size_t Dp = lat_rows(maxT, maxU);
     const size_t idx = lat_index(b, n, u, maxT, maxU, Up);
     const size_t o = (static_cast<size_t>(b) * lw + (u >> lsh)) * Dp + kLatPad + n;
@@ -1809,7 +1904,7 @@ static __global__ __launch_bounds__(256) void loss_sum_kernel(const C* __restric
 
 // ------------------------------------------------------------------------------------------
 // Packed layout with a per-sample gradient scale: one scale per packed ROW, so that the gradient kernel's lookup
-// needs no search (rowscale lives in the `alpha` array of the workspace, dead once the coefficients exist).
+// needs no search (rowscale lives in lattice blocks of the workspace that are dead once the coefficients exist: make_layout).
 // grid = (N, 8), block = 256.
 template <typename C>
 static __global__ __launch_bounds__(256) void fill_row_scale_kernel(

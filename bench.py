@@ -193,8 +193,8 @@ def cpu_baseline(w, acts, labels, act_lens, label_lens, budget_samples):
         prepared1 = O.RefCall(lp[:n1s], lab[:n1s], tl[:n1s], ll[:n1s], 0, 1)
         ms_steady1 = timed(prepared1, reps=2) * (N / n1s)
         steady = dict(value=round(ms_steady, 3), unit="ms/batch", cores=threads,
-                      sample="%d of %d samples, gradient / workspace / cost buffers allocated and touched once outside the timing, "
-                             "median of 5 warmed calls, scaled x%.2f" % (n, N, N / n),
+                      sample="%d of %d samples, gradient / workspace / cost buffers allocated once and first touched by an untimed call of the "
+                             "reference itself (each OpenMP thread faults in its own samples' slabs), median of 5 warmed calls, scaled x%.2f" % (n, N, N / n),
                       single_thread=dict(value=round(ms_steady1, 3), unit="ms/batch", cores=1,
                                          sample="%d of %d samples, same protocol, median of 2, scaled x%.2f" % (n1s, N, N / n1s)))
         del prepared, prepared1

@@ -257,9 +257,12 @@ def ref_rnnt_logprobs(log_probs, labels, act_lens, label_lens, blank=0, want_gra
 
 class RefCall:
     """The reference's compute_rnnt_loss (RNNT_CPU) with every buffer it writes -- gradients, workspace, costs --
-    allocated and TOUCHED once here, so that repeated calls measure arithmetic (and the reference's own memset of the
-    gradient slab, include/detail/cpu_rnnt.h:155-158), not first-touch page faults of fresh allocations: the steady-state
-    protocol BASELINE.md 3 promised next to the reference harness's (tests/test_time.cpp:57-60 allocates per iteration)."""
+    allocated ONCE here and touched by one untimed call, so that repeated calls measure arithmetic (and the reference's own
+    memset of the gradient slab, include/detail/cpu_rnnt.h:155-158), not first-touch page faults of fresh allocations: the
+    steady-state protocol BASELINE.md 3 promised next to the reference harness's (tests/test_time.cpp:57-60 allocates per
+    iteration).  The first touch is the reference's own: each OpenMP thread faults in the slab of the samples it processes
+    (cpu_rnnt.h:290), so on a multi-socket host the pages land next to the threads that use them -- zero-filling from the
+    calling thread put all 8 GB of c3 on one NUMA node and made 128 threads slower than one."""
 
     def __init__(self, log_probs, labels, act_lens, label_lens, blank=0, num_threads=0):
         lp = np.ascontiguousarray(log_probs)
@@ -267,12 +270,13 @@ class RefCall:
         self.lp, self.N, self.A = lp, N, A
         self.labels, self.tl, self.ll = _i32(labels), _i32(act_lens), _i32(label_lens)
         self.costs = np.zeros(N, dtype=lp.dtype)
-        self.grads = np.zeros_like(lp)                                  # zeros: every page touched
+        self.grads = np.empty_like(lp)
         nbytes = C.c_size_t(0)
         assert ref().get_workspace_size(T, U, N, False, C.byref(nbytes), lp.dtype.itemsize) == 0
-        self.ws = np.zeros(nbytes.value + 16, dtype=np.uint8)
+        self.ws = np.empty(nbytes.value + 16, dtype=np.uint8)
         self.opt = rnntOptions(loc=0, num_threads=num_threads, stream=None, blank_label=blank, maxT=T, maxU=U, batch_first=True)
         self.fn = ref().compute_rnnt_loss if lp.dtype == np.float32 else ref().compute_rnnt_loss_fp64
+        self()                                                          # the first touch, by the threads that will do the work
 
     def __call__(self):
         st = self.fn(self.lp.ctypes.data, self.grads.ctypes.data, self.labels.ctypes.data, self.ll.ctypes.data,

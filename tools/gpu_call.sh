@@ -23,8 +23,10 @@ python bench.py --workload c4 --aux-stream --steps 50 --no-cpu-baseline --no-tra
 python bench.py --gpus 2 --oversubscribe-gloo --steps 5 --warmup 2 > gpurun_out/${TAG}_bench_2ranks_oversubscribed.json 2> /dev/null
 ( cd /tmp && bash $OLDPWD/tools/joint_c4_profile.sh $TAG > /dev/null 2>&1 )
 # round 5: a roofline per kernel of the additive joint, the first call of a process per storage type, the c4 placement matrix
-( cd /tmp && for s in "c3" "--bf16 c3" "c4"; do n=$(echo $s | tr -d " -"); timeout 400 python $OLDPWD/tools/add_network_roofline.py $s > $OLDPWD/gpurun_out/${TAG}_add_roofline_$n.md 2>/dev/null; done )
+( cd /tmp && for s in "c3" "--bf16 c3" "c4"; do n=$(echo $s | tr -d " -"); timeout 400 python $OLDPWD/tools/add_network_roofline.py --json $OLDPWD/gpurun_out/${TAG}_add_traffic.json $s > $OLDPWD/gpurun_out/${TAG}_add_roofline_$n.md 2>/dev/null; done )
 ( python tools/first_call.py x; python tools/first_call.py; python tools/first_call.py add; python tools/first_call.py add16 ) 2>&1 | grep -v amdgpu.ids > gpurun_out/${TAG}_first_call.log
 timeout 300 python tools/c4_bimodal_probe.py matrix 2> /dev/null > gpurun_out/${TAG}_c4_placement_matrix.jsonl
 timeout 300 python tools/materialised_fuzz.py 200 7 2>&1 | tail -1 > gpurun_out/${TAG}_materialised_fuzz.log
+for seed in 31 32 33; do timeout 300 python tools/add_network_fuzz.py 200 $seed 2>&1 | tail -1; done > gpurun_out/${TAG}_add_network_fuzz3.log
+python bench.py --workload c3 --in-place --steps 30 --no-cpu-baseline --no-traffic-pass > gpurun_out/${TAG}_bench_c3_in_place.json 2> /dev/null
 python tools/readme_table.py > gpurun_out/${TAG}_readme_table.md 2> gpurun_out/${TAG}_readme_table.err

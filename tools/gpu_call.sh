@@ -28,5 +28,6 @@ python bench.py --gpus 2 --oversubscribe-gloo --steps 5 --warmup 2 > gpurun_out/
 timeout 300 python tools/c4_bimodal_probe.py matrix 2> /dev/null > gpurun_out/${TAG}_c4_placement_matrix.jsonl
 timeout 300 python tools/materialised_fuzz.py 200 7 2>&1 | tail -1 > gpurun_out/${TAG}_materialised_fuzz.log
 for seed in 31 32 33; do timeout 300 python tools/add_network_fuzz.py 200 $seed 2>&1 | tail -1; done > gpurun_out/${TAG}_add_network_fuzz3.log
+for seed in 11 12; do timeout 500 python tools/overlay_fuzz.py 40 $seed 2>&1 | tail -1; done > gpurun_out/${TAG}_overlay_fuzz.log
 python bench.py --workload c3 --in-place --steps 30 --no-cpu-baseline --no-traffic-pass > gpurun_out/${TAG}_bench_c3_in_place.json 2> /dev/null
 python tools/readme_table.py > gpurun_out/${TAG}_readme_table.md 2> gpurun_out/${TAG}_readme_table.err

@@ -1,0 +1,10 @@
+#!/bin/bash
+cd "${GRAFT_REPO_ROOT:-.}"
+timeout 1500 python -m pytest tests -m gpu -q -x 2>&1 | tail -4 | head -3
+J='import json,sys; r=json.loads(sys.stdin.read()); print(sys.argv[1], r["ms_per_step"], r["stage_ms"], r["check"].get("passed"))'
+for i in 1 2; do python bench.py --workload c4 --steps 30 --no-cpu-baseline --no-traffic-pass 2>/dev/null | python -c "$J" c4; done
+python bench.py --workload c4 --varlen --steps 30 --no-cpu-baseline --no-traffic-pass 2>/dev/null | python -c "$J" c4-varlen
+python bench.py --workload c4 --varlen --packed --steps 30 --no-cpu-baseline --no-traffic-pass 2>/dev/null | python -c "$J" c4-varlen-packed
+python tools/add_network_bench.py --fused-only c4 long128 long1024 2>&1 | grep -v amdgpu | sed "s/| autograd.*//"
+python tools/add_network_bench.py --bf16 c4 2>&1 | grep -v amdgpu | sed "s/| autograd.*//"
+timeout 300 python tools/overlay_fuzz.py 30 41 2>&1 | tail -1

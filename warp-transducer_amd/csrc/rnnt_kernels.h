@@ -1745,29 +1745,63 @@ static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4)))
         }
     }
 
-    // ---- compute, skewed order: the operands of COEF_KB of the wavefront's DN/4 cells are requested together
+    // ---- compute, skewed order: wavefront w takes the K = DN/4 CONSECUTIVE diagonals n0 + w K ..., COEF_KB of them per round trip.
+    // Consecutive, because the beta row a cell needs below it is the next diagonal's own row: a group of KB cells per lane reads
+    // KB + 1 rows of beta instead of 3 KB values (its own, the one below, the one below-right), the below-right value is the
+    // below value of the lane to the right (one DPP shift; lane 63 takes column u0 + 64 from a wave-uniform load), the right
+    // column's offset is one of two wave-uniform values, and the label is read once per lane.  Vector loads per group of four
+    // cells: 17 instead of 32 (round 5: lp2, log Z, alpha, three betas, a per-lane fp64 offset and the label per cell) -- the
+    // kernel is bound by the rate of its L1 requests, not by bytes.  Same values into coef_eval, same records.
+    // (Where the diagonal index is clamped at the lattice's end the shared row differs from the old "row + 1" -- only for the
+    // terminal diagonal and beyond, whose cells use neither value: last_t / last_u in coef_eval, or padding.)
     {
         constexpr int K = DN / 4;                          // diagonals per wavefront
         constexpr int KB = COEF_KB;                        // ... requested together
         const int u = u0 + lane;
         const int uc = u < maxU ? u : maxU - 1;            // columns past the lattice fetch a valid one, their record is padding
+        const int uc63 = u0 + 63 < maxU ? u0 + 63 : maxU - 1;   // lane 63's column (wave-uniform)
         const double ll2 = ll_fwd[b];
+        const size_t Dp = lat_rows(maxT, maxU);
+        const int wi = u0 >> lsh;                          // the lattice wavefront these 64 columns belong to (offsets are per lattice wavefront)
+        const double* oa = offa + (static_cast<size_t>(b) * lw + wi) * Dp + kLatPad;
+        const double* ob = offb + (static_cast<size_t>(b) * lw + wi) * Dp + kLatPad;
+        const double* obn = ob + Dp;                       // the next lattice wavefront's: column uc + 1 when it is that wavefront's first
+        const bool right_next = ((uc + 1) >> lsh) != wi;
+        const int lab = maxU > 1 ? labels[static_cast<size_t>(b) * (maxU - 1) + (uc < maxU - 1 ? uc : maxU - 2)] : 0;
+        const LogPair<L>* pcol = lp2 + lat_pair_index(b, 0, uc, maxT, maxU, Up);
+        const size_t vcol = lat_index(b, 0, uc, maxT, maxU, Up);
+        const L* bedge = beta + lat_index(b, 0, uc63, maxT, maxU, Up) + Up + 1;       // [row * Up]: the value below-right of lane 63's cell
 #pragma unroll 1
         for (int i0 = 0; i0 < K; i0 += KB) {
-            CoefRaw<L> raw[KB];
+            LogPair<L> cp[KB];
+            L lz[KB], al[KB], bb[KB + 1], be[KB];
+            int row[KB];
 #pragma unroll
             for (int i = 0; i < KB; ++i) {
-                const int n = n0 + wave + 4 * (i0 + i);
-                raw[i] = coef_fetch<L>(lp2, logz, alpha_arr, beta, offa, offb, labels, b, n < D ? n : D - 1, uc, maxT, maxU, Up, lw, lsh,
-                                       u0 >> lsh);
+                const int n = n0 + wave * K + i0 + i;
+                row[i] = n < D ? n : D - 1;
+                const size_t r = static_cast<size_t>(row[i]) * Up;
+                cp[i] = pcol[r];
+                lz[i] = logz[vcol + r];
+                al[i] = alpha_arr[vcol + r];
+                bb[i] = beta[vcol + r];
+                be[i] = bedge[r];
             }
+            bb[KB] = beta[vcol + static_cast<size_t>(row[KB - 1]) * Up + Up];
 #pragma unroll
             for (int i = 0; i < KB; ++i) {
-                const int dn = wave + 4 * (i0 + i);
+                const int dn = wave * K + i0 + i;
                 const int n = n0 + dn, t = n - u;
+                CoefRaw<L> raw;
+                raw.p = cp[i]; raw.lz = lz[i]; raw.al = al[i];
+                raw.b0 = bb[i]; raw.b1 = bb[i + 1];
+                raw.b2 = wave_shl1(be[i], bb[i + 1]);      // lane l: the below value of lane l + 1; lane 63: the wave-uniform edge value
+                raw.oa = oa[row[i]]; raw.ob = ob[row[i]]; raw.ob1 = ob[row[i] + 1];
+                raw.obr = right_next ? obn[row[i] + 1] : raw.ob1;
+                raw.lab = lab;
                 Cell<L> o;
                 o.x = log_zero<L>(); o.y = 0; o.z = 0; o.w = static_cast<L>(kPadded);
-                if (n < D && u < maxU && t >= 0 && t < maxT) o = coef_eval<L>(raw[i], ll2, t, u, Tb, Ub, fastemit);
+                if (n < D && u < maxU && t >= 0 && t < maxT) o = coef_eval<L>(raw, ll2, t, u, Tb, Ub, fastemit);
                 recs[dn][lane] = o;
             }
         }

@@ -1667,14 +1667,19 @@ static __global__ __launch_bounds__(256) void coef_cell_kernel(
 //            cell, which cost 0.225 of this kernel's 0.42 ms on c4 even with the partial lines meeting in
 //            one L2.  The dense weight matrix of the additive-joint path leaves the same way.
 // grid = (ceil(D/DN) * ceil(maxU/64), N), block = 256.
-// Cells of a wavefront whose operands are requested together in the tiled kernel.  All eight: 155 VGPRs, three
-// wavefronts per SIMD, c4 0.30 ms; FOUR (two round trips): 126 VGPRs, four wavefronts per SIMD, 0.27 ms; two: the
-// same; one: 0.39 ms.
+// Cells of a wavefront whose operands are requested together in the tiled kernel (COEF_KB) and the occupancy the kernel is
+// compiled for (COEF_WAVES per SIMD).  Round 5 form (interleaved diagonals, 8 vector loads per cell): all eight 155 VGPRs, c4
+// 0.30 ms; four 126 VGPRs, 0.27 ms.  Round 6 form (consecutive diagonals, shared beta rows), c4 / additive joint's c4 shape:
+// four cells at 4 waves 0.234 / 0.246 ms, at 5 waves 0.239 / 0.250; EIGHT cells at 4 waves 0.227 / 0.235, at 5 waves
+// 0.228 / 0.231, at 3 waves 0.229 / 0.234 (`profiles/r06/coef_variants.log`).
 #ifndef COEF_KB
-#define COEF_KB 4
+#define COEF_KB 8
+#endif
+#ifndef COEF_WAVES
+#define COEF_WAVES 5
 #endif
 template <typename L, bool SUMS = false>   // SUMS: additive joint, the correction sums of the gradient GEMMs' epilogues (see below)
-static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void coef_kernel(
+static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(COEF_WAVES))) void coef_kernel(
         const LogPair<L>* __restrict__ lp2, const L* __restrict__ logz, const L* __restrict__ alpha_arr,
         const L* __restrict__ beta, const double* __restrict__ offa,
         const double* __restrict__ offb, const double* __restrict__ ll_fwd,
@@ -1756,7 +1761,7 @@ static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4)))
     // terminal diagonal and beyond, whose cells use neither value: last_t / last_u in coef_eval, or padding.)
     {
         constexpr int K = DN / 4;                          // diagonals per wavefront
-        constexpr int KB = COEF_KB;                        // ... requested together
+        constexpr int KB = COEF_KB < K ? COEF_KB : K;      // ... requested together
         const int u = u0 + lane;
         const int uc = u < maxU ? u : maxU - 1;            // columns past the lattice fetch a valid one, their record is padding
         const int uc63 = u0 + 63 < maxU ? u0 + 63 : maxU - 1;   // lane 63's column (wave-uniform)

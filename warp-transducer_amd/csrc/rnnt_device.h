@@ -176,13 +176,43 @@ template <> __device__ __forceinline__ double log_zero<double>() { return -1.0e3
 
 // (-|a - b| instead of min - max: the negation and the absolute value are source modifiers of v_exp_f32,
 // one instruction less on the lattice's dependent chain)
+// (the maximum as the bare instruction: through fmaxf the compiler canonicalises an operand that came out of a DPP move --
+//  a bit pattern it cannot prove quiet -- with an extra v_max x, x per step of the lattice's dependent chain)
 __device__ __forceinline__ float log2_add(float a, float b) {
-    const float d = a - b, hi = fmaxf(a, b);
+    const float d = a - b;
+    float hi;
+    asm("v_max_f32 %0, %1, %2" : "=v"(hi) : "v"(a), "v"(b));
     return hi + __builtin_amdgcn_logf(1.0f + __builtin_amdgcn_exp2f(-__builtin_fabsf(d)));
 }
 __device__ __forceinline__ double log2_add(double a, double b) {
     const double d = a - b, hi = fmax(a, b);
     return hi + log2(1.0 + exp2(-fabs(d)));
+}
+// TWO independent log2_add's with their instructions INTERLEAVED (the two lattice columns of a lane).  Left to the compiler the
+// two chains came out one after the other -- sub, max, exp, add, log, add of the first, then the same of the second, sharing
+// temporaries -- and an in-order SIMD with one resident wavefront then waits out every dependency twice: a two-column step took
+// 1.7x a one-column one.  Interleaved, each instruction's producer is two issue slots back, which also covers the one wait state
+// a reader of a transcendental's result needs (no s_nop inside).
+__device__ __forceinline__ void log2_add_x2(float a0, float b0, float a1, float b1, float& r0, float& r1) {
+    float d0, d1, h0, h1;
+    asm("v_sub_f32 %2, %6, %7\n\t"
+        "v_sub_f32 %3, %8, %9\n\t"
+        "v_max_f32 %4, %6, %7\n\t"
+        "v_max_f32 %5, %8, %9\n\t"
+        "v_exp_f32_e64 %2, -|%2|\n\t"
+        "v_exp_f32_e64 %3, -|%3|\n\t"
+        "v_add_f32 %2, 1.0, %2\n\t"
+        "v_add_f32 %3, 1.0, %3\n\t"
+        "v_log_f32 %2, %2\n\t"
+        "v_log_f32 %3, %3\n\t"
+        "v_add_f32 %0, %4, %2\n\t"
+        "v_add_f32 %1, %5, %3"
+        : "=&v"(r0), "=&v"(r1), "=&v"(d0), "=&v"(d1), "=&v"(h0), "=&v"(h1)
+        : "v"(a0), "v"(b0), "v"(a1), "v"(b1));
+}
+__device__ __forceinline__ void log2_add_x2(double a0, double b0, double a1, double b1, double& r0, double& r1) {
+    r0 = log2_add(a0, b0);
+    r1 = log2_add(a1, b1);
 }
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 __device__ __forceinline__ double fast_exp2(double x) { return exp2(x); }
@@ -222,6 +252,38 @@ template <int CTRL, int ROWMASK> __device__ __forceinline__ double dpp_mov(doubl
     const int lo = __builtin_amdgcn_update_dpp(__double2loint(v), __double2loint(v), CTRL, ROWMASK, 0xf, false);
     const int hi = __builtin_amdgcn_update_dpp(__double2hiint(v), __double2hiint(v), CTRL, ROWMASK, 0xf, false);
     return __hiloint2double(hi, lo);
+}
+// Shift inside the 16-lane rows by K lanes (K compile-time after unrolling): row_shl: lane l takes lane l + K of its row,
+// row_shr: lane l takes lane l - K; lanes without a source get ZERO (bound_ctrl: no "old" operand, so no register copy in
+// front of the move).  The lattice kernel's boundary hand-off: lane 0 <- lane k of row 0, lane 63 <- lane 63 - k of row 3,
+// without a trip through the scalar unit; every other lane of the result is don't-care there.
+template <int CTRL> __device__ __forceinline__ float dpp_mov0(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+template <int CTRL> __device__ __forceinline__ double dpp_mov0(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+template <typename T> __device__ __forceinline__ T row_shl(T v, int k) {
+    switch (k) {
+        case 1: return dpp_mov0<0x101>(v); case 2: return dpp_mov0<0x102>(v); case 3: return dpp_mov0<0x103>(v);
+        case 4: return dpp_mov0<0x104>(v); case 5: return dpp_mov0<0x105>(v); case 6: return dpp_mov0<0x106>(v);
+        case 7: return dpp_mov0<0x107>(v); case 8: return dpp_mov0<0x108>(v); case 9: return dpp_mov0<0x109>(v);
+        case 10: return dpp_mov0<0x10A>(v); case 11: return dpp_mov0<0x10B>(v); case 12: return dpp_mov0<0x10C>(v);
+        case 13: return dpp_mov0<0x10D>(v); case 14: return dpp_mov0<0x10E>(v); case 15: return dpp_mov0<0x10F>(v);
+        default: return v;
+    }
+}
+template <typename T> __device__ __forceinline__ T row_shr(T v, int k) {
+    switch (k) {
+        case 1: return dpp_mov0<0x111>(v); case 2: return dpp_mov0<0x112>(v); case 3: return dpp_mov0<0x113>(v);
+        case 4: return dpp_mov0<0x114>(v); case 5: return dpp_mov0<0x115>(v); case 6: return dpp_mov0<0x116>(v);
+        case 7: return dpp_mov0<0x117>(v); case 8: return dpp_mov0<0x118>(v); case 9: return dpp_mov0<0x119>(v);
+        case 10: return dpp_mov0<0x11A>(v); case 11: return dpp_mov0<0x11B>(v); case 12: return dpp_mov0<0x11C>(v);
+        case 13: return dpp_mov0<0x11D>(v); case 14: return dpp_mov0<0x11E>(v); case 15: return dpp_mov0<0x11F>(v);
+        default: return v;
+    }
 }
 // Value of lane `k` (compile-time) as a wave-uniform scalar; write a scalar into lane `k`.
 __device__ __forceinline__ float lane_get(float v, int k) {

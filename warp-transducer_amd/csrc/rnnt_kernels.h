@@ -850,7 +850,7 @@ __global__ __launch_bounds__(256) void row_stats_tile2d_kernel(
 // than four wavefronts (two wavefronts per SIMD: 256 registers per lane; the two chunk buffers and the result
 // history of a two-column lane are 10 values per diagonal).
 template <typename L, int MAXW, int COLS> struct LatChunk {
-    static constexpr int C = (sizeof(L) == 4 ? 16 : 8) / ((COLS > 1 && MAXW > 4) ? 2 : 1);
+    static constexpr int C = sizeof(L) == 4 ? (MAXW <= 4 ? 16 : 16 / (COLS > 1 ? 2 : 1)) : 8 / ((COLS > 1 && MAXW > 4) ? 2 : 1);
 };
 
 typedef unsigned int lat_u32x2 __attribute__((ext_vector_type(2)));
@@ -864,45 +864,86 @@ __device__ __forceinline__ float lat_clamp(float v) { return __builtin_amdgcn_fm
 __device__ __forceinline__ double lat_clamp(double v) { return fmin(fmax(v, log_zero<double>()), 0.0); }
 __device__ __forceinline__ double lat_f64(unsigned lo, unsigned hi) { return __hiloint2double(static_cast<int>(hi), static_cast<int>(lo)); }
 
+// The fp32 lattice issues its row loads and stores as inline assembly and counts them itself (kHand): the sweep keeps the NEXT
+// chunk's operand rows in flight while it works on this one, and the compiler's own wait insertion cannot express that -- it
+// merged the waits for the rows of a chunk into `s_waitcnt vmcnt(15 - k)` placed AFTER the stores and loads the chunk had just
+// issued, so every chunk waited a full memory round trip for its own prefetch (round 6: 0.275 -> see EXPERIMENTS 13).  The
+// counter is in order: with F younger accesses issued after the rows that are needed, `s_waitcnt vmcnt(F)` is exact.  `Raw` is a row
+// as it arrives (the clamp to [log zero, 0] is applied when the value is used); the fp64 lattice keeps the compiler-tracked builtins.
+typedef int lat_i32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ lat_i32x4 lat_desc(const void* p, int bytes) {
+    const unsigned long long a = reinterpret_cast<unsigned long long>(p);
+    return lat_i32x4{static_cast<int>(a), static_cast<int>((a >> 32) & 0xffffu), bytes, 0x00020000};
+}
+template <int N> __device__ __forceinline__ void lat_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+// "These registers are written by loads the compiler cannot see": every later use depends on this statement, so none moves
+// above the wait that precedes it, and the registers stay allocated to the rows until here.
+template <typename R> __device__ __forceinline__ void lat_pin(R (&r)[16]) {
+    asm volatile("" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7]),
+                      "+v"(r[8]), "+v"(r[9]), "+v"(r[10]), "+v"(r[11]), "+v"(r[12]), "+v"(r[13]), "+v"(r[14]), "+v"(r[15]));
+}
+template <typename R> __device__ __forceinline__ void lat_pin(R (&r)[8]) {
+    asm volatile("" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7]));
+}
+__device__ __forceinline__ void lat_put_f64(const lat_i32x4& d, int voff, int soff, double v) {
+    asm volatile("buffer_store_dwordx2 %0, %1, %2, %3 offen" ::"v"(v), "v"(voff), "s"(d), "s"(soff) : "memory");
+}
+
 template <typename L, int COLS> struct LatIO;
 template <> struct LatIO<float, 1> {
-    static __device__ __forceinline__ void load_xy(__amdgpu_buffer_rsrc_t r, int voff, int soff, float* x, float* y) {
-        const lat_u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
+    static constexpr bool kHand = true;
+    using Raw = lat_u32x2;
+    static __device__ __forceinline__ void request(const lat_i32x4& d, __amdgpu_buffer_rsrc_t, int voff, int soff, Raw& r) {
+        asm volatile("buffer_load_dwordx2 %0, %1, %2, %3 offen" : "+v"(r) : "v"(voff), "s"(d), "s"(soff) : "memory");
+    }
+    static __device__ __forceinline__ void unpack(const Raw& v, float* x, float* y) {
         x[0] = lat_clamp(__uint_as_float(v.x)); y[0] = lat_clamp(__uint_as_float(v.y));
     }
-    static __device__ __forceinline__ void store(__amdgpu_buffer_rsrc_t r, int voff, int soff, const float* v) {
-        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[0]), r, voff, soff, 0);
+    static __device__ __forceinline__ void put(const lat_i32x4& d, __amdgpu_buffer_rsrc_t, int voff, int soff, const float* v) {
+        asm volatile("buffer_store_dword %0, %1, %2, %3 offen" ::"v"(v[0]), "v"(voff), "s"(d), "s"(soff) : "memory");
     }
 };
 template <> struct LatIO<float, 2> {
-    static __device__ __forceinline__ void load_xy(__amdgpu_buffer_rsrc_t r, int voff, int soff, float* x, float* y) {
-        const lat_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+    static constexpr bool kHand = true;
+    using Raw = lat_u32x4;
+    static __device__ __forceinline__ void request(const lat_i32x4& d, __amdgpu_buffer_rsrc_t, int voff, int soff, Raw& r) {
+        asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "+v"(r) : "v"(voff), "s"(d), "s"(soff) : "memory");
+    }
+    static __device__ __forceinline__ void unpack(const Raw& v, float* x, float* y) {
         x[0] = lat_clamp(__uint_as_float(v.x)); y[0] = lat_clamp(__uint_as_float(v.y));
         x[1] = lat_clamp(__uint_as_float(v.z)); y[1] = lat_clamp(__uint_as_float(v.w));
     }
-    static __device__ __forceinline__ void store(__amdgpu_buffer_rsrc_t r, int voff, int soff, const float* v) {
+    static __device__ __forceinline__ void put(const lat_i32x4& d, __amdgpu_buffer_rsrc_t, int voff, int soff, const float* v) {
         const lat_u32x2 w = {__float_as_uint(v[0]), __float_as_uint(v[1])};
-        __builtin_amdgcn_raw_buffer_store_b64(w, r, voff, soff, 0);
+        asm volatile("buffer_store_dwordx2 %0, %1, %2, %3 offen" ::"v"(w), "v"(voff), "s"(d), "s"(soff) : "memory");
     }
 };
 template <> struct LatIO<double, 1> {
-    static __device__ __forceinline__ void load_xy(__amdgpu_buffer_rsrc_t r, int voff, int soff, double* x, double* y) {
-        const lat_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+    static constexpr bool kHand = false;
+    using Raw = lat_u32x4;
+    static __device__ __forceinline__ void request(const lat_i32x4&, __amdgpu_buffer_rsrc_t r, int voff, int soff, Raw& v) {
+        v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+    }
+    static __device__ __forceinline__ void unpack(const Raw& v, double* x, double* y) {
         x[0] = lat_clamp(lat_f64(v.x, v.y)); y[0] = lat_clamp(lat_f64(v.z, v.w));
     }
-    static __device__ __forceinline__ void store(__amdgpu_buffer_rsrc_t r, int voff, int soff, const double* v) {
+    static __device__ __forceinline__ void put(const lat_i32x4&, __amdgpu_buffer_rsrc_t r, int voff, int soff, const double* v) {
         const lat_u32x2 w = {static_cast<unsigned>(__double2loint(v[0])), static_cast<unsigned>(__double2hiint(v[0]))};
         __builtin_amdgcn_raw_buffer_store_b64(w, r, voff, soff, 0);
     }
 };
 template <> struct LatIO<double, 2> {
-    static __device__ __forceinline__ void load_xy(__amdgpu_buffer_rsrc_t r, int voff, int soff, double* x, double* y) {
-        const lat_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
-        const lat_u32x4 w = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff + 16, 0);
-        x[0] = lat_clamp(lat_f64(v.x, v.y)); y[0] = lat_clamp(lat_f64(v.z, v.w));
-        x[1] = lat_clamp(lat_f64(w.x, w.y)); y[1] = lat_clamp(lat_f64(w.z, w.w));
+    static constexpr bool kHand = false;
+    struct Raw { lat_u32x4 a, b; };
+    static __device__ __forceinline__ void request(const lat_i32x4&, __amdgpu_buffer_rsrc_t r, int voff, int soff, Raw& v) {
+        v.a = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+        v.b = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff + 16, 0);
     }
-    static __device__ __forceinline__ void store(__amdgpu_buffer_rsrc_t r, int voff, int soff, const double* v) {
+    static __device__ __forceinline__ void unpack(const Raw& v, double* x, double* y) {
+        x[0] = lat_clamp(lat_f64(v.a.x, v.a.y)); y[0] = lat_clamp(lat_f64(v.a.z, v.a.w));
+        x[1] = lat_clamp(lat_f64(v.b.x, v.b.y)); y[1] = lat_clamp(lat_f64(v.b.z, v.b.w));
+    }
+    static __device__ __forceinline__ void put(const lat_i32x4&, __amdgpu_buffer_rsrc_t r, int voff, int soff, const double* v) {
         const lat_u32x4 w = {static_cast<unsigned>(__double2loint(v[0])), static_cast<unsigned>(__double2hiint(v[0])),
                              static_cast<unsigned>(__double2loint(v[1])), static_cast<unsigned>(__double2hiint(v[1]))};
         __builtin_amdgcn_raw_buffer_store_b128(w, r, voff, soff, 0);
@@ -955,8 +996,12 @@ __device__ __forceinline__ void lattice_body(
     constexpr int C = LatChunk<L, MAXW, COLS>::C;
     constexpr bool MULTI = MAXW > 1;
     using IO = LatIO<L, COLS>;
+    using Raw = typename IO::Raw;
+    constexpr bool HAND = IO::kHand;
+    static_assert(COLS <= 2 && C <= 16 && C <= kLatPad, "two columns per lane at most; a chunk's boundary values fit one DPP row; the beta sweep's overshoot stays in the front padding");
     __shared__ L ring[MAXW][2][C];
     __shared__ double ringoff[MAXW][2];
+    __shared__ L dump[MULTI ? MAXW : 1][MULTI ? 64 + C : 1];      // where the lanes that are NOT the boundary lane put their copy of a step's hand-off value
     const int u0 = tid * COLS;                       // first of this lane's COLS adjacent columns
     const int lane = tid & 63;
     const int wave = uniform(tid >> 6);
@@ -983,6 +1028,11 @@ __device__ __forceinline__ void lattice_body(
     const int vc = in_row ? u0 * static_cast<int>(sizeof(LogPair<L>)) : kLatOob;
     const int vb = in_row ? u0 * static_cast<int>(sizeof(L)) : kLatOob;
     double* off = (dir == 0 ? offa : offb) + (static_cast<size_t>(b) * W + wave) * Dp + kLatPad;
+    // the same three ranges for the hand-issued accesses (LatIO; `off` from its first pad entry, like the rows)
+    const lat_i32x4 dc = lat_desc(lp2 + lat_sample_pair(b, maxT, maxU, Up), static_cast<int>(Dp * cell_row));
+    const lat_i32x4 db = lat_desc((dir == 0 ? alpha : beta) + sample0, static_cast<int>(Dp * beta_row));
+    const lat_i32x4 dof = lat_desc(off - kLatPad, static_cast<int>(Dp * sizeof(double)));
+    (void)dc; (void)db; (void)dof;
     const L NEG = log_zero<L>();
     unsigned Tb_eff[COLS];                           // cell (n-u,u) in the lattice <=> (unsigned)(n-u) < Tb_eff
 #pragma unroll
@@ -990,12 +1040,40 @@ __device__ __forceinline__ void lattice_body(
     const int nsteps = Db - 1;
     const int nchunks = (nsteps + C - 1) / C;
     const int nslots = nchunks + (MULTI ? W - 1 : 0);
-    (void)ring; (void)ringoff;
+    (void)ring; (void)ringoff; (void)dump;
     double Coff = 0.0, Cused = 0.0;
-    L bufA_b[C][COLS], bufA_l[C][COLS], bufB_b[C][COLS], bufB_l[C][COLS], hist[C][COLS];
+    Raw rawA[C], rawB[C];                // operand rows of this chunk and of the next, as they arrive (LatIO: clamped when used)
+    L hist[C][COLS];
     int jprev = -1;                      // chunk whose results are still in `hist`
     const int ulast = Ub - 1;            // the column of the terminal cell, its owner lane and slot
     const bool own_last = (ulast / COLS) == tid;
+    // Order of the memory traffic of a chunk (fp32: counted by hand, LatIO): the C result rows of the PREVIOUS chunk and its
+    // offsets (C + 1 stores), then the C operand rows of the NEXT chunk (C loads), then the wait for THIS chunk's rows --
+    // everything issued since them may stay in flight: 2C + 1 accesses, or C for a wavefront's first chunk (nothing to flush).
+    auto await = [&](Raw (&cur)[C], bool flushed) {
+        if constexpr (HAND) {
+            if (flushed) lat_wait_vm<2 * C + 1>(); else lat_wait_vm<C>();
+            lat_pin(cur);
+        }
+    };
+    // Slots: wavefront w works on chunk j in slot j + lead (the wavefronts form a pipeline along the diagonal direction),
+    // every wavefront passes every slot's barrier.  The two chunk buffers have FIXED roles per call site, so no value that
+    // is still in flight ever crosses a control-flow merge (where the compiler might copy it).
+    auto sweep = [&](int lead, auto& chunk) {
+        if constexpr (MULTI) for (int i = 0; i < lead; ++i) lds_barrier();
+        for (int j = 0; j < nchunks; j += 2) {
+            chunk(lead + j, j, rawA, rawB);
+            if constexpr (MULTI) lds_barrier();
+            if (j + 1 < nchunks) {
+                chunk(lead + j + 1, j + 1, rawB, rawA);
+                if constexpr (MULTI) lds_barrier();
+            }
+        }
+        if constexpr (MULTI) for (int i = lead + nchunks; i < nslots; ++i) lds_barrier();
+    };
+    auto drain = [&]() {                 // the last prefetch (nobody reads it) and the stores: before the registers go to other values / the read-back
+        if constexpr (HAND) { lat_wait_vm<0>(); lat_pin(rawA); lat_pin(rawB); }
+    };
 
     if (dir == 0) {
         // ------------------------------- alpha -------------------------------
@@ -1007,50 +1085,57 @@ __device__ __forceinline__ void lattice_body(
         L up = NEG;                                  // shifted neighbour values; lane 0 stays "zero" (see the step)
         if (tid == 0) lat_store1(rb, 0, kLatPad * beta_row, L(0));
         if (lane == 0) off[0] = 0.0;
-        auto fetch = [&](int j, L (*xb)[COLS], L (*xl)[COLS]) {     // chunk j: diagonals j*C+1 .. j*C+C read SOURCE rows j*C .. j*C+C-1
+        auto fetch = [&](int j, Raw (&dst)[C]) {     // chunk j: diagonals j*C+1 .. j*C+C read SOURCE rows j*C .. j*C+C-1
 #pragma unroll
-            for (int k = 0; k < C; ++k) IO::load_xy(rc, vc, (j * C + k + kLatPad) * cell_row, xb[k], xl[k]);
+            for (int k = 0; k < C; ++k) IO::request(dc, rc, vc, (j * C + k + kLatPad) * cell_row, dst[k]);
         };
         auto flush = [&]() {                        // results of chunk jprev (issued BEFORE the next prefetch)
 #pragma unroll
-            for (int k = 0; k < C; ++k) IO::store(rb, vb, (jprev * C + 1 + k + kLatPad) * beta_row, hist[k]);
-            if (lane < C) off[jprev * C + 1 + lane] = Cused;
+            for (int k = 0; k < C; ++k) IO::put(db, rb, vb, (jprev * C + 1 + k + kLatPad) * beta_row, hist[k]);
+            if constexpr (HAND) lat_put_f64(dof, lane < C ? lane * 8 : kLatOob, (jprev * C + 1 + kLatPad) * 8, Cused);
+            else if (lane < C) off[jprev * C + 1 + lane] = Cused;
         };
-        auto chunk = [&](int s, int j, const L (*pb)[COLS], const L (*pl)[COLS], L (*nb)[COLS], L (*nl)[COLS]) {
-            if (jprev >= 0) flush();
-            fetch(j + 1 < nchunks ? j + 1 : j, nb, nl);       // (stay inside the back padding)
+        auto chunk = [&](int s, int j, Raw (&cur)[C], Raw (&nxt)[C]) {
+            const bool flushed = jprev >= 0;
+            if (flushed) flush();
+            fetch(j + 1 < nchunks ? j + 1 : j, nxt);          // (stay inside the back padding)
             L inv = NEG;
             if constexpr (MULTI) {
-                if (wave > 0) {
-                    const L raw = ring[wave - 1][(s - 1) & 1][lane & (C - 1)];
-                    const L delta = static_cast<L>(ringoff[wave - 1][(s - 1) & 1] - Coff);
-                    inv = raw + delta;
-                }
+                if (wave > 0) inv = ring[wave - 1][(s - 1) & 1][lane & (C - 1)] + static_cast<L>(ringoff[wave - 1][(s - 1) & 1] - Coff);
             }
-            L outv = NEG;
+            // Boundary hand-off between the wavefronts of a block, per step, WITHOUT the scalar unit (round 5: a readlane + writelane
+            // pair each way per step, with their hazard nops): IN -- the C values of the chunk sit in the lanes of `inv` (lane l
+            // holds value l mod C), a row shift by k brings value k to lane 0, and the wave shift below KEEPS lane 0 of its
+            // first operand; OUT -- every lane stores its step value to LDS, the boundary lane into the ring slot, the others
+            // into a scratch row nobody reads (one ds_write per step, no EXEC games).
+            L* wr = nullptr;
+            if constexpr (MULTI) wr = lane == 63 ? &ring[wave][s & 1][0] : &dump[wave][lane];
+            await(cur, flushed);
 #pragma unroll
             for (int k = 0; k < C; ++k) {
-                L stay[COLS], emit[COLS];
+                L pb[COLS], pl[COLS], stay[COLS], emit[COLS];
+                IO::unpack(cur[k], pb, pl);
 #pragma unroll
-                for (int c = 0; c < COLS; ++c) { stay[c] = a[c] + pb[k][c]; emit[c] = a[c] + pl[k][c]; }
+                for (int c = 0; c < COLS; ++c) { stay[c] = a[c] + pb[c]; emit[c] = a[c] + pl[c]; }
                 // the left neighbour of column u0 is the previous lane's last column; lane 0 of `up` is never
-                // written by the shift (it keeps the "zero" it started with) or takes the neighbouring
-                // wavefront's boundary value: one readlane + one writelane, no branch
-                up = wave_shr1(up, emit[COLS - 1]);
+                // written by the shift: it keeps the "zero" it started with, or (MULTI) the neighbouring wavefront's boundary value
                 if constexpr (MULTI) {
-                    up = lane_set(up, lane_get(inv, k), 0);
-                    outv = lane_set(outv, lane_get(emit[COLS - 1], 63), k);
+                    up = wave_shr1(row_shl(inv, k), emit[COLS - 1]);
+                    wr[k] = emit[COLS - 1];
+                } else {
+                    up = wave_shr1(up, emit[COLS - 1]);
                 }
-                a[0] = log2_add(stay[0], up);
-#pragma unroll
-                for (int c = 1; c < COLS; ++c) a[c] = log2_add(stay[c], emit[c - 1]);
+                if constexpr (COLS == 2) {
+                    log2_add_x2(stay[0], up, stay[1], emit[0], a[0], a[1]);    // the lane's two columns, interleaved
+                } else {
+                    a[0] = log2_add(stay[0], up);
+                }
 #pragma unroll
                 for (int c = 0; c < COLS; ++c) hist[k][c] = a[c];
             }
             jprev = j;
             Cused = Coff;
             if constexpr (MULTI) {
-                if (lane < C) ring[wave][s & 1][lane] = outv;
                 if (lane == 0) ringoff[wave][s & 1] = Coff;
             }
             if (j + 1 < nchunks) {                       // re-centre (not after the final diagonal)
@@ -1068,24 +1153,10 @@ __device__ __forceinline__ void lattice_body(
                 }
             }
         };
-        fetch(0, bufA_b, bufA_l);
-        for (int s = 0; s < nslots; s += 2) {
-            {
-                const int j = MULTI ? s - wave : s;
-                if (j >= 0 && j < nchunks) {
-                    if (j & 1) chunk(s, j, bufB_b, bufB_l, bufA_b, bufA_l); else chunk(s, j, bufA_b, bufA_l, bufB_b, bufB_l);
-                }
-                if constexpr (MULTI) lds_barrier();
-            }
-            if (s + 1 < nslots) {
-                const int j = MULTI ? s + 1 - wave : s + 1;
-                if (j >= 0 && j < nchunks) {
-                    if (j & 1) chunk(s + 1, j, bufB_b, bufB_l, bufA_b, bufA_l); else chunk(s + 1, j, bufA_b, bufA_l, bufB_b, bufB_l);
-                }
-                if constexpr (MULTI) lds_barrier();
-            }
-        }
+        fetch(0, rawA);
+        sweep(MULTI ? wave : 0, chunk);
         if (jprev >= 0) flush();
+        drain();
         if (own_last) {
             // alpha(T-1,U-1): read it back (this thread wrote it), with the offset that was current when its
             // diagonal was stored
@@ -1120,42 +1191,45 @@ __device__ __forceinline__ void lattice_body(
         }
         L right = NEG;                               // shifted neighbour values; lane 63 stays "zero"
         if (lane == 0) off[Db - 1] = 0.0;
-        auto fetch = [&](int j, L (*xb)[COLS], L (*xl)[COLS]) {     // chunk j: steps i = j*C .. j*C+C-1, TARGET rows n = Db-2-i
+        auto fetch = [&](int j, Raw (&dst)[C]) {     // chunk j: steps i = j*C .. j*C+C-1, TARGET rows n = Db-2-i
 #pragma unroll
-            for (int k = 0; k < C; ++k) IO::load_xy(rc, vc, (Db - 2 - (j * C + k) + kLatPad) * cell_row, xb[k], xl[k]);
+            for (int k = 0; k < C; ++k) IO::request(dc, rc, vc, (Db - 2 - (j * C + k) + kLatPad) * cell_row, dst[k]);
         };
-        auto flush = [&]() {
+        auto flush = [&]() {                        // (i may run past nsteps - 1 in the last chunk: those rows lie in the front padding)
 #pragma unroll
-            for (int k = 0; k < C; ++k) IO::store(rb, vb, (Db - 2 - (jprev * C + k) + kLatPad) * beta_row, hist[k]);
-            if (lane < C) off[Db - 2 - (jprev * C + lane)] = Cused;
+            for (int k = 0; k < C; ++k) IO::put(db, rb, vb, (Db - 2 - (jprev * C + k) + kLatPad) * beta_row, hist[k]);
+            if constexpr (HAND) lat_put_f64(dof, lane < C ? (C - 1 - lane) * 8 : kLatOob, (Db - 2 - jprev * C - (C - 1) + kLatPad) * 8, Cused);
+            else if (lane < C) off[Db - 2 - (jprev * C + lane)] = Cused;
         };
-        auto chunk = [&](int s, int j, const L (*pb)[COLS], const L (*pl)[COLS], L (*nb)[COLS], L (*nl)[COLS]) {
-            if (jprev >= 0) flush();
-            fetch(j + 1 < nchunks ? j + 1 : j, nb, nl);      // (no rows below the front padding)
+        auto chunk = [&](int s, int j, Raw (&cur)[C], Raw (&nxt)[C]) {
+            const bool flushed = jprev >= 0;
+            if (flushed) flush();
+            fetch(j + 1 < nchunks ? j + 1 : j, nxt);         // (no rows below the front padding)
             L inv = NEG;
             if constexpr (MULTI) {
-                if (wave + 1 < W) {
-                    const L raw = ring[wave + 1][(s - 1) & 1][lane & (C - 1)];
-                    const L delta = static_cast<L>(ringoff[wave + 1][(s - 1) & 1] - Coff);
-                    inv = raw + delta;
-                }
+                if (wave + 1 < W) inv = ring[wave + 1][(s - 1) & 1][lane & (C - 1)] + static_cast<L>(ringoff[wave + 1][(s - 1) & 1] - Coff);
             }
-            L outv = NEG;
+            L* wr = nullptr;                                 // (hand-off as in the alpha sweep, mirrored: in at lane 63, out from lane 0)
+            if constexpr (MULTI) wr = lane == 0 ? &ring[wave][s & 1][0] : &dump[wave][lane];
+            await(cur, flushed);
 #pragma unroll
             for (int k = 0; k < C; ++k) {
+                L pb[COLS], pl[COLS];
+                IO::unpack(cur[k], pb, pl);
                 // the right neighbour of the lane's last column is the next lane's first; lane 63 of `right`
-                // keeps its "zero" or takes the neighbouring wavefront's boundary value
-                right = wave_shl1(right, bv[0]);
+                // keeps its "zero" or (MULTI) takes the neighbouring wavefront's boundary value: value k sits in lane 48 + k
+                // (C = 8: 56 + k) of `inv`, a row shift right by C - 1 - k brings it to lane 63
                 if constexpr (MULTI) {
-                    right = lane_set(right, lane_get(inv, k), 63);
-                    outv = lane_set(outv, lane_get(bv[0], 0), k);
+                    right = wave_shl1(row_shr(inv, C - 1 - k), bv[0]);
+                    wr[k] = bv[0];
+                } else {
+                    right = wave_shl1(right, bv[0]);
                 }
                 L nv[COLS];
-#pragma unroll
-                for (int c = 0; c < COLS; ++c) {
-                    const L stay = bv[c] + pb[k][c];
-                    const L emit = (c + 1 < COLS ? bv[c + 1 < COLS ? c + 1 : c] : right) + pl[k][c];
-                    nv[c] = log2_add(stay, emit);
+                if constexpr (COLS == 2) {
+                    log2_add_x2(bv[0] + pb[0], bv[1] + pl[0], bv[1] + pb[1], right + pl[1], nv[0], nv[1]);   // interleaved
+                } else {
+                    nv[0] = log2_add(bv[0] + pb[0], right + pl[0]);
                 }
 #pragma unroll
                 for (int c = 0; c < COLS; ++c) { bv[c] = nv[c]; hist[k][c] = nv[c]; }
@@ -1163,7 +1237,6 @@ __device__ __forceinline__ void lattice_body(
             jprev = j;
             Cused = Coff;
             if constexpr (MULTI) {
-                if (lane < C) ring[wave][s & 1][lane] = outv;
                 if (lane == 0) ringoff[wave][s & 1] = Coff;
             }
             if (j + 1 < nchunks) {
@@ -1179,24 +1252,10 @@ __device__ __forceinline__ void lattice_body(
                 }
             }
         };
-        fetch(0, bufA_b, bufA_l);
-        for (int s = 0; s < nslots; s += 2) {
-            {
-                const int j = MULTI ? s - (W - 1 - wave) : s;
-                if (j >= 0 && j < nchunks) {
-                    if (j & 1) chunk(s, j, bufB_b, bufB_l, bufA_b, bufA_l); else chunk(s, j, bufA_b, bufA_l, bufB_b, bufB_l);
-                }
-                if constexpr (MULTI) lds_barrier();
-            }
-            if (s + 1 < nslots) {
-                const int j = MULTI ? s + 1 - (W - 1 - wave) : s + 1;
-                if (j >= 0 && j < nchunks) {
-                    if (j & 1) chunk(s + 1, j, bufB_b, bufB_l, bufA_b, bufA_l); else chunk(s + 1, j, bufA_b, bufA_l, bufB_b, bufB_l);
-                }
-                if constexpr (MULTI) lds_barrier();
-            }
-        }
+        fetch(0, rawA);
+        sweep(MULTI ? W - 1 - wave : 0, chunk);
         if (jprev >= 0) flush();
+        drain();
         if (tid == 0) {
             const L b0 = lat_load1(rb, 0, kLatPad * beta_row, L(0));
             ll_bwd[b] = (static_cast<double>(b0) + (nsteps == 0 ? 0.0 : Cused)) * kLn2;

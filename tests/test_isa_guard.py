@@ -62,3 +62,33 @@ def test_no_kernel_uses_scratch_or_spills_vector_registers(device_asm):
     assert len(res.kernels(joint)) > 40 and res.check(joint) == []      # (fp32 storage; bf16 and fp16 have code objects of their own: other_asms)
     assert guard.check(joint) == []                      # the second copy of lattice_lin_kernel (the joint translation unit's)
     assert res.check(joint.replace(".private_segment_fixed_size: 0", ".private_segment_fixed_size: 64", 1)) != []   # the check can fail
+
+
+def test_hand_issued_lattice_accesses_have_no_sgpr_hazard_and_no_row_touched_in_flight(device_asm):
+    """The fp32 lattice kernels issue their row loads and stores as inline assembly with exact `s_waitcnt vmcnt` (LatIO): the
+    compiler's hazard recogniser and wait insertion do not look inside.  tools/check_lattice_asm_hazards.py checks the ISA of every
+    translation unit for the two things that can go wrong -- and must trip on the form that did (a v_readfirstlane of a row offset
+    right in front of the access: 139 GPU tests failed on it in round 6) and on a copy of a row that has not arrived."""
+    guard, asm = device_asm
+    import check_lattice_asm_hazards as haz
+    units = {"rnnt_gpu": asm, "rnnt_joint": guard.joint_asm}
+    units.update(guard.other_asms)
+    accesses = 0
+    for name, text in units.items():
+        seen, n, problems = haz.check(text)
+        assert problems == [], (name, problems[:3])
+        accesses += n
+    assert accesses > 1000
+    lines = asm.split("\n")
+    start = next(i for i, l in enumerate(lines) if l.startswith("_ZN4rnntL14lattice_kernelIfLi4ELi2EE") and ":" in l)
+    acc = [i for i in range(start, len(lines)) if lines[i].lstrip().startswith("buffer_load_dwordx4") and ";;#ASMSTART" in "".join(lines[i - 3:i])]
+    i = acc[20]
+    soff = lines[i].split(",")[-1].split()[0]                      # its scalar offset register
+    bad = list(lines)
+    bad.insert(i, "\tv_readfirstlane_b32 %s, v5" % soff)           # directly in front of the access, behind the block's own s_mov
+    assert any("wait state" in p for p in haz.check("\n".join(bad))[2])
+    dst = lines[i].split()[1].rstrip(",")                          # v[a:b]
+    lo = int(dst[2:].split(":")[0])
+    bad = list(lines)
+    bad.insert(i + 2, "\tv_mov_b32_e32 v250, v%d" % lo)            # a copy right after the request
+    assert any("in flight" in p for p in haz.check("\n".join(bad))[2])

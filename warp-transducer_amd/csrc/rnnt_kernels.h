@@ -873,9 +873,16 @@ __device__ __forceinline__ double lat_f64(unsigned lo, unsigned hi) { return __h
 typedef int lat_i32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ lat_i32x4 lat_desc(const void* p, int bytes) {
     const unsigned long long a = reinterpret_cast<unsigned long long>(p);
-    return lat_i32x4{static_cast<int>(a), static_cast<int>((a >> 32) & 0xffffu), bytes, 0x00020000};
+    return lat_i32x4{__builtin_amdgcn_readfirstlane(static_cast<int>(a)), __builtin_amdgcn_readfirstlane(static_cast<int>((a >> 32) & 0xffffu)),
+                     __builtin_amdgcn_readfirstlane(bytes), 0x00020000};     // (wave-uniform by construction; said so for the "s" operands)
 }
-template <int N> __device__ __forceinline__ void lat_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+template <int N> __device__ __forceinline__ void lat_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N)); }
+template <typename R> __device__ __forceinline__ void lat_pin(R& r) { asm volatile("" : "+v"(r)); }
+// Scalar operands: a vector-memory instruction that reads an SGPR written by the VECTOR unit less than five wait states earlier
+// reads the old value, and the compiler's hazard recogniser does not look into an asm block: when it keeps a row offset in a
+// vector register (it does, when scalar registers run short) its v_readfirstlane lands right in front of the access.  Every
+// access therefore takes its offset through an s_mov of its own (the scalar unit's reads are interlocked, and a scalar write
+// needs no wait states before a vector-memory read); the descriptors are checked in the ISA (tools/check_lattice_asm_hazards.py).
 // "These registers are written by loads the compiler cannot see": every later use depends on this statement, so none moves
 // above the wait that precedes it, and the registers stay allocated to the rows until here.
 template <typename R> __device__ __forceinline__ void lat_pin(R (&r)[16]) {
@@ -886,7 +893,8 @@ template <typename R> __device__ __forceinline__ void lat_pin(R (&r)[8]) {
     asm volatile("" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7]));
 }
 __device__ __forceinline__ void lat_put_f64(const lat_i32x4& d, int voff, int soff, double v) {
-    asm volatile("buffer_store_dwordx2 %0, %1, %2, %3 offen" ::"v"(v), "v"(voff), "s"(d), "s"(soff) : "memory");
+    int t;
+    asm volatile("s_mov_b32 %0, %4\n\tbuffer_store_dwordx2 %1, %2, %3, %0 offen" : "=&s"(t) : "v"(v), "v"(voff), "s"(d), "s"(soff));
 }
 
 template <typename L, int COLS> struct LatIO;
@@ -894,20 +902,23 @@ template <> struct LatIO<float, 1> {
     static constexpr bool kHand = true;
     using Raw = lat_u32x2;
     static __device__ __forceinline__ void request(const lat_i32x4& d, __amdgpu_buffer_rsrc_t, int voff, int soff, Raw& r) {
-        asm volatile("buffer_load_dwordx2 %0, %1, %2, %3 offen" : "+v"(r) : "v"(voff), "s"(d), "s"(soff) : "memory");
+        int t;
+        asm volatile("s_mov_b32 %1, %4\n\tbuffer_load_dwordx2 %0, %2, %3, %1 offen" : "+v"(r), "=&s"(t) : "v"(voff), "s"(d), "s"(soff));
     }
     static __device__ __forceinline__ void unpack(const Raw& v, float* x, float* y) {
         x[0] = lat_clamp(__uint_as_float(v.x)); y[0] = lat_clamp(__uint_as_float(v.y));
     }
     static __device__ __forceinline__ void put(const lat_i32x4& d, __amdgpu_buffer_rsrc_t, int voff, int soff, const float* v) {
-        asm volatile("buffer_store_dword %0, %1, %2, %3 offen" ::"v"(v[0]), "v"(voff), "s"(d), "s"(soff) : "memory");
+        int t;
+        asm volatile("s_mov_b32 %0, %4\n\tbuffer_store_dword %1, %2, %3, %0 offen" : "=&s"(t) : "v"(v[0]), "v"(voff), "s"(d), "s"(soff));
     }
 };
 template <> struct LatIO<float, 2> {
     static constexpr bool kHand = true;
     using Raw = lat_u32x4;
     static __device__ __forceinline__ void request(const lat_i32x4& d, __amdgpu_buffer_rsrc_t, int voff, int soff, Raw& r) {
-        asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "+v"(r) : "v"(voff), "s"(d), "s"(soff) : "memory");
+        int t;
+        asm volatile("s_mov_b32 %1, %4\n\tbuffer_load_dwordx4 %0, %2, %3, %1 offen" : "+v"(r), "=&s"(t) : "v"(voff), "s"(d), "s"(soff));
     }
     static __device__ __forceinline__ void unpack(const Raw& v, float* x, float* y) {
         x[0] = lat_clamp(__uint_as_float(v.x)); y[0] = lat_clamp(__uint_as_float(v.y));
@@ -915,7 +926,8 @@ template <> struct LatIO<float, 2> {
     }
     static __device__ __forceinline__ void put(const lat_i32x4& d, __amdgpu_buffer_rsrc_t, int voff, int soff, const float* v) {
         const lat_u32x2 w = {__float_as_uint(v[0]), __float_as_uint(v[1])};
-        asm volatile("buffer_store_dwordx2 %0, %1, %2, %3 offen" ::"v"(w), "v"(voff), "s"(d), "s"(soff) : "memory");
+        int t;
+        asm volatile("s_mov_b32 %0, %4\n\tbuffer_store_dwordx2 %1, %2, %3, %0 offen" : "=&s"(t) : "v"(w), "v"(voff), "s"(d), "s"(soff));
     }
 };
 template <> struct LatIO<double, 1> {
@@ -998,6 +1010,7 @@ __device__ __forceinline__ void lattice_body(
     using IO = LatIO<L, COLS>;
     using Raw = typename IO::Raw;
     constexpr bool HAND = IO::kHand;
+    constexpr bool SPREAD = MAXW <= 4;     // one wavefront per SIMD: its accesses go out one pair per step (see await); two per SIMD: as one burst per chunk
     static_assert(COLS <= 2 && C <= 16 && C <= kLatPad, "two columns per lane at most; a chunk's boundary values fit one DPP row; the beta sweep's overshoot stays in the front padding");
     __shared__ L ring[MAXW][2][C];
     __shared__ double ringoff[MAXW][2];
@@ -1047,13 +1060,30 @@ __device__ __forceinline__ void lattice_body(
     int jprev = -1;                      // chunk whose results are still in `hist`
     const int ulast = Ub - 1;            // the column of the terminal cell, its owner lane and slot
     const bool own_last = (ulast / COLS) == tid;
-    // Order of the memory traffic of a chunk (fp32: counted by hand, LatIO): the C result rows of the PREVIOUS chunk and its
-    // offsets (C + 1 stores), then the C operand rows of the NEXT chunk (C loads), then the wait for THIS chunk's rows --
-    // everything issued since them may stay in flight: 2C + 1 accesses, or C for a wavefront's first chunk (nothing to flush).
-    auto await = [&](Raw (&cur)[C], bool flushed) {
-        if constexpr (HAND) {
-            if (flushed) lat_wait_vm<2 * C + 1>(); else lat_wait_vm<C>();
-            lat_pin(cur);
+    // Memory traffic of a chunk (fp32: counted by hand, LatIO), SPREAD over its steps -- a burst of 2C + 1 accesses at the chunk's
+    // start fills the CU's vector-memory queue and the wavefront, alone on its SIMD, sits in the issue stage until it drains
+    // (round 6: 0.220 ms on config 4 against 0.141 with no traffic at all).  Step k of chunk j: store result row k of chunk
+    // j - 1 (still in hist[k]), request operand row k of chunk j + 1, wait for operand row k of chunk j, compute.  That row was
+    // requested one chunk ago; since then the wavefront has issued 2 (C - 1 - k) accesses in the steps after it, the offsets'
+    // store, and 2 (k + 1) in this chunk: 2C + 1, the same for every step.  To keep the count the same for a wavefront's FIRST
+    // chunk, its stores are issued too, parked out of range (dropped by the range check, counted like any other), and the
+    // prologue that requests chunk 0 pairs every request with such a store.
+    // Blocks of more than four wavefronts (two per SIMD, the other one fills the stall) keep the burst -- same order, same count,
+    // one wait per chunk: spreading cost them 10 % (U = 512: 0.344 -> 0.381 ms).
+    auto await = [&](Raw& row) {
+        if constexpr (HAND && SPREAD) { lat_wait_vm<2 * C + 1>(); lat_pin(row); }
+    };
+    auto burst = [&](auto& put, auto& request, int vput, int jn, Raw (&cur)[C], Raw (&nxt)[C]) {
+        if constexpr (!SPREAD) {
+#pragma unroll
+            for (int k = 0; k < C; ++k) put(k, vput);
+#pragma unroll
+            for (int k = 0; k < C; ++k) request(jn, k, nxt[k]);
+            if constexpr (HAND) {
+                lat_wait_vm<2 * C + 1>();
+#pragma unroll
+                for (int k = 0; k < C; ++k) lat_pin(cur[k]);
+            }
         }
     };
     // Slots: wavefront w works on chunk j in slot j + lead (the wavefronts form a pipeline along the diagonal direction),
@@ -1072,7 +1102,24 @@ __device__ __forceinline__ void lattice_body(
         if constexpr (MULTI) for (int i = lead + nchunks; i < nslots; ++i) lds_barrier();
     };
     auto drain = [&]() {                 // the last prefetch (nobody reads it) and the stores: before the registers go to other values / the read-back
-        if constexpr (HAND) { lat_wait_vm<0>(); lat_pin(rawA); lat_pin(rawB); }
+        if constexpr (HAND) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); lat_pin(rawA); lat_pin(rawB); }
+    };
+    auto prologue = [&](auto& put, auto& request) {      // chunk 0's rows, in the rhythm of a chunk (see await)
+#pragma unroll
+        for (int k = 0; k < C; ++k) {
+#pragma unroll
+            for (int c = 0; c < COLS; ++c) hist[k][c] = L(0);
+            if constexpr (HAND) IO::put(db, rb, kLatOob, 0, hist[k]);
+            request(0, k, rawA[k]);
+        }
+    };
+    auto epilogue = [&](auto& put, auto& put_off) {      // the last chunk's results
+        if (jprev >= 0) {
+            put_off(true);
+#pragma unroll
+            for (int k = 0; k < C; ++k) put(k, vb);
+        }
+        drain();
     };
 
     if (dir == 0) {
@@ -1085,20 +1132,19 @@ __device__ __forceinline__ void lattice_body(
         L up = NEG;                                  // shifted neighbour values; lane 0 stays "zero" (see the step)
         if (tid == 0) lat_store1(rb, 0, kLatPad * beta_row, L(0));
         if (lane == 0) off[0] = 0.0;
-        auto fetch = [&](int j, Raw (&dst)[C]) {     // chunk j: diagonals j*C+1 .. j*C+C read SOURCE rows j*C .. j*C+C-1
-#pragma unroll
-            for (int k = 0; k < C; ++k) IO::request(dc, rc, vc, (j * C + k + kLatPad) * cell_row, dst[k]);
-        };
-        auto flush = [&]() {                        // results of chunk jprev (issued BEFORE the next prefetch)
-#pragma unroll
-            for (int k = 0; k < C; ++k) IO::put(db, rb, vb, (jprev * C + 1 + k + kLatPad) * beta_row, hist[k]);
-            if constexpr (HAND) lat_put_f64(dof, lane < C ? lane * 8 : kLatOob, (jprev * C + 1 + kLatPad) * 8, Cused);
-            else if (lane < C) off[jprev * C + 1 + lane] = Cused;
+        // chunk j: diagonals j*C+1 .. j*C+C read SOURCE rows j*C .. j*C+C-1 and write result rows j*C+1 .. j*C+C
+        auto request = [&](int j, int k, Raw& dst) { IO::request(dc, rc, vc, (j * C + k + kLatPad) * cell_row, dst); };
+        auto put = [&](int k, int vput) { IO::put(db, rb, vput, (jprev * C + 1 + k + kLatPad) * beta_row, hist[k]); };
+        auto put_off = [&](bool flushed) {
+            if constexpr (HAND) lat_put_f64(dof, (flushed && lane < C) ? lane * 8 : kLatOob, (jprev * C + 1 + kLatPad) * 8, Cused);
+            else if (flushed && lane < C) off[jprev * C + 1 + lane] = Cused;
         };
         auto chunk = [&](int s, int j, Raw (&cur)[C], Raw (&nxt)[C]) {
             const bool flushed = jprev >= 0;
-            if (flushed) flush();
-            fetch(j + 1 < nchunks ? j + 1 : j, nxt);          // (stay inside the back padding)
+            const int vput = flushed ? vb : kLatOob;         // a wavefront's first chunk has nothing to store yet
+            const int jn = j + 1 < nchunks ? j + 1 : j;      // (stay inside the back padding)
+            put_off(flushed);
+            burst(put, request, vput, jn, cur, nxt);
             L inv = NEG;
             if constexpr (MULTI) {
                 if (wave > 0) inv = ring[wave - 1][(s - 1) & 1][lane & (C - 1)] + static_cast<L>(ringoff[wave - 1][(s - 1) & 1] - Coff);
@@ -1110,10 +1156,11 @@ __device__ __forceinline__ void lattice_body(
             // into a scratch row nobody reads (one ds_write per step, no EXEC games).
             L* wr = nullptr;
             if constexpr (MULTI) wr = lane == 63 ? &ring[wave][s & 1][0] : &dump[wave][lane];
-            await(cur, flushed);
 #pragma unroll
             for (int k = 0; k < C; ++k) {
                 L pb[COLS], pl[COLS], stay[COLS], emit[COLS];
+                if constexpr (SPREAD) { put(k, vput); request(jn, k, nxt[k]); }
+                await(cur[k]);
                 IO::unpack(cur[k], pb, pl);
 #pragma unroll
                 for (int c = 0; c < COLS; ++c) { stay[c] = a[c] + pb[c]; emit[c] = a[c] + pl[c]; }
@@ -1153,10 +1200,9 @@ __device__ __forceinline__ void lattice_body(
                 }
             }
         };
-        fetch(0, rawA);
+        prologue(put, request);
         sweep(MULTI ? wave : 0, chunk);
-        if (jprev >= 0) flush();
-        drain();
+        epilogue(put, put_off);
         if (own_last) {
             // alpha(T-1,U-1): read it back (this thread wrote it), with the offset that was current when its
             // diagonal was stored
@@ -1191,30 +1237,30 @@ __device__ __forceinline__ void lattice_body(
         }
         L right = NEG;                               // shifted neighbour values; lane 63 stays "zero"
         if (lane == 0) off[Db - 1] = 0.0;
-        auto fetch = [&](int j, Raw (&dst)[C]) {     // chunk j: steps i = j*C .. j*C+C-1, TARGET rows n = Db-2-i
-#pragma unroll
-            for (int k = 0; k < C; ++k) IO::request(dc, rc, vc, (Db - 2 - (j * C + k) + kLatPad) * cell_row, dst[k]);
-        };
-        auto flush = [&]() {                        // (i may run past nsteps - 1 in the last chunk: those rows lie in the front padding)
-#pragma unroll
-            for (int k = 0; k < C; ++k) IO::put(db, rb, vb, (Db - 2 - (jprev * C + k) + kLatPad) * beta_row, hist[k]);
-            if constexpr (HAND) lat_put_f64(dof, lane < C ? (C - 1 - lane) * 8 : kLatOob, (Db - 2 - jprev * C - (C - 1) + kLatPad) * 8, Cused);
-            else if (lane < C) off[Db - 2 - (jprev * C + lane)] = Cused;
+        // chunk j: steps i = j*C .. j*C+C-1, TARGET rows n = Db-2-i (i may run past nsteps - 1 in the last chunk: those rows lie in the front padding)
+        auto request = [&](int j, int k, Raw& dst) { IO::request(dc, rc, vc, (Db - 2 - (j * C + k) + kLatPad) * cell_row, dst); };
+        auto put = [&](int k, int vput) { IO::put(db, rb, vput, (Db - 2 - (jprev * C + k) + kLatPad) * beta_row, hist[k]); };
+        auto put_off = [&](bool flushed) {
+            if constexpr (HAND) lat_put_f64(dof, (flushed && lane < C) ? (C - 1 - lane) * 8 : kLatOob, (Db - 2 - jprev * C - (C - 1) + kLatPad) * 8, Cused);
+            else if (flushed && lane < C) off[Db - 2 - (jprev * C + lane)] = Cused;
         };
         auto chunk = [&](int s, int j, Raw (&cur)[C], Raw (&nxt)[C]) {
             const bool flushed = jprev >= 0;
-            if (flushed) flush();
-            fetch(j + 1 < nchunks ? j + 1 : j, nxt);         // (no rows below the front padding)
+            const int vput = flushed ? vb : kLatOob;
+            const int jn = j + 1 < nchunks ? j + 1 : j;      // (no rows below the front padding)
+            put_off(flushed);
+            burst(put, request, vput, jn, cur, nxt);
             L inv = NEG;
             if constexpr (MULTI) {
                 if (wave + 1 < W) inv = ring[wave + 1][(s - 1) & 1][lane & (C - 1)] + static_cast<L>(ringoff[wave + 1][(s - 1) & 1] - Coff);
             }
             L* wr = nullptr;                                 // (hand-off as in the alpha sweep, mirrored: in at lane 63, out from lane 0)
             if constexpr (MULTI) wr = lane == 0 ? &ring[wave][s & 1][0] : &dump[wave][lane];
-            await(cur, flushed);
 #pragma unroll
             for (int k = 0; k < C; ++k) {
                 L pb[COLS], pl[COLS];
+                if constexpr (SPREAD) { put(k, vput); request(jn, k, nxt[k]); }
+                await(cur[k]);
                 IO::unpack(cur[k], pb, pl);
                 // the right neighbour of the lane's last column is the next lane's first; lane 63 of `right`
                 // keeps its "zero" or (MULTI) takes the neighbouring wavefront's boundary value: value k sits in lane 48 + k
@@ -1252,10 +1298,9 @@ __device__ __forceinline__ void lattice_body(
                 }
             }
         };
-        fetch(0, rawA);
+        prologue(put, request);
         sweep(MULTI ? W - 1 - wave : 0, chunk);
-        if (jprev >= 0) flush();
-        drain();
+        epilogue(put, put_off);
         if (tid == 0) {
             const L b0 = lat_load1(rb, 0, kLatPad * beta_row, L(0));
             ll_bwd[b] = (static_cast<double>(b0) + (nsteps == 0 ? 0.0 : Cused)) * kLn2;

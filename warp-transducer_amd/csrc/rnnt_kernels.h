@@ -880,9 +880,10 @@ template <int N> __device__ __forceinline__ void lat_wait_vm() { asm volatile("s
 template <typename R> __device__ __forceinline__ void lat_pin(R& r) { asm volatile("" : "+v"(r)); }
 // Scalar operands: a vector-memory instruction that reads an SGPR written by the VECTOR unit less than five wait states earlier
 // reads the old value, and the compiler's hazard recogniser does not look into an asm block: when it keeps a row offset in a
-// vector register (it does, when scalar registers run short) its v_readfirstlane lands right in front of the access.  Every
-// access therefore takes its offset through an s_mov of its own (the scalar unit's reads are interlocked, and a scalar write
-// needs no wait states before a vector-memory read); the descriptors are checked in the ISA (tools/check_lattice_asm_hazards.py).
+// vector register (it does, when scalar registers run short) its v_readfirstlane lands right in front of the access.  A row
+// access therefore ADVANCES a running offset with an s_add of its own, inside its asm block (the scalar unit's reads are
+// interlocked, and a scalar write needs no wait states before a vector-memory read) -- which also spares the multiply and add per
+// access the compiler spent on the offsets; the descriptors are checked in the ISA (tools/check_lattice_asm_hazards.py).
 // "These registers are written by loads the compiler cannot see": every later use depends on this statement, so none moves
 // above the wait that precedes it, and the registers stay allocated to the rows until here.
 template <typename R> __device__ __forceinline__ void lat_pin(R (&r)[16]) {
@@ -901,64 +902,64 @@ template <typename L, int COLS> struct LatIO;
 template <> struct LatIO<float, 1> {
     static constexpr bool kHand = true;
     using Raw = lat_u32x2;
-    static __device__ __forceinline__ void request(const lat_i32x4& d, __amdgpu_buffer_rsrc_t, int voff, int soff, Raw& r) {
-        int t;
-        asm volatile("s_mov_b32 %1, %4\n\tbuffer_load_dwordx2 %0, %2, %3, %1 offen" : "+v"(r), "=&s"(t) : "v"(voff), "s"(d), "s"(soff));
+    static __device__ __forceinline__ void request(const lat_i32x4& d, __amdgpu_buffer_rsrc_t, int voff, int& run, int stride, Raw& r) {
+        asm volatile("s_add_i32 %1, %1, %4\n\tbuffer_load_dwordx2 %0, %2, %3, %1 offen" : "+v"(r), "+s"(run) : "v"(voff), "s"(d), "s"(stride) : "scc");
     }
     static __device__ __forceinline__ void unpack(const Raw& v, float* x, float* y) {
         x[0] = lat_clamp(__uint_as_float(v.x)); y[0] = lat_clamp(__uint_as_float(v.y));
     }
-    static __device__ __forceinline__ void put(const lat_i32x4& d, __amdgpu_buffer_rsrc_t, int voff, int soff, const float* v) {
-        int t;
-        asm volatile("s_mov_b32 %0, %4\n\tbuffer_store_dword %1, %2, %3, %0 offen" : "=&s"(t) : "v"(v[0]), "v"(voff), "s"(d), "s"(soff));
+    static __device__ __forceinline__ void put(const lat_i32x4& d, __amdgpu_buffer_rsrc_t, int voff, int& run, int stride, const float* v) {
+        asm volatile("s_add_i32 %0, %0, %4\n\tbuffer_store_dword %1, %2, %3, %0 offen" : "+s"(run) : "v"(v[0]), "v"(voff), "s"(d), "s"(stride) : "scc");
     }
 };
 template <> struct LatIO<float, 2> {
     static constexpr bool kHand = true;
     using Raw = lat_u32x4;
-    static __device__ __forceinline__ void request(const lat_i32x4& d, __amdgpu_buffer_rsrc_t, int voff, int soff, Raw& r) {
-        int t;
-        asm volatile("s_mov_b32 %1, %4\n\tbuffer_load_dwordx4 %0, %2, %3, %1 offen" : "+v"(r), "=&s"(t) : "v"(voff), "s"(d), "s"(soff));
+    static __device__ __forceinline__ void request(const lat_i32x4& d, __amdgpu_buffer_rsrc_t, int voff, int& run, int stride, Raw& r) {
+        asm volatile("s_add_i32 %1, %1, %4\n\tbuffer_load_dwordx4 %0, %2, %3, %1 offen" : "+v"(r), "+s"(run) : "v"(voff), "s"(d), "s"(stride) : "scc");
     }
     static __device__ __forceinline__ void unpack(const Raw& v, float* x, float* y) {
         x[0] = lat_clamp(__uint_as_float(v.x)); y[0] = lat_clamp(__uint_as_float(v.y));
         x[1] = lat_clamp(__uint_as_float(v.z)); y[1] = lat_clamp(__uint_as_float(v.w));
     }
-    static __device__ __forceinline__ void put(const lat_i32x4& d, __amdgpu_buffer_rsrc_t, int voff, int soff, const float* v) {
+    static __device__ __forceinline__ void put(const lat_i32x4& d, __amdgpu_buffer_rsrc_t, int voff, int& run, int stride, const float* v) {
         const lat_u32x2 w = {__float_as_uint(v[0]), __float_as_uint(v[1])};
-        int t;
-        asm volatile("s_mov_b32 %0, %4\n\tbuffer_store_dwordx2 %1, %2, %3, %0 offen" : "=&s"(t) : "v"(w), "v"(voff), "s"(d), "s"(soff));
+        asm volatile("s_add_i32 %0, %0, %4\n\tbuffer_store_dwordx2 %1, %2, %3, %0 offen" : "+s"(run) : "v"(w), "v"(voff), "s"(d), "s"(stride) : "scc");
     }
 };
 template <> struct LatIO<double, 1> {
     static constexpr bool kHand = false;
     using Raw = lat_u32x4;
-    static __device__ __forceinline__ void request(const lat_i32x4&, __amdgpu_buffer_rsrc_t r, int voff, int soff, Raw& v) {
-        v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+    static __device__ __forceinline__ void request(const lat_i32x4&, __amdgpu_buffer_rsrc_t r, int voff, int& run, int stride, Raw& v) {
+        run += stride;
+        v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, run, 0);
     }
     static __device__ __forceinline__ void unpack(const Raw& v, double* x, double* y) {
         x[0] = lat_clamp(lat_f64(v.x, v.y)); y[0] = lat_clamp(lat_f64(v.z, v.w));
     }
-    static __device__ __forceinline__ void put(const lat_i32x4&, __amdgpu_buffer_rsrc_t r, int voff, int soff, const double* v) {
+    static __device__ __forceinline__ void put(const lat_i32x4&, __amdgpu_buffer_rsrc_t r, int voff, int& run, int stride, const double* v) {
         const lat_u32x2 w = {static_cast<unsigned>(__double2loint(v[0])), static_cast<unsigned>(__double2hiint(v[0]))};
-        __builtin_amdgcn_raw_buffer_store_b64(w, r, voff, soff, 0);
+        run += stride;
+        __builtin_amdgcn_raw_buffer_store_b64(w, r, voff, run, 0);
     }
 };
 template <> struct LatIO<double, 2> {
     static constexpr bool kHand = false;
     struct Raw { lat_u32x4 a, b; };
-    static __device__ __forceinline__ void request(const lat_i32x4&, __amdgpu_buffer_rsrc_t r, int voff, int soff, Raw& v) {
-        v.a = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
-        v.b = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff + 16, 0);
+    static __device__ __forceinline__ void request(const lat_i32x4&, __amdgpu_buffer_rsrc_t r, int voff, int& run, int stride, Raw& v) {
+        run += stride;
+        v.a = __builtin_amdgcn_raw_buffer_load_b128(r, voff, run, 0);
+        v.b = __builtin_amdgcn_raw_buffer_load_b128(r, voff, run + 16, 0);
     }
     static __device__ __forceinline__ void unpack(const Raw& v, double* x, double* y) {
         x[0] = lat_clamp(lat_f64(v.a.x, v.a.y)); y[0] = lat_clamp(lat_f64(v.a.z, v.a.w));
         x[1] = lat_clamp(lat_f64(v.b.x, v.b.y)); y[1] = lat_clamp(lat_f64(v.b.z, v.b.w));
     }
-    static __device__ __forceinline__ void put(const lat_i32x4&, __amdgpu_buffer_rsrc_t r, int voff, int soff, const double* v) {
+    static __device__ __forceinline__ void put(const lat_i32x4&, __amdgpu_buffer_rsrc_t r, int voff, int& run, int stride, const double* v) {
+        run += stride;
         const lat_u32x4 w = {static_cast<unsigned>(__double2loint(v[0])), static_cast<unsigned>(__double2hiint(v[0])),
                              static_cast<unsigned>(__double2loint(v[1])), static_cast<unsigned>(__double2hiint(v[1]))};
-        __builtin_amdgcn_raw_buffer_store_b128(w, r, voff, soff, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(w, r, voff, run, 0);
     }
 };
 // Single elements (the corner cells), addressed by their column's byte offset.
@@ -1058,6 +1059,7 @@ __device__ __forceinline__ void lattice_body(
     Raw rawA[C], rawB[C];                // operand rows of this chunk and of the next, as they arrive (LatIO: clamped when used)
     L hist[C][COLS];
     int jprev = -1;                      // chunk whose results are still in `hist`
+    int ld_run = 0, st_run = 0;          // running row offsets of the operand requests / the result stores (bytes)
     const int ulast = Ub - 1;            // the column of the terminal cell, its owner lane and slot
     const bool own_last = (ulast / COLS) == tid;
     // Memory traffic of a chunk (fp32: counted by hand, LatIO), SPREAD over its steps -- a burst of 2C + 1 accesses at the chunk's
@@ -1109,7 +1111,7 @@ __device__ __forceinline__ void lattice_body(
         for (int k = 0; k < C; ++k) {
 #pragma unroll
             for (int c = 0; c < COLS; ++c) hist[k][c] = L(0);
-            if constexpr (HAND) IO::put(db, rb, kLatOob, 0, hist[k]);
+            if constexpr (HAND) { int parked = 0; IO::put(db, rb, kLatOob, parked, 0, hist[k]); }
             request(0, k, rawA[k]);
         }
     };
@@ -1133,8 +1135,15 @@ __device__ __forceinline__ void lattice_body(
         if (tid == 0) lat_store1(rb, 0, kLatPad * beta_row, L(0));
         if (lane == 0) off[0] = 0.0;
         // chunk j: diagonals j*C+1 .. j*C+C read SOURCE rows j*C .. j*C+C-1 and write result rows j*C+1 .. j*C+C
-        auto request = [&](int j, int k, Raw& dst) { IO::request(dc, rc, vc, (j * C + k + kLatPad) * cell_row, dst); };
-        auto put = [&](int k, int vput) { IO::put(db, rb, vput, (jprev * C + 1 + k + kLatPad) * beta_row, hist[k]); };
+        // (row k of a chunk: the running offset is aimed one row short at k = 0 and advanced by the access itself -- LatIO)
+        auto request = [&](int j, int k, Raw& dst) {
+            if (k == 0) ld_run = (j * C + kLatPad - 1) * cell_row;
+            IO::request(dc, rc, vc, ld_run, cell_row, dst);
+        };
+        auto put = [&](int k, int vput) {
+            if (k == 0) st_run = (jprev * C + kLatPad) * beta_row;
+            IO::put(db, rb, vput, st_run, beta_row, hist[k]);
+        };
         auto put_off = [&](bool flushed) {
             if constexpr (HAND) lat_put_f64(dof, (flushed && lane < C) ? lane * 8 : kLatOob, (jprev * C + 1 + kLatPad) * 8, Cused);
             else if (flushed && lane < C) off[jprev * C + 1 + lane] = Cused;
@@ -1238,8 +1247,14 @@ __device__ __forceinline__ void lattice_body(
         L right = NEG;                               // shifted neighbour values; lane 63 stays "zero"
         if (lane == 0) off[Db - 1] = 0.0;
         // chunk j: steps i = j*C .. j*C+C-1, TARGET rows n = Db-2-i (i may run past nsteps - 1 in the last chunk: those rows lie in the front padding)
-        auto request = [&](int j, int k, Raw& dst) { IO::request(dc, rc, vc, (Db - 2 - (j * C + k) + kLatPad) * cell_row, dst); };
-        auto put = [&](int k, int vput) { IO::put(db, rb, vput, (Db - 2 - (jprev * C + k) + kLatPad) * beta_row, hist[k]); };
+        auto request = [&](int j, int k, Raw& dst) {
+            if (k == 0) ld_run = (Db - 1 - j * C + kLatPad) * cell_row;
+            IO::request(dc, rc, vc, ld_run, -cell_row, dst);
+        };
+        auto put = [&](int k, int vput) {
+            if (k == 0) st_run = (Db - 1 - jprev * C + kLatPad) * beta_row;
+            IO::put(db, rb, vput, st_run, -beta_row, hist[k]);
+        };
         auto put_off = [&](bool flushed) {
             if constexpr (HAND) lat_put_f64(dof, (flushed && lane < C) ? (C - 1 - lane) * 8 : kLatOob, (Db - 2 - jprev * C - (C - 1) + kLatPad) * 8, Cused);
             else if (flushed && lane < C) off[Db - 2 - (jprev * C + lane)] = Cused;

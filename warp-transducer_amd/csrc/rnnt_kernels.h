@@ -893,12 +893,6 @@ template <typename R> __device__ __forceinline__ void lat_pin(R (&r)[16]) {
 template <typename R> __device__ __forceinline__ void lat_pin(R (&r)[8]) {
     asm volatile("" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7]));
 }
-// One dword per 128-byte line of rows the sweep will ask for TWO chunks from now: the lines are on their way to the L2 when the
-// real request goes out (the value is never looked at).
-__device__ __forceinline__ void lat_touch(const lat_i32x4& d, int voff, int soff, unsigned& sink) {
-    int t;
-    asm volatile("s_mov_b32 %1, %4\n\tbuffer_load_dword %0, %2, %3, %1 offen" : "+v"(sink), "=&s"(t) : "v"(voff), "s"(d), "s"(soff));
-}
 __device__ __forceinline__ void lat_put_f64(const lat_i32x4& d, int voff, int soff, double v) {
     int t;
     asm volatile("s_mov_b32 %0, %4\n\tbuffer_store_dwordx2 %1, %2, %3, %0 offen" : "=&s"(t) : "v"(v), "v"(voff), "s"(d), "s"(soff));
@@ -1017,11 +1011,6 @@ __device__ __forceinline__ void lattice_body(
     using IO = LatIO<L, COLS>;
     using Raw = typename IO::Raw;
     constexpr bool HAND = IO::kHand;
-#ifndef LAT_TOUCH
-#define LAT_TOUCH 0
-#endif
-    constexpr bool TOUCH = LAT_TOUCH && IO::kHand && MAXW <= 4 && COLS == 2 && C == 16;   // two-column fp32 lanes: a wavefront's row is 1 KB = 8 lines
-    constexpr int NT = TOUCH ? C / 8 : 0;                  // touch loads per chunk (8 rows x 8 lines each), counted like any access
     constexpr bool SPREAD = MAXW <= 4;     // one wavefront per SIMD: its accesses go out one pair per step (see await); two per SIMD: as one burst per chunk
     static_assert(COLS <= 2 && C <= 16 && C <= kLatPad, "two columns per lane at most; a chunk's boundary values fit one DPP row; the beta sweep's overshoot stays in the front padding");
     __shared__ L ring[MAXW][2][C];
@@ -1084,7 +1073,7 @@ __device__ __forceinline__ void lattice_body(
     // Blocks of more than four wavefronts (two per SIMD, the other one fills the stall) keep the burst -- same order, same count,
     // one wait per chunk: spreading cost them 10 % (U = 512: 0.344 -> 0.381 ms).
     auto await = [&](Raw& row) {
-        if constexpr (HAND && SPREAD) { lat_wait_vm<2 * C + 1 + NT>(); lat_pin(row); }
+        if constexpr (HAND && SPREAD) { lat_wait_vm<2 * C + 1>(); lat_pin(row); }
     };
     auto burst = [&](auto& put, auto& request, int vput, int jn, Raw (&cur)[C], Raw (&nxt)[C]) {
         if constexpr (!SPREAD) {
@@ -1114,21 +1103,8 @@ __device__ __forceinline__ void lattice_body(
         }
         if constexpr (MULTI) for (int i = lead + nchunks; i < nslots; ++i) lds_barrier();
     };
-    // touch loads: lane l looks at line l % 8 of row l / 8 of a group of eight rows; `first_row` = the LOWEST of the eight
-    unsigned sink0 = 0, sink1 = 0;
-    const int pf_byte = wave * 64 * COLS * static_cast<int>(sizeof(LogPair<L>)) + (lane & 7) * 128;
-    const int pf_v = pf_byte < cell_row ? pf_byte + (lane >> 3) * cell_row : kLatOob;
-    auto touch = [&](int first_row, bool real) {
-        if constexpr (TOUCH) {
-            const int v = real ? pf_v : kLatOob;
-            lat_touch(dc, v, (first_row + kLatPad) * cell_row, sink0);
-            lat_touch(dc, v, (first_row + 8 + kLatPad) * cell_row, sink1);
-        }
-    };
-    (void)pf_v; (void)sink0; (void)sink1;
     auto drain = [&]() {                 // the last prefetch (nobody reads it) and the stores: before the registers go to other values / the read-back
         if constexpr (HAND) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); lat_pin(rawA); lat_pin(rawB); }
-        if constexpr (TOUCH) { lat_pin(sink0); lat_pin(sink1); }
     };
     auto prologue = [&](auto& put, auto& request) {      // chunk 0's rows, in the rhythm of a chunk (see await)
 #pragma unroll
@@ -1177,7 +1153,6 @@ __device__ __forceinline__ void lattice_body(
             const int vput = flushed ? vb : kLatOob;         // a wavefront's first chunk has nothing to store yet
             const int jn = j + 1 < nchunks ? j + 1 : j;      // (stay inside the back padding)
             put_off(flushed);
-            touch((j + 2) * C, j + 2 < nchunks);
             burst(put, request, vput, jn, cur, nxt);
             L inv = NEG;
             if constexpr (MULTI) {
@@ -1234,7 +1209,6 @@ __device__ __forceinline__ void lattice_body(
                 }
             }
         };
-        touch(C, 1 < nchunks);
         prologue(put, request);
         sweep(MULTI ? wave : 0, chunk);
         epilogue(put, put_off);
@@ -1290,7 +1264,6 @@ __device__ __forceinline__ void lattice_body(
             const int vput = flushed ? vb : kLatOob;
             const int jn = j + 1 < nchunks ? j + 1 : j;      // (no rows below the front padding)
             put_off(flushed);
-            touch(Db - 2 - ((j + 2) * C + C - 1), j + 2 < nchunks);
             burst(put, request, vput, jn, cur, nxt);
             L inv = NEG;
             if constexpr (MULTI) {
@@ -1340,7 +1313,6 @@ __device__ __forceinline__ void lattice_body(
                 }
             }
         };
-        touch(Db - 2 - (2 * C - 1), 1 < nchunks);
         prologue(put, request);
         sweep(MULTI ? W - 1 - wave : 0, chunk);
         epilogue(put, put_off);

@@ -1011,7 +1011,6 @@ __device__ __forceinline__ void lattice_body(
     using IO = LatIO<L, COLS>;
     using Raw = typename IO::Raw;
     constexpr bool HAND = IO::kHand;
-    constexpr bool SPREAD = MAXW <= 4;     // one wavefront per SIMD: its accesses go out one pair per step (see await); two per SIMD: as one burst per chunk
     static_assert(COLS <= 2 && C <= 16 && C <= kLatPad, "two columns per lane at most; a chunk's boundary values fit one DPP row; the beta sweep's overshoot stays in the front padding");
     __shared__ L ring[MAXW][2][C];
     __shared__ double ringoff[MAXW][2];
@@ -1070,23 +1069,10 @@ __device__ __forceinline__ void lattice_body(
     // store, and 2 (k + 1) in this chunk: 2C + 1, the same for every step.  To keep the count the same for a wavefront's FIRST
     // chunk, its stores are issued too, parked out of range (dropped by the range check, counted like any other), and the
     // prologue that requests chunk 0 pairs every request with such a store.
-    // Blocks of more than four wavefronts (two per SIMD, the other one fills the stall) keep the burst -- same order, same count,
-    // one wait per chunk: spreading cost them 10 % (U = 512: 0.344 -> 0.381 ms).
+    // (Measured against the burst on one box, alternating -- profiles/r06/lattice_spread_ab.log: never slower; -11 % at N = 16, -10 % at
+    // U = 512, -2 % with two wavefronts per SIMD, U > 512; equal where the kernel runs at the memory system's rate, N = 64.)
     auto await = [&](Raw& row) {
-        if constexpr (HAND && SPREAD) { lat_wait_vm<2 * C + 1>(); lat_pin(row); }
-    };
-    auto burst = [&](auto& put, auto& request, int vput, int jn, Raw (&cur)[C], Raw (&nxt)[C]) {
-        if constexpr (!SPREAD) {
-#pragma unroll
-            for (int k = 0; k < C; ++k) put(k, vput);
-#pragma unroll
-            for (int k = 0; k < C; ++k) request(jn, k, nxt[k]);
-            if constexpr (HAND) {
-                lat_wait_vm<2 * C + 1>();
-#pragma unroll
-                for (int k = 0; k < C; ++k) lat_pin(cur[k]);
-            }
-        }
+        if constexpr (HAND) { lat_wait_vm<2 * C + 1>(); lat_pin(row); }
     };
     // Slots: wavefront w works on chunk j in slot j + lead (the wavefronts form a pipeline along the diagonal direction),
     // every wavefront passes every slot's barrier.  The two chunk buffers have FIXED roles per call site, so no value that
@@ -1153,7 +1139,6 @@ __device__ __forceinline__ void lattice_body(
             const int vput = flushed ? vb : kLatOob;         // a wavefront's first chunk has nothing to store yet
             const int jn = j + 1 < nchunks ? j + 1 : j;      // (stay inside the back padding)
             put_off(flushed);
-            burst(put, request, vput, jn, cur, nxt);
             L inv = NEG;
             if constexpr (MULTI) {
                 if (wave > 0) inv = ring[wave - 1][(s - 1) & 1][lane & (C - 1)] + static_cast<L>(ringoff[wave - 1][(s - 1) & 1] - Coff);
@@ -1168,7 +1153,8 @@ __device__ __forceinline__ void lattice_body(
 #pragma unroll
             for (int k = 0; k < C; ++k) {
                 L pb[COLS], pl[COLS], stay[COLS], emit[COLS];
-                if constexpr (SPREAD) { put(k, vput); request(jn, k, nxt[k]); }
+                put(k, vput);
+                request(jn, k, nxt[k]);
                 await(cur[k]);
                 IO::unpack(cur[k], pb, pl);
 #pragma unroll
@@ -1264,7 +1250,6 @@ __device__ __forceinline__ void lattice_body(
             const int vput = flushed ? vb : kLatOob;
             const int jn = j + 1 < nchunks ? j + 1 : j;      // (no rows below the front padding)
             put_off(flushed);
-            burst(put, request, vput, jn, cur, nxt);
             L inv = NEG;
             if constexpr (MULTI) {
                 if (wave + 1 < W) inv = ring[wave + 1][(s - 1) & 1][lane & (C - 1)] + static_cast<L>(ringoff[wave + 1][(s - 1) & 1] - Coff);
@@ -1274,7 +1259,8 @@ __device__ __forceinline__ void lattice_body(
 #pragma unroll
             for (int k = 0; k < C; ++k) {
                 L pb[COLS], pl[COLS];
-                if constexpr (SPREAD) { put(k, vput); request(jn, k, nxt[k]); }
+                put(k, vput);
+                request(jn, k, nxt[k]);
                 await(cur[k]);
                 IO::unpack(cur[k], pb, pl);
                 // the right neighbour of the lane's last column is the next lane's first; lane 63 of `right`

@@ -819,17 +819,19 @@ __global__ __launch_bounds__(256) void row_stats_tile2d_kernel(
 //   beta : b(n,u) = log2add(b(n+1,u) + lp_blank(n,u),   b(n+1,u+1) + lp_label(n,u))
 // (n = t+u; the skewed layout makes every per-diagonal access one coalesced row, addressed as
 // buffer base + scalar row offset + per-lane column offset).  The neighbour value moves one lane
-// through a DPP wave shift.  A lone wavefront is ISSUE-bound, not latency-bound (measured: a
-// dependent VALU op 3.5 ns, but ~2 ns per issued instruction of any kind), so the step is
-// stripped to its ten arithmetic instructions plus one load and one store:
+// through a DPP wave shift.  The step is stripped to its ten arithmetic instructions plus one load
+// and one store (a lone wavefront pays ~2 ns per issued instruction of any kind, a dependent VALU op
+// 3.5 ns; on long lattices the rest of the time is memory: EXPERIMENTS 13, the ablation table):
 //   * NO validity tests.  All state starts at the finite "log zero" sentinel and every loaded
 //     log-prob is clamped to [sentinel, 0] (one v_med3_f32), so columns that have not started
 //     yet stay at "zero", and whatever is computed for cells outside the T_b x U_b lattice can
 //     only flow further outside it (alpha moves to larger t,u; beta to smaller): probability
 //     mass that leaves the lattice never comes back, and none exists outside it to begin with.
 //   * Diagonals are processed in chunks of C with two register buffers: the log-probs of chunk
-//     j+1 are fetched while chunk j computes; the C results of a chunk are stored at the start
-//     of the next chunk, BEFORE its prefetch is issued, so the in-order vmcnt never drains.
+//     j+1 are fetched while chunk j computes, one row per step, and the C results of a chunk are
+//     stored during the next chunk, one row per step; the fp32 lattice issues both by hand and waits
+//     with the exact in-order count (LatIO, lattice_body: the compiler's own wait insertion made every
+//     chunk wait for its own prefetch).
 //   * At the end of a chunk the wavefront re-centres its values on their maximum (DPP reduction)
 //     and adds the shift to its fp64 offset (off[b][wave][n]); fp32 values stay O(10) however
 //     long T+U is, so the round-off of an un-scaled fp32 recursion (5e-3 on grads at T=1500,

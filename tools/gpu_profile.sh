@@ -16,6 +16,7 @@ for wl in $WLS; do
   rm -rf /tmp/prof_$wl
   rocprofv3 --kernel-trace --stats -d /tmp/prof_$wl -o trace -- python "$REPO/bench.py" --workload $wl --steps 20 \
       --warmup 3 --no-cpu-baseline --no-traffic-pass > "$OUT/${TAG}_trace_${wl}.log" 2>&1
+  grep "^{" "$OUT/${TAG}_trace_${wl}.log" | tail -1 > "$OUT/${TAG}_trace_${wl}.json"     # the TRACED process's own line: its HIP-event average of the dominant kernel is the one the trace must agree with
   db=$(find /tmp/prof_$wl -name "*.db" | head -1)
   [ -n "$db" ] && python "$REPO/tools/rocpd_summary.py" "$db" \
       "$TAG kernel trace: rocprofv3 --kernel-trace --stats -- python bench.py --workload $wl --steps 20 --warmup 3 --no-cpu-baseline" \

@@ -25,7 +25,7 @@ lib = _lib.lib()
 HALF = torch.bfloat16 if "--bf16" in sys.argv else (torch.float16 if "--fp16" in sys.argv else None)
 FUSED_ONLY = "--fused-only" in sys.argv or HALF is not None
 for name in [a for a in sys.argv[1:] if not a.startswith("--")] or ["c3"]:
-    N, T, U, A = SHAPES[name]
+    N, T, U, A = SHAPES[name] if name in SHAPES else tuple(int(x) for x in name.split(","))      # a named shape or N,T,U,A
     g0 = torch.Generator(device=dev); g0.manual_seed(1)
     f = torch.rand((N, T, A), generator=g0, device=dev)
     g = torch.rand((N, U, A), generator=g0, device=dev)
